@@ -1,0 +1,29 @@
+"""CPU oracle for the PhenDiff diffusion hot path -- TEST INFRASTRUCTURE ONLY.
+
+This package is a plain-PyTorch (CPU, fp32) restatement of the arithmetic that
+the reference executes on its hot path (class-conditional UNet forward, DDIM /
+inverse-DDIM scheduler updates, the conditional DDIM pipeline and the DDIB
+invert -> class-swap -> denoise loop).  It exists so that the HIP kernels in
+``phendiff_amd`` can be checked against an independent implementation.
+
+**Parity unpinned.**  The reference (`/root/reference`) is pure-Python glue over
+``diffusers==0.18.2`` (``environment.yaml:80``), which is neither vendored in the
+reference tree nor installable here (no network), and the reference ships no
+tests, golden vectors or fixtures for this path.  The restatement therefore
+follows the reference's own call sites plus the published diffusers-0.18.2
+algorithms (recorded in SURVEY.md Appendix A); it is pinned only by
+known-answer checks (parameter counts of public checkpoints, closed-form
+scheduler tables) -- see ``tests/test_oracle_*.py``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this package.  Nothing under ``phendiff_amd/`` does.
+"""
+
+from .schedulers_ref import DDIMSchedulerRef, DDIMInverseSchedulerRef  # noqa: F401
+from .unet_ref import CondUNet2DRef, UNET_CONFIGS  # noqa: F401
+from .pipeline_ref import (  # noqa: F401
+    ConditionalDDIMPipelineRef,
+    inversion_ref,
+    ddib_ref,
+    numpy_to_uint8,
+)

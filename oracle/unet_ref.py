@@ -1,0 +1,314 @@
+"""Oracle (test infrastructure): class-conditional UNet, plain PyTorch CPU fp32.
+
+Parity unpinned (see ``oracle/__init__.py``).  Restates what
+``src/cond_unet_2d/cond_unet_2d.py:73-362`` builds out of ``diffusers==0.18.2`` blocks
+(``get_down_block`` / ``get_up_block`` / ``UNetMidBlock2D`` / ``Timesteps`` /
+``TimestepEmbedding``).  Sub-module and parameter names are
+the diffusers in-memory ``state_dict`` names so weights are exchangeable with the product
+engine (``phendiff_amd.unet``) and with real PhenDiff checkpoints.
+
+Pinned by known answers only: parameter counts (15 725 443 ``super_small``; 62 826 243
+``small_denoiser_config``; 113 673 219 = public google/ddpm-celebahq-256;
+35 746 307 = public google/ddpm-cifar10-32) -- ``tests/test_oracle_unet.py``.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# Hyper-parameter VALUES of models_configs/denoiser/*.json (values, not files).
+UNET_CONFIGS = {
+    # models_configs/denoiser/super_small.json
+    "super_small": dict(
+        in_channels=3, out_channels=3, block_out_channels=(64, 128, 256), layers_per_block=2,
+        down_block_types=("DownBlock2D", "DownBlock2D", "AttnDownBlock2D"),
+        up_block_types=("AttnUpBlock2D", "UpBlock2D", "UpBlock2D"),
+        attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, num_class_embeds=2,
+        flip_sin_to_cos=True, freq_shift=0, downsample_padding=1, sample_size=128),
+    # models_configs/denoiser/small_denoiser_config.json
+    "small_denoiser_config": dict(
+        in_channels=3, out_channels=3, block_out_channels=(128, 256, 512), layers_per_block=2,
+        down_block_types=("DownBlock2D", "DownBlock2D", "AttnDownBlock2D"),
+        up_block_types=("AttnUpBlock2D", "UpBlock2D", "UpBlock2D"),
+        attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, num_class_embeds=2,
+        flip_sin_to_cos=True, freq_shift=0, downsample_padding=1, sample_size=128),
+    # models_configs/denoiser/orig_google_ddpm_model_denoiser.json (public ddpm-celebahq-256 layout)
+    "orig_google_ddpm": dict(
+        in_channels=3, out_channels=3, block_out_channels=(128, 128, 256, 256, 512, 512), layers_per_block=2,
+        down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+        up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4,
+        attention_head_dim=None, norm_num_groups=32, norm_eps=1e-6, num_class_embeds=None,
+        flip_sin_to_cos=False, freq_shift=1, downsample_padding=0, sample_size=256),
+    # public google/ddpm-cifar10-32 layout (known-answer check only)
+    "ddpm_cifar10": dict(
+        in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 256), layers_per_block=2,
+        down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D", "DownBlock2D"),
+        up_block_types=("UpBlock2D", "UpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
+        attention_head_dim=None, norm_num_groups=32, norm_eps=1e-6, num_class_embeds=None,
+        flip_sin_to_cos=False, freq_shift=1, downsample_padding=0, sample_size=32),
+}
+
+
+def timestep_embedding_ref(timesteps: torch.Tensor, dim: int, flip_sin_to_cos: bool, freq_shift: float):
+    """diffusers ``get_timestep_embedding`` (scale=1, max_period=10000); Appendix A.1."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32)
+    exponent = exponent / (half - freq_shift)
+    emb = torch.exp(exponent)
+    emb = timesteps[:, None].float() * emb[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    if dim % 2 == 1:
+        emb = F.pad(emb, (0, 1, 0, 0))
+    return emb
+
+
+class TimestepEmbeddingRef(nn.Module):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class ResnetBlock2DRef(nn.Module):
+    """Appendix A.3 (time_embedding_norm="default", output_scale_factor=1, dropout=0)."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, groups, eps, output_scale_factor=1.0):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps, affine=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+        self.output_scale_factor = output_scale_factor
+
+    def forward(self, x, temb):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return (x + h) / self.output_scale_factor
+
+
+class AttentionRef(nn.Module):
+    """Appendix A.4: GroupNorm -> q,k,v Linear (bias) -> SDPA over heads -> out Linear -> +residual."""
+
+    def __init__(self, channels, heads, groups, eps, rescale_output_factor=1.0):
+        super().__init__()
+        self.heads = heads
+        self.group_norm = nn.GroupNorm(groups, channels, eps=eps, affine=True)
+        self.to_q = nn.Linear(channels, channels)
+        self.to_k = nn.Linear(channels, channels)
+        self.to_v = nn.Linear(channels, channels)
+        self.to_out = nn.ModuleList([nn.Linear(channels, channels), nn.Dropout(0.0)])
+        self.rescale_output_factor = rescale_output_factor
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        residual = x
+        hs = x.view(b, c, h * w).transpose(1, 2)
+        hs = self.group_norm(hs.transpose(1, 2)).transpose(1, 2)
+        q, k, v = self.to_q(hs), self.to_k(hs), self.to_v(hs)
+        d = c // self.heads
+        q = q.view(b, -1, self.heads, d).transpose(1, 2)
+        k = k.view(b, -1, self.heads, d).transpose(1, 2)
+        v = v.view(b, -1, self.heads, d).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+        o = o.transpose(1, 2).reshape(b, -1, c)
+        o = self.to_out[0](o)
+        o = o.transpose(-1, -2).reshape(b, c, h, w)
+        return (o + residual) / self.rescale_output_factor
+
+
+class Downsample2DRef(nn.Module):
+    """Appendix A.5: 3x3 stride-2 conv; padding 1, or (0,1,0,1) zero-pad + pad-0 conv."""
+
+    def __init__(self, channels, padding):
+        super().__init__()
+        self.padding = padding
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        if self.padding == 0:
+            x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+        return self.conv(x)
+
+
+class Upsample2DRef(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlockRef(nn.Module):
+    def __init__(self, in_ch, out_ch, temb_ch, num_layers, groups, eps, add_downsample, downsample_padding,
+                 attn_head_dim=None):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2DRef(in_ch if i == 0 else out_ch, out_ch, temb_ch, groups, eps) for i in range(num_layers)])
+        self.attentions = None
+        if attn_head_dim is not None:
+            self.attentions = nn.ModuleList(
+                [AttentionRef(out_ch, out_ch // attn_head_dim, groups, eps) for _ in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2DRef(out_ch, downsample_padding)]) if add_downsample else None
+
+    def forward(self, h, temb):
+        outs = ()
+        for i, r in enumerate(self.resnets):
+            h = r(h, temb)
+            if self.attentions is not None:
+                h = self.attentions[i](h)
+            outs += (h,)
+        if self.downsamplers is not None:
+            h = self.downsamplers[0](h)
+            outs += (h,)
+        return h, outs
+
+
+class MidBlockRef(nn.Module):
+    def __init__(self, ch, temb_ch, groups, eps, attn_head_dim, add_attention=True):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2DRef(ch, ch, temb_ch, groups, eps) for _ in range(2)])
+        self.attentions = nn.ModuleList(
+            [AttentionRef(ch, ch // attn_head_dim, groups, eps) if add_attention else None])
+
+    def forward(self, h, temb):
+        h = self.resnets[0](h, temb)
+        if self.attentions[0] is not None:
+            h = self.attentions[0](h)
+        return self.resnets[1](h, temb)
+
+
+class UpBlockRef(nn.Module):
+    def __init__(self, in_ch, prev_out_ch, out_ch, temb_ch, num_layers, groups, eps, add_upsample, attn_head_dim=None):
+        super().__init__()
+        rs = []
+        for i in range(num_layers):
+            res_skip = in_ch if i == num_layers - 1 else out_ch
+            res_in = prev_out_ch if i == 0 else out_ch
+            rs.append(ResnetBlock2DRef(res_in + res_skip, out_ch, temb_ch, groups, eps))
+        self.resnets = nn.ModuleList(rs)
+        self.attentions = None
+        if attn_head_dim is not None:
+            self.attentions = nn.ModuleList(
+                [AttentionRef(out_ch, out_ch // attn_head_dim, groups, eps) for _ in range(num_layers)])
+        self.upsamplers = nn.ModuleList([Upsample2DRef(out_ch)]) if add_upsample else None
+
+    def forward(self, h, res_tuple, temb):
+        for i, r in enumerate(self.resnets):
+            res = res_tuple[-1]
+            res_tuple = res_tuple[:-1]
+            h = torch.cat([h, res], dim=1)
+            h = r(h, temb)
+            if self.attentions is not None:
+                h = self.attentions[i](h)
+        if self.upsamplers is not None:
+            h = self.upsamplers[0](h)
+        return h
+
+
+class CondUNet2DRef(nn.Module):
+    """``CustomCondUNet2DModel`` restated (``cond_unet_2d.py:29-362``)."""
+
+    def __init__(self, sample_size=None, in_channels=3, out_channels=3, block_out_channels=(224, 448, 672, 896),
+                 layers_per_block=2,
+                 down_block_types=("DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"),
+                 up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
+                 attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, num_class_embeds=None,
+                 flip_sin_to_cos=True, freq_shift=0, downsample_padding=1, add_attention=True):
+        super().__init__()
+        self.config = SimpleNamespace(
+            sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+            block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+            down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+            attention_head_dim=attention_head_dim, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
+            num_class_embeds=num_class_embeds, flip_sin_to_cos=flip_sin_to_cos, freq_shift=freq_shift,
+            downsample_padding=downsample_padding, center_input_sample=False, class_embed_type=None,
+            time_embedding_type="positional")
+        boc = list(block_out_channels)
+        ted = boc[0] * 4
+        self.time_embed_dim = ted  # cond_unet_2d.py:111-113
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)  # :127-129
+        self.time_embedding = TimestepEmbeddingRef(boc[0], ted)  # :143
+        self.class_embedding = nn.Embedding(num_class_embeds, ted) if num_class_embeds is not None else None  # :146-147
+        g, eps = norm_num_groups, norm_eps
+        self.down_blocks = nn.ModuleList()
+        out_ch = boc[0]
+        for i, t in enumerate(down_block_types):  # :160-182
+            in_ch, out_ch = out_ch, boc[i]
+            final = i == len(boc) - 1
+            hd = (attention_head_dim if attention_head_dim is not None else out_ch) if t == "AttnDownBlock2D" else None
+            self.down_blocks.append(DownBlockRef(in_ch, out_ch, ted, layers_per_block, g, eps, not final,
+                                                 downsample_padding, hd))
+        mid_hd = attention_head_dim if attention_head_dim is not None else boc[-1]
+        self.mid_block = MidBlockRef(boc[-1], ted, g, eps, mid_hd, add_attention)  # :185-197
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        out_ch = rev[0]
+        for i, t in enumerate(up_block_types):  # :200-228
+            prev, out_ch = out_ch, rev[i]
+            in_ch = rev[min(i + 1, len(boc) - 1)]
+            final = i == len(boc) - 1
+            hd = (attention_head_dim if attention_head_dim is not None else out_ch) if t == "AttnUpBlock2D" else None
+            self.up_blocks.append(UpBlockRef(in_ch, prev, out_ch, ted, layers_per_block + 1, g, eps, not final, hd))
+        self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)  # :236-238
+        self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)  # :240-242
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def embed(self, batch, timestep, class_labels=None, class_emb=None):
+        """cond_unet_2d.py:276-309 -> (B, time_embed_dim)."""
+        timesteps = timestep
+        if not torch.is_tensor(timesteps):
+            timesteps = torch.tensor([timesteps], dtype=torch.long)
+        elif timesteps.ndim == 0:
+            timesteps = timesteps[None]
+        timesteps = timesteps * torch.ones(batch, dtype=timesteps.dtype)
+        c = self.config
+        t_emb = timestep_embedding_ref(timesteps, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift)
+        emb = self.time_embedding(t_emb.to(self.dtype))
+        if self.class_embedding is not None:
+            if class_labels is None and class_emb is None:
+                raise ValueError("either class_labels or class_emb should be provided when doing class conditioning")
+            if class_emb is None:
+                class_emb = self.class_embedding(class_labels).to(self.dtype)
+            emb = emb + class_emb
+        return emb
+
+    def forward(self, sample, timestep, class_labels=None, class_emb=None, return_dict=True):
+        if class_labels is not None and class_emb is not None:
+            raise ValueError("Cannot specify both class_labels and class_emb")
+        emb = self.embed(sample.shape[0], timestep, class_labels, class_emb)
+        sample = self.conv_in(sample)
+        skips = (sample,)
+        for blk in self.down_blocks:
+            sample, res = blk(sample, emb)
+            skips += res
+        sample = self.mid_block(sample, emb)
+        for blk in self.up_blocks:
+            n = len(blk.resnets)
+            res, skips = skips[-n:], skips[:-n]
+            sample = blk(sample, res, emb)
+        sample = self.conv_out(F.silu(self.conv_norm_out(sample)))
+        if not return_dict:
+            return (sample,)
+        return SimpleNamespace(sample=sample)
