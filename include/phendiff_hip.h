@@ -1,0 +1,224 @@
+/*
+ * phendiff_hip.h -- C ABI of libphendiff_hip.so (MI355X / gfx950).
+ *
+ * The reference (thethomasboyer/PhenDiff) has no FFI of its own: its hot path is Python calling
+ * diffusers-0.18.2 modules which dispatch to ATen/cuDNN kernels.  Each entry point below replaces
+ * the device work of one such call site; the Python host (phendiff_amd/ *.py) mirrors the reference's
+ * object protocol on top of this ABI and INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pd_<op>() returns 0 on success, a negative pd_status on failure; pd_last_error() gives
+ *     the thread-local message.  No exceptions, no allocation, no host sync inside: all launches are
+ *     asynchronous on `stream` (a hipStream_t passed as void*) and are hipGraph-capturable.
+ *   - all pointers are caller-owned DEVICE pointers (the host takes them from live torch tensors).
+ *   - activations are NHWC (channel-contiguous) in `dtype` (PD_F32 or PD_BF16); the model boundary
+ *     tensors (UNet input sample / output prediction, scheduler state) are NCHW fp32 exactly as the
+ *     reference's tensors are.
+ *   - conv / linear weights are passed PRE-PACKED in the MFMA fragment order produced by
+ *     phendiff_amd/packing.py (documented at pd_conv_args.w_packed).
+ */
+#ifndef PHENDIFF_HIP_H_
+#define PHENDIFF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_ABI_VERSION 1
+
+typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
+typedef enum { PD_F32 = 0, PD_BF16 = 1 } pd_dtype;
+typedef enum { PD_PRED_EPSILON = 0, PD_PRED_SAMPLE = 1, PD_PRED_V = 2 } pd_pred_type;
+
+int pd_abi_version(void);
+const char* pd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * pd_temb: timestep + class embedding and every ResnetBlock2D's time_emb_proj in one launch.
+ * Replaces cond_unet_2d.py:289-309 (Timesteps -> TimestepEmbedding -> +class embedding) and the
+ * `time_emb_proj(SiLU(temb))` Linear of all ResnetBlock2D instances (diffusers resnet.py; reached via
+ * cond_unet_2d.py:171,187,217).  One output row per (timestep, class) pair, so a whole sampling
+ * trajectory (S steps x B images) is one call.
+ *   emb[r]  = W2 . silu(W1 . sincos(t[r]) + b1) + b2 + (class_emb[r] | E[label[r]] | 0)
+ *   proj[r] = Wp . silu(emb[r]) + bp            (Wp = all time_emb_proj stacked: [proj_dim][T])
+ */
+typedef struct {
+  int rows;                 /* number of (timestep, class) rows */
+  int c0;                   /* block_out_channels[0] (sinusoid width) */
+  int tdim;                 /* time_embed_dim = 4*c0 */
+  int proj_dim;             /* sum of all resnet out_channels */
+  int flip_sin_to_cos;      /* cond_unet_2d.py:139 */
+  float freq_shift;         /* downscale_freq_shift */
+  int num_classes;          /* rows of class table (0: no class embedding) */
+  const float* timesteps;   /* [rows] fp32 (integer-valued) */
+  const int64_t* labels;    /* [rows] or NULL */
+  const float* class_emb;   /* [rows][tdim] or NULL (zeros => unconditional, cond_unet_2d.py:306-309) */
+  const float* w1; const float* b1;   /* time_embedding.linear_1 [tdim][c0], [tdim] */
+  const float* w2; const float* b2;   /* time_embedding.linear_2 [tdim][tdim], [tdim] */
+  const float* class_table;           /* class_embedding.weight [num_classes][tdim] or NULL */
+  const float* wp; const float* bp;   /* stacked time_emb_proj [proj_dim][tdim], [proj_dim] */
+  float* emb;               /* out [rows][tdim] (may be NULL) */
+  float* proj;              /* out [rows][proj_dim] */
+} pd_temb_args;
+int pd_temb(const pd_temb_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pd_conv_in: first 3x3 conv (cond_unet_2d.py:127-129,313): NCHW fp32 sample -> NHWC activations.
+ */
+typedef struct {
+  int dtype;                /* output activation dtype */
+  int B, H, W, Cin, Cout;   /* Cin <= 4, Cout % 32 == 0 */
+  const float* x;           /* [B][Cin][H][W] fp32 */
+  const float* w;           /* [Cout][Cin][3][3] fp32 (OIHW, unpacked) */
+  const float* bias;        /* [Cout] */
+  void* y;                  /* [B][H][W][Cout] */
+} pd_conv_in_args;
+int pd_conv_in(const pd_conv_in_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pd_gn_stats: GroupNorm statistics folded with the affine parameters into per-(sample, channel)
+ * scale/shift, so that the consumer conv applies y = x*scale + shift (+SiLU) while staging its tile.
+ * Replaces the statistics half of torch.nn.GroupNorm(32, C) as used by ResnetBlock2D.norm1/norm2,
+ * Attention.group_norm and conv_norm_out (cond_unet_2d.py:175,195,221,236).  The input may be the
+ * channel concatenation [x0 | x1] of two NHWC tensors (skip connections, cond_unet_2d.py:333-343),
+ * (statistics are invariant under the nearest x2 upsample, so Upsample2D needs no flag here).
+ * Two launches: partial sums (fp64 combine) and finalize.
+ */
+typedef struct {
+  int dtype;
+  int B, HW;                /* pixels per sample */
+  int C0, C1;               /* channels of source 0 / source 1 (C1 = 0: single source) */
+  int groups;               /* 32 */
+  float eps;
+  const void* x0; const void* x1;
+  const float* gamma; const float* beta;   /* [C0+C1] */
+  double* partial;          /* workspace [B][groups][splits][2] */
+  int splits;               /* partial blocks per (sample, group); >= 1 */
+  float* scale; float* shift;   /* out [B][C0+C1] */
+} pd_gn_stats_args;
+int pd_gn_stats(const pd_gn_stats_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pd_conv: implicit-GEMM convolution on MFMA (NHWC, LDS-staged halo tiles).
+ * Replaces torch.nn.Conv2d 3x3 (ResnetBlock2D.conv1/conv2, Downsample2D.conv, Upsample2D.conv,
+ * conv_out) and 1x1 / Linear (ResnetBlock2D.conv_shortcut, Attention.to_q/k/v/to_out) together with the
+ * elementwise ops around them in diffusers' ResnetBlock2D.forward / AttnProcessor2_0:
+ *   prologue : x <- silu?(x*scale + shift)    (GroupNorm apply + SiLU), zero padding AFTER the transform
+ *              optional nearest x2 upsample of the source (Upsample2D: F.interpolate never materialised)
+ *              optional channel concat of two sources (torch.cat([h, skip], 1) never materialised)
+ *   epilogue : + bias[co] + temb[n][co] + residual[n][y][x][co]
+ * w_packed layout (T = dtype element): [Cout/32][Cin/32][taps][2][64 lanes][8] where for lane l
+ * (r = l & 31, h = l >> 5) element j is W[co = 32*ct + r][ci = 32*chunk + 16*s + 8*h + j][tap].
+ */
+typedef enum { PD_OUT_NHWC = 0, PD_OUT_NCHW_F32 = 1, PD_OUT_QKV_HEADS = 2 } pd_out_mode;
+typedef struct {
+  int dtype;
+  int B, Hin, Win;          /* source spatial size (before upsample) */
+  int Hout, Wout;           /* output spatial size (checked against the conv arithmetic) */
+  int C0, C1;               /* source channels; Cin = C0 + C1, each % 32 == 0 */
+  int Cout;                 /* logical output channels */
+  int Cout_pad;             /* packed output channels, % 32 == 0 (>= Cout) */
+  int ksize;                /* 1 or 3 */
+  int stride;               /* 1 or 2 (3x3 only) */
+  int pad;                  /* 1 for 3x3 pad 1; 0 for 1x1 or the asymmetric (0,1,0,1) downsample */
+  int upsample;             /* 1: nearest x2 before the conv */
+  int silu;                 /* 1: SiLU after the affine */
+  int out_mode;             /* pd_out_mode */
+  int heads;                /* PD_OUT_QKV_HEADS: number of heads (Cout = 3*heads*8) */
+  const void* x0; const void* x1;
+  const float* scale; const float* shift;   /* [B][Cin] or NULL (no GroupNorm) */
+  const void* w_packed;
+  const float* bias;        /* [Cout_pad] */
+  const float* temb; int temb_stride;       /* temb[n*temb_stride + co] or NULL */
+  const void* residual;     /* NHWC [B][Hout][Wout][Cout] or NULL */
+  void* y;
+} pd_conv_args;
+int pd_conv(const pd_conv_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pd_attn_d8: softmax(q k^T / sqrt(8)) v for head_dim 8 (attention_head_dim=8, cond_unet_2d.py:176-178),
+ * streaming (flash-style) softmax, scores never materialised.  Replaces F.scaled_dot_product_attention in
+ * AttnProcessor2_0.  Inputs come head-major from pd_conv(out_mode = PD_OUT_QKV_HEADS):
+ *   q, k : [B][heads][N][8]     v : [B][heads][N][8]     out: NHWC [B][N][heads*8]
+ */
+typedef struct {
+  int dtype;
+  int B, heads, N;
+  const void* q; const void* k; const void* v;
+  void* out;
+} pd_attn_args;
+int pd_attn_d8(const pd_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pd_ddim_step: one fused DDIM / inverse-DDIM update on NCHW fp32 tensors.
+ * Replaces DDIMScheduler.step (pipeline_conditionial_ddim.py:340-347) and DDIMInverseScheduler.step
+ * (utils_Img2Img.py:794-798): both are  x' = sqrt_ap * clamp(x0) + dir_coef * eps  with
+ *   epsilon: x0 = (x - sqrt_b*out)/sqrt_a, eps = out        sample: x0 = out, eps = (x - sqrt_a*x0)/sqrt_b
+ *   v:       x0 = sqrt_a*x - sqrt_b*out,   eps = sqrt_a*out + sqrt_b*x
+ * The host passes the four coefficients (computed in fp32 exactly as the reference's 0-dim tensors).
+ * Optional classifier-free-guidance combine (pipeline_conditionial_ddim.py:324-328):
+ *   out = uncond + w*(out - uncond)  [imagen]   or   out + w*(out - uncond)  [CFG]
+ */
+typedef struct {
+  int64_t numel;            /* B*C*H*W */
+  int64_t per_sample;       /* C*H*W (for per-sample guidance weights) */
+  int pred_type;            /* pd_pred_type */
+  int clip;                 /* clip_sample */
+  float clip_range;
+  int use_clipped_model_output;
+  float sqrt_a, sqrt_b;     /* sqrt(alpha_prod_t), sqrt(1 - alpha_prod_t) */
+  float sqrt_ap, dir_coef;  /* sqrt(alpha_prod_t_prev), sqrt(1 - alpha_prod_t_prev - sigma^2) */
+  const float* sample;      /* x_t */
+  const float* model_out;   /* conditional prediction */
+  const float* uncond_out;  /* NULL: no guidance */
+  const float* w;           /* guidance weights: [B] or 1 value */
+  int w_per_sample;         /* 1: w has one value per sample */
+  int guidance_cfg;         /* 0: imagen eqn, 1: CFG eqn */
+  float* prev_sample;       /* out (may alias sample) */
+  float* pred_x0;           /* out or NULL */
+} pd_ddim_step_args;
+int pd_ddim_step(const pd_ddim_step_args* a, void* stream);
+
+/* pd_add_noise: sa[n]*x + sb[n]*noise (DDIMScheduler.add_noise) or velocity sa*noise - sb*x. */
+typedef struct {
+  int64_t numel, per_sample;
+  int velocity;
+  const float* x; const float* noise;
+  const float* sa; const float* sb;   /* [B] per-sample coefficients (device) */
+  float* out;
+} pd_add_noise_args;
+int pd_add_noise(const pd_add_noise_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pd_postproc: (x/2 + 0.5).clamp(0,1), NCHW -> NHWC (pipeline_conditionial_ddim.py:349-350), optionally
+ * also the uint8 quantisation round(255*x) of DiffusionPipeline.numpy_to_pil.
+ */
+typedef struct {
+  int B, C, H, W;
+  const float* x;           /* NCHW */
+  float* out_f32;           /* NHWC or NULL */
+  uint8_t* out_u8;          /* NHWC or NULL */
+} pd_postproc_args;
+int pd_postproc(const pd_postproc_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stream capture helpers (hipGraph): the S-step sampling loop is captured once and replayed.
+ */
+int pd_graph_begin(void* stream);
+int pd_graph_end(void* stream, void** graph_exec_out);
+int pd_graph_launch(void* graph_exec, void* stream);
+int pd_graph_destroy(void* graph_exec);
+
+/* Timing helpers: HIP events on the launch stream (bench.py roofline leg). */
+int pd_event_create(void** ev);
+int pd_event_record(void* ev, void* stream);
+int pd_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int pd_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHENDIFF_HIP_H_ */

@@ -1,0 +1,13 @@
+"""phendiff_amd -- MI355X-native engine for PhenDiff's diffusion hot path.
+
+Drop-in (Python-level) replacements for the objects the reference's loops drive:
+``CustomCondUNet2DModel`` (``src/cond_unet_2d``), ``DDIMScheduler`` / ``DDIMInverseScheduler`` (diffusers),
+``ConditionalDDIMPipeline`` (``src/pipeline_conditional_ddim``), and the DDIB class-transfer loops of
+``src/utils_Img2Img.py``.  All device work goes through ``libphendiff_hip.so`` (``include/phendiff_hip.h``).
+"""
+from ._lib import PhenDiffHipError, lib  # noqa: F401
+from .unet import CustomCondUNet2DModel, UNet2DOutput  # noqa: F401
+from .schedulers import DDIMScheduler, DDIMInverseScheduler  # noqa: F401
+from .pipeline import ConditionalDDIMPipeline, ImagePipelineOutput  # noqa: F401
+from .img2img import inversion, ddib, DDIBGraph, shard_batches, swap_binary_labels  # noqa: F401
+from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401

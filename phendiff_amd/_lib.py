@@ -1,0 +1,131 @@
+"""ctypes binding of ``libphendiff_hip.so`` (the C ABI declared in ``include/phendiff_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing or fails to load, importing
+:func:`lib` raises.  Build it with ``phendiff_amd/csrc/build.sh`` (``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphendiff_hip.so")
+
+PD_F32, PD_BF16 = 0, 1
+PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
+PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
+ABI_VERSION = 1
+
+vp = C.c_void_p
+
+
+class TembArgs(C.Structure):
+    _fields_ = [("rows", C.c_int), ("c0", C.c_int), ("tdim", C.c_int), ("proj_dim", C.c_int),
+                ("flip_sin_to_cos", C.c_int), ("freq_shift", C.c_float), ("num_classes", C.c_int),
+                ("timesteps", vp), ("labels", vp), ("class_emb", vp),
+                ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("class_table", vp), ("wp", vp), ("bp", vp),
+                ("emb", vp), ("proj", vp)]
+
+
+class ConvInArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("x", vp), ("w", vp), ("bias", vp), ("y", vp)]
+
+
+class GnStatsArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C0", C.c_int), ("C1", C.c_int),
+                ("groups", C.c_int), ("eps", C.c_float), ("x0", vp), ("x1", vp), ("gamma", vp), ("beta", vp),
+                ("partial", vp), ("splits", C.c_int), ("scale", vp), ("shift", vp)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+                ("C0", C.c_int), ("C1", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("ksize", C.c_int),
+                ("stride", C.c_int), ("pad", C.c_int), ("upsample", C.c_int), ("silu", C.c_int), ("out_mode", C.c_int),
+                ("heads", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("w_packed", vp), ("bias", vp),
+                ("temb", vp), ("temb_stride", C.c_int), ("residual", vp), ("y", vp)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("N", C.c_int),
+                ("q", vp), ("k", vp), ("v", vp), ("out", vp)]
+
+
+class DdimStepArgs(C.Structure):
+    _fields_ = [("numel", C.c_int64), ("per_sample", C.c_int64), ("pred_type", C.c_int), ("clip", C.c_int),
+                ("clip_range", C.c_float), ("use_clipped_model_output", C.c_int),
+                ("sqrt_a", C.c_float), ("sqrt_b", C.c_float), ("sqrt_ap", C.c_float), ("dir_coef", C.c_float),
+                ("sample", vp), ("model_out", vp), ("uncond_out", vp), ("w", vp), ("w_per_sample", C.c_int),
+                ("guidance_cfg", C.c_int), ("prev_sample", vp), ("pred_x0", vp)]
+
+
+class AddNoiseArgs(C.Structure):
+    _fields_ = [("numel", C.c_int64), ("per_sample", C.c_int64), ("velocity", C.c_int),
+                ("x", vp), ("noise", vp), ("sa", vp), ("sb", vp), ("out", vp)]
+
+
+class PostprocArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("x", vp), ("out_f32", vp), ("out_u8", vp)]
+
+
+# every symbol include/phendiff_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "pd_abi_version": (C.c_int, []),
+    "pd_last_error": (C.c_char_p, []),
+    "pd_temb": (C.c_int, [C.POINTER(TembArgs), vp]),
+    "pd_conv_in": (C.c_int, [C.POINTER(ConvInArgs), vp]),
+    "pd_gn_stats": (C.c_int, [C.POINTER(GnStatsArgs), vp]),
+    "pd_conv": (C.c_int, [C.POINTER(ConvArgs), vp]),
+    "pd_attn_d8": (C.c_int, [C.POINTER(AttnArgs), vp]),
+    "pd_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), vp]),
+    "pd_add_noise": (C.c_int, [C.POINTER(AddNoiseArgs), vp]),
+    "pd_postproc": (C.c_int, [C.POINTER(PostprocArgs), vp]),
+    "pd_graph_begin": (C.c_int, [vp]),
+    "pd_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "pd_graph_launch": (C.c_int, [vp, vp]),
+    "pd_graph_destroy": (C.c_int, [vp]),
+    "pd_event_create": (C.c_int, [C.POINTER(vp)]),
+    "pd_event_record": (C.c_int, [vp, vp]),
+    "pd_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    "pd_event_destroy": (C.c_int, [vp]),
+}
+
+_lib = None
+
+
+class PhenDiffHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the HIP library; raises if it is absent -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PhenDiffHipError(
+            f"{LIB_PATH} not found: build it with phendiff_amd/csrc/build.sh (hipcc --offload-arch=gfx950). "
+            "phendiff_amd has no CPU fallback.")
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise PhenDiffHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if l.pd_abi_version() != ABI_VERSION:
+        raise PhenDiffHipError(f"ABI mismatch: library {l.pd_abi_version()} != binding {ABI_VERSION}")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().pd_last_error()
+        raise PhenDiffHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()

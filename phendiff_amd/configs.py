@@ -1,0 +1,44 @@
+"""Hyper-parameter VALUES of the reference's shipped configs (``models_configs/denoiser/*.json``,
+``models_configs/noise_scheduler/*.json``) so the engine can be instantiated without the reference tree."""
+
+UNET_CONFIGS = {
+    # models_configs/denoiser/super_small.json -- 15 725 443 parameters
+    "super_small": dict(
+        act_fn="silu", attention_head_dim=8, block_out_channels=(64, 128, 256), center_input_sample=False,
+        class_embed_type=None, down_block_types=("DownBlock2D", "DownBlock2D", "AttnDownBlock2D"),
+        downsample_padding=1, flip_sin_to_cos=True, freq_shift=0, in_channels=3, layers_per_block=2,
+        mid_block_scale_factor=1, norm_eps=1e-05, norm_num_groups=32, num_class_embeds=2, out_channels=3,
+        resnet_time_scale_shift="default", sample_size=128, time_embedding_type="positional",
+        up_block_types=("AttnUpBlock2D", "UpBlock2D", "UpBlock2D")),
+    # models_configs/denoiser/small_denoiser_config.json -- 62 826 243 parameters
+    "small_denoiser_config": dict(
+        act_fn="silu", attention_head_dim=8, block_out_channels=(128, 256, 512), center_input_sample=False,
+        class_embed_type=None, down_block_types=("DownBlock2D", "DownBlock2D", "AttnDownBlock2D"),
+        downsample_padding=1, flip_sin_to_cos=True, freq_shift=0, in_channels=3, layers_per_block=2,
+        mid_block_scale_factor=1, norm_eps=1e-05, norm_num_groups=32, num_class_embeds=2, out_channels=3,
+        resnet_time_scale_shift="default", sample_size=128, time_embedding_type="positional",
+        up_block_types=("AttnUpBlock2D", "UpBlock2D", "UpBlock2D")),
+}
+
+SCHEDULER_CONFIGS = {
+    # models_configs/noise_scheduler/3k_steps_clipping_rescaling.json (paired with super_small in launch_script_DDIM.sh:46-47)
+    "3k_steps_clipping_rescaling": dict(
+        beta_schedule="scaled_linear", beta_end=0.02, beta_start=0.0001, clip_sample=True, clip_sample_range=1.0,
+        num_train_timesteps=3000, prediction_type="v_prediction", rescale_betas_zero_snr=True,
+        timestep_spacing="trailing"),
+    # models_configs/noise_scheduler/1k_epsilon_pred.json
+    "1k_epsilon_pred": dict(
+        beta_schedule="scaled_linear", beta_end=0.02, beta_start=0.0001, clip_sample=True, clip_sample_range=1.0,
+        num_train_timesteps=1000, prediction_type="epsilon", rescale_betas_zero_snr=True,
+        timestep_spacing="trailing"),
+    # models_configs/noise_scheduler/SD_orig_config.json
+    "SD_orig_config": dict(
+        beta_end=0.012, beta_schedule="scaled_linear", beta_start=0.00085, clip_sample=False, clip_sample_range=1.0,
+        num_train_timesteps=1000, prediction_type="v_prediction", rescale_betas_zero_snr=False,
+        set_alpha_to_one=False, steps_offset=1, thresholding=False, timestep_spacing="leading"),
+    # models_configs/noise_scheduler/better_SD_config.json
+    "better_SD_config": dict(
+        beta_schedule="scaled_linear", beta_end=0.015, beta_start=0.00001, clip_sample=False, thresholding=False,
+        num_train_timesteps=3000, prediction_type="v_prediction", rescale_betas_zero_snr=True,
+        timestep_spacing="trailing"),
+}

@@ -1,0 +1,192 @@
+// pd_attn_d8: softmax(q k^T / sqrt(8)) v, head_dim = 8, streaming softmax (scores never leave registers).
+//
+// Per wave: 32 queries of one (batch, head).  Keys are visited in tiles of 32:
+//   S^T[key][query] = K[32 x 8] . Q^T[8 x 32]        one 32x32 MFMA (bf16: K=16 slot half used; fp32: 4 x 32x32x2)
+//     -> D layout puts the QUERY on the lane and 16 keys in the lane's registers, so the row max / exp of the
+//        softmax is lane-local (one cross-half exchange per tile), and the exponentiated tile is ALREADY the
+//        B operand of the next product (rows of D == k index of B), no LDS round trip:
+//   O^T[row][query] += A[row][key] . P^T[key][query]  A rows 0..7 = V^T (d), rows 8..15 = 1.0  (=> row sum l for free)
+// Workgroup = 4 waves = 128 queries; K and V^T tiles of 128 keys are staged through LDS (V transposed on the way).
+#include "pd_common.h"
+
+namespace pd {
+
+constexpr int KT = 128;   // keys per LDS tile
+
+template <typename T> struct AttnOps;
+
+template <> struct AttnOps<bf16_t> {
+  static constexpr int VT_PITCH = (KT + 8) * 2;   // bytes per V^T row (pad -> 8 rows on distinct banks)
+  struct QF { s16x8 v; };
+  static __device__ __forceinline__ QF load_q(const bf16_t* q, int h, float scale) {
+    QF f; f.v = (s16x8)(0);
+    if (h == 0) {
+      s16x8 raw = *(const s16x8*)q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (short)f2bf(bf2f((bf16_t)raw[j]) * scale);
+    }
+    return f;
+  }
+  // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
+  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    s16x8 a = (s16x8)(0);
+    if (h == 0) a = *(const s16x8*)(klds + key * 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, q.v), (f32x16)(0.f), 0, 0, 0);
+  }
+  // O^T += A . P^T for the 32 keys starting at key0; p = exponentiated tile (fp32 accumulator layout)
+  static __device__ __forceinline__ f32x16 pv(const unsigned char* vlds, int key0, int r, int h, const f32x16& p, f32x16 o) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const bool ones = (r & 8) != 0;
+    const unsigned char* row = vlds + (r & 7) * VT_PITCH + (key0 + 4 * h) * 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // B fragment: element j <-> key 16s + 8(j>>2) + 4h + (j&3) == accumulator register 8s + j
+      uint32_t bw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bw[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 bv = {bw[0], bw[1], bw[2], bw[3]};
+      uint2 a0 = *(const uint2*)(row + (16 * s) * 2);
+      uint2 a1 = *(const uint2*)(row + (16 * s + 8) * 2);
+      u32x4 av = {a0.x, a0.y, a1.x, a1.y};
+      if (ones) av = (u32x4)(0x3F803F80u);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), o, 0, 0, 0);
+    }
+    return o;
+  }
+};
+
+template <> struct AttnOps<float> {
+  static constexpr int VT_PITCH = (KT + 4) * 4;
+  struct QF { f32x4 v; };
+  static __device__ __forceinline__ QF load_q(const float* q, int h, float scale) {
+    QF f; f.v = *(const f32x4*)(q + 4 * h);
+    f.v *= scale;
+    return f;
+  }
+  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q) {
+    const f32x4 a = *(const f32x4*)(klds + key * 32 + h * 16);   // d = 4h + i
+    f32x16 c = (f32x16)(0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], q.v[i], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ f32x16 pv(const unsigned char* vlds, int key0, int r, int h, const f32x16& p, f32x16 o) {
+    const bool ones = (r & 8) != 0;
+    const unsigned char* row = vlds + (r & 7) * VT_PITCH + (key0 + 4 * h) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a = *(const f32x4*)(row + (8 * g) * 4);   // keys 8g + 4h + (0..3)  == accumulator registers 4g + (0..3)
+      if (ones) a = (f32x4)(1.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], p[4 * g + i], o, 0, 0, 0);
+    }
+    return o;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
+  using E = Elem<T>;
+  using Ops = AttnOps<T>;
+  constexpr int KROW = 8 * E::BYTES;                 // bytes per K row
+  __shared__ __attribute__((aligned(16))) unsigned char klds[KT * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char vlds[8 * Ops::VT_PITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int N = a.N;
+  const size_t bh = ((size_t)b * a.heads + head) * N;
+  const T* qp = (const T*)a.q + bh * 8;
+  const T* kp = (const T*)a.k + bh * 8;
+  const T* vp = (const T*)a.v + bh * 8;
+
+  const int query = blockIdx.x * 128 + wave * 32 + r;
+  const int qclamp = min(query, N - 1);
+  // fold softmax scale 8^-1/2 and log2(e) into q: p = exp2(s' - m')
+  const float qscale = 0.35355339059327373f * 1.4426950408889634f;
+  const typename Ops::QF qf = Ops::load_q(qp + (size_t)qclamp * 8, h, qscale);
+
+  f32x16 o = (f32x16)(0.f);
+  float m = -INFINITY;
+
+  // staging: thread t < 128 owns K row t, thread t >= 128 owns V row t-128 of the tile
+  const int srow = tid & 127;
+  const bool is_v = tid >= 128;
+  typename E::Frag st;
+  auto issue = [&](int k0) {
+    const int key = k0 + srow;
+    if (key < N) st = E::load((is_v ? vp : kp) + (size_t)key * 8);
+    else st = E::zero();
+  };
+  auto commit = [&]() {
+    if (!is_v) {
+      E::store(klds + srow * KROW, st);
+    } else {
+      float v[8];
+      E::unpack(st, v);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) *(T*)(vlds + d * Ops::VT_PITCH + srow * E::BYTES) = E::from_f(v[d]);
+    }
+  };
+
+  issue(0);
+  for (int k0 = 0; k0 < N; k0 += KT) {
+    if (k0 > 0) __syncthreads();
+    commit();
+    __syncthreads();
+    if (k0 + KT < N) issue(k0 + KT);
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      const int kb = sub * 32;
+      if (k0 + kb >= N) break;
+      f32x16 s = Ops::qk(klds, kb + r, h, qf);
+      // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
+      if (k0 + kb + 32 > N) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = k0 + kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= N) s[i] = -INFINITY;
+        }
+      }
+      float tmax = s[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m, tmax);           // finite: every tile has at least one valid key
+      const float alpha = exp2f(m - m_new);         // m = -inf on the first tile -> 0
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = exp2f(s[i] - m_new);
+      // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= alpha;
+      m = m_new;
+      o = Ops::pv(vlds, kb, r, h, s, o);
+    }
+  }
+
+  if (query < N) {
+    // lane (query, h): registers 0..3 = O^T rows 4h..4h+3 (d), register 4 = row 8 + 4h = l
+    const float inv = 1.0f / o[4];
+    T* dst = (T*)a.out + ((size_t)b * N + query) * (a.heads * 8) + head * 8 + 4 * h;
+    store4(dst, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+  }
+}
+
+}  // namespace pd
+
+extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
+  using namespace pd;
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_attn_d8: null args");
+  PD_CHECK(a->B > 0 && a->heads > 0 && a->N > 0, PD_ERR_SHAPE, "pd_attn_d8: bad shape");
+  PD_CHECK(a->q && a->k && a->v && a->out, PD_ERR_ARG, "pd_attn_d8: null pointer");
+  PD_CHECK(a->heads <= 65535 && a->B <= 65535, PD_ERR_SHAPE, "pd_attn_d8: grid too large");
+  dim3 grid((a->N + 127) / 128, a->heads, a->B);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}

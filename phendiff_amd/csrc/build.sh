@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libphendiff_hip.so for gfx950 (MI355X) in-tree.  Cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../libphendiff_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+mkdir -p "$HERE/build"
+pids=()
+for f in conv_igemm attn_d8 small_kernels; do
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_common.h" -nt "$HERE/build/$f.o" ] \
+     || [ "$HERE/../../include/phendiff_hip.h" -nt "$HERE/build/$f.o" ]; then
+    $HIPCC $FLAGS $EXTRA_HIPCC_FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/build/conv_igemm.o" "$HERE/build/attn_d8.o" "$HERE/build/small_kernels.o"
+echo "built $OUT"

@@ -1,0 +1,121 @@
+// Shared device helpers for libphendiff_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/phendiff_hip.h"
+
+namespace pd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+void set_error(const char* fmt, ...);
+
+#define PD_CHECK(cond, code, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      pd::set_error(__VA_ARGS__);        \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+#define PD_LAUNCH_CHECK()                                              \
+  do {                                                                 \
+    hipError_t e_ = hipGetLastError();                                 \
+    if (e_ != hipSuccess) {                                            \
+      pd::set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return PD_ERR_LAUNCH;                                            \
+    }                                                                  \
+  } while (0)
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+// ---- element traits: an "8-element fragment" is what one lane feeds to one MFMA k16-step ----------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int BYTES = 4;
+  struct Frag { f32x4 lo, hi; };   // 8 fp32
+  static __device__ __forceinline__ void unpack(const Frag& f, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = f.lo[i]; o[4 + i] = f.hi[i]; }
+  }
+  static __device__ __forceinline__ Frag pack(const float (&o)[8]) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f.lo[i] = o[i]; f.hi[i] = o[4 + i]; }
+    return f;
+  }
+  static __device__ __forceinline__ Frag zero() { Frag f; f.lo = (f32x4)(0.f); f.hi = (f32x4)(0.f); return f; }
+  static __device__ __forceinline__ Frag load(const void* p) {
+    Frag f; f.lo = *(const f32x4*)p; f.hi = *((const f32x4*)p + 1); return f;
+  }
+  static __device__ __forceinline__ void store(void* p, const Frag& f) { *(f32x4*)p = f.lo; *((f32x4*)p + 1) = f.hi; }
+  // D[32x32] += A[32 x 8k] * B[8k x 32]; exact fp32 (v_mfma_f32_32x32x2_f32 x4, k order consistent in A and B)
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[i], b.lo[i], c, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[i], b.hi[i], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int BYTES = 2;
+  struct Frag { s16x8 v; };        // 8 bf16
+  static __device__ __forceinline__ void unpack(const Frag& f, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = bf2f((bf16_t)f.v[i]);
+  }
+  static __device__ __forceinline__ Frag pack(const float (&o)[8]) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.v[i] = (short)f2bf(o[i]);
+    return f;
+  }
+  static __device__ __forceinline__ Frag zero() { Frag f; f.v = (s16x8)(0); return f; }
+  static __device__ __forceinline__ Frag load(const void* p) { Frag f; f.v = *(const s16x8*)p; return f; }
+  static __device__ __forceinline__ void store(void* p, const Frag& f) { *(s16x8*)p = f.v; }
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+  static __device__ __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+};
+
+// store 4 consecutive output elements
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *(f32x4*)p = (f32x4){a, b, c, d};
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+  uint2 v; v.x = pack2bf(a, b); v.y = pack2bf(c, d);
+  *(uint2*)p = v;
+}
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+  f32x4 v = *(const f32x4*)p; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&o)[4]) {
+  uint2 v = *(const uint2*)p;
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+}  // namespace pd

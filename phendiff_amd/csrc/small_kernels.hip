@@ -1,0 +1,374 @@
+// Small (bandwidth / latency bound) kernels of the PhenDiff hot path: embeddings, conv_in, GroupNorm
+// statistics, fused DDIM step, add_noise, post-processing, plus the C-ABI plumbing (errors, graphs, events).
+#include <stdarg.h>
+#include <stdio.h>
+#include "pd_common.h"
+
+namespace pd {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ================================================================================================
+// pd_temb: one block per (timestep, class) row.  All weights are passed TRANSPOSED ([in][out]) so that
+// thread `o` streams column o with coalesced loads.
+// ================================================================================================
+__global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a) {
+  extern __shared__ float sm[];          // [c0] sincos | [tdim] h1 | [tdim] act
+  float* se = sm;
+  float* h1 = sm + a.c0;
+  float* act = h1 + a.tdim;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float t = a.timesteps[row];
+  const int half = a.c0 / 2;
+  for (int i = tid; i < a.c0; i += 256) {
+    // get_timestep_embedding: emb = [sin | cos], flipped to [cos | sin] when flip_sin_to_cos
+    const bool second = i >= half;
+    const int k = second ? i - half : i;
+    const float expo = (-9.210340371976184f /* -ln(10000) */ * (float)k) / ((float)half - a.freq_shift);
+    const float arg = t * expf(expo);
+    const bool want_sin = a.flip_sin_to_cos ? second : !second;
+    se[i] = want_sin ? sinf(arg) : cosf(arg);
+  }
+  __syncthreads();
+  for (int o = tid; o < a.tdim; o += 256) {
+    float acc = a.b1[o];
+    for (int i = 0; i < a.c0; ++i) acc += a.w1[(size_t)i * a.tdim + o] * se[i];
+    h1[o] = silu_f(acc);
+  }
+  __syncthreads();
+  for (int o = tid; o < a.tdim; o += 256) {
+    float acc = a.b2[o];
+    for (int i = 0; i < a.tdim; ++i) acc += a.w2[(size_t)i * a.tdim + o] * h1[i];
+    if (a.class_emb) acc += a.class_emb[(size_t)row * a.tdim + o];
+    else if (a.labels && a.class_table) acc += a.class_table[(size_t)a.labels[row] * a.tdim + o];
+    if (a.emb) a.emb[(size_t)row * a.tdim + o] = acc;
+    act[o] = silu_f(acc);
+  }
+  __syncthreads();
+  for (int o = tid; o < a.proj_dim; o += 256) {
+    float acc = a.bp[o];
+    for (int i = 0; i < a.tdim; ++i) acc += a.wp[(size_t)i * a.proj_dim + o] * act[i];
+    a.proj[(size_t)row * a.proj_dim + o] = acc;
+  }
+}
+
+// ================================================================================================
+// pd_conv_in: direct 3x3 conv, Cin <= 4.  thread = (pixel, group of 8 output channels); the 8 threads of a
+// pixel write one contiguous NHWC row.
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_kernel(const pd_conv_in_args a) {
+  extern __shared__ float wsm[];   // [Cin*9][Cout] transposed weights
+  const int nw = a.Cout * a.Cin * 9;
+  for (int i = threadIdx.x; i < nw; i += 256) {
+    const int co = i / (a.Cin * 9), k = i % (a.Cin * 9);
+    wsm[k * a.Cout + co] = a.w[i];
+  }
+  __syncthreads();
+  const int groups = a.Cout / 8;
+  const size_t total = (size_t)a.B * a.H * a.W * groups;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cg = (int)(gid % groups);
+  const size_t pix = gid / groups;
+  const int x = (int)(pix % a.W), y = (int)((pix / a.W) % a.H), n = (int)(pix / ((size_t)a.W * a.H));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = a.bias[cg * 8 + j];
+  for (int ci = 0; ci < a.Cin; ++ci) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = y + ky - 1, ix = x + kx - 1;
+        float v = 0.f;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = a.x[(((size_t)n * a.Cin + ci) * a.H + iy) * a.W + ix];
+        const float* wr = wsm + ((ci * 3 + ky) * 3 + kx) * a.Cout + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wr[j] * v;
+      }
+    }
+  }
+  T* dst = (T*)a.y + pix * a.Cout + cg * 8;
+  store4(dst, acc[0], acc[1], acc[2], acc[3]);
+  store4(dst + 4, acc[4], acc[5], acc[6], acc[7]);
+}
+
+// ================================================================================================
+// pd_gn_stats: (1) per-channel partial sums over a pixel slice, coalesced 8-channel pieces, fp32 per
+// thread then fp64 combine; (2) finalize: group moments in fp64 -> per-(sample, channel) scale / shift.
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const pd_gn_stats_args a) {
+  using E = Elem<T>;
+  __shared__ float red[256 * 16];
+  const int C = a.C0 + a.C1;
+  const int PP = C / 8;                 // pieces per pixel
+  const int ppi = 256 / PP;             // pixels per iteration
+  const int nthr = ppi * PP;
+  const int n = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int per = (a.HW + a.splits - 1) / a.splits;
+  const int p0 = split * per, p1 = min(a.HW, p0 + per);
+  const int tid = threadIdx.x;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (tid < nthr) {
+    const int piece = tid % PP, prow = tid / PP;
+    const int c8 = piece * 8;
+    const T* src; int cs, coff;
+    if (c8 < a.C0) { src = (const T*)a.x0; cs = a.C0; coff = c8; }
+    else           { src = (const T*)a.x1; cs = a.C1; coff = c8 - a.C0; }
+    for (int p = p0 + prow; p < p1; p += ppi) {
+      float v[8];
+      E::unpack(E::load(src + ((size_t)n * a.HW + p) * cs + coff), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s[j]; red[tid * 16 + 8 + j] = q[j]; }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int piece = c >> 3, j = c & 7;
+    double ds = 0.0, dq = 0.0;
+    for (int k = 0; k < ppi; ++k) {
+      const int t = k * PP + piece;
+      ds += (double)red[t * 16 + j];
+      dq += (double)red[t * 16 + 8 + j];
+    }
+    double* out = a.partial + (((size_t)n * a.splits + split) * C + c) * 2;
+    out[0] = ds; out[1] = dq;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const pd_gn_stats_args a) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int C = a.C0 + a.C1;
+  const int gs = C / a.groups;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid < a.groups) {
+    double ds = 0.0, dq = 0.0;
+    for (int sp = 0; sp < a.splits; ++sp) {
+      const double* in = a.partial + (((size_t)n * a.splits + sp) * C + tid * gs) * 2;
+      for (int c = 0; c < gs; ++c) { ds += in[2 * c]; dq += in[2 * c + 1]; }
+    }
+    const double cnt = (double)gs * (double)a.HW;
+    const double mean = ds / cnt;
+    double var = dq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / gs;
+    const float sc = rstd_s[g] * a.gamma[c];
+    a.scale[(size_t)n * C + c] = sc;
+    a.shift[(size_t)n * C + c] = a.beta[c] - mean_s[g] * sc;
+  }
+}
+
+// ================================================================================================
+// pd_ddim_step / pd_add_noise / pd_postproc: elementwise on fp32 NCHW
+// ================================================================================================
+__global__ __launch_bounds__(256) void ddim_step_kernel(const pd_ddim_step_args a) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= a.numel) return;
+  const int cnt = (int)min((int64_t)4, a.numel - i0);
+  float x[4], o[4], u[4], xp[4], x0v[4];
+  if (cnt == 4) {
+    f32x4 vx = *(const f32x4*)(a.sample + i0), vo = *(const f32x4*)(a.model_out + i0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = vx[j]; o[j] = vo[j]; }
+    if (a.uncond_out) { f32x4 vu = *(const f32x4*)(a.uncond_out + i0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = vu[j]; }
+  } else {
+    for (int j = 0; j < 4; ++j) { x[j] = j < cnt ? a.sample[i0 + j] : 0.f; o[j] = j < cnt ? a.model_out[i0 + j] : 0.f;
+      u[j] = (a.uncond_out && j < cnt) ? a.uncond_out[i0 + j] : 0.f; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float out = o[j];
+    if (a.uncond_out) {
+      const float w = a.w_per_sample ? a.w[(i0 + j) / a.per_sample] : a.w[0];
+      out = a.guidance_cfg ? (o[j] + w * (o[j] - u[j])) : (u[j] + w * (o[j] - u[j]));
+    }
+    float x0, eps;
+    if (a.pred_type == PD_PRED_EPSILON) { x0 = (x[j] - a.sqrt_b * out) / a.sqrt_a; eps = out; }
+    else if (a.pred_type == PD_PRED_SAMPLE) { x0 = out; eps = (x[j] - a.sqrt_a * x0) / a.sqrt_b; }
+    else { x0 = a.sqrt_a * x[j] - a.sqrt_b * out; eps = a.sqrt_a * out + a.sqrt_b * x[j]; }
+    if (a.clip) x0 = fminf(fmaxf(x0, -a.clip_range), a.clip_range);
+    if (a.use_clipped_model_output) eps = (x[j] - a.sqrt_a * x0) / a.sqrt_b;
+    x0v[j] = x0;
+    xp[j] = a.sqrt_ap * x0 + a.dir_coef * eps;
+  }
+  if (cnt == 4) {
+    *(f32x4*)(a.prev_sample + i0) = (f32x4){xp[0], xp[1], xp[2], xp[3]};
+    if (a.pred_x0) *(f32x4*)(a.pred_x0 + i0) = (f32x4){x0v[0], x0v[1], x0v[2], x0v[3]};
+  } else {
+    for (int j = 0; j < cnt; ++j) { a.prev_sample[i0 + j] = xp[j]; if (a.pred_x0) a.pred_x0[i0 + j] = x0v[j]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_noise_kernel(const pd_add_noise_args a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.numel) return;
+  const int64_t n = i / a.per_sample;
+  const float sa = a.sa[n], sb = a.sb[n];
+  a.out[i] = a.velocity ? (sa * a.noise[i] - sb * a.x[i]) : (sa * a.x[i] + sb * a.noise[i]);
+}
+
+__global__ __launch_bounds__(256) void postproc_kernel(const pd_postproc_args a) {
+  const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t hw = (size_t)a.H * a.W;
+  if (pix >= (size_t)a.B * hw) return;
+  const size_t n = pix / hw, p = pix % hw;
+  for (int c = 0; c < a.C; ++c) {
+    float v = a.x[(n * a.C + c) * hw + p];
+    v = fminf(fmaxf(v / 2.f + 0.5f, 0.f), 1.f);
+    if (a.out_f32) a.out_f32[pix * a.C + c] = v;
+    if (a.out_u8) a.out_u8[pix * a.C + c] = (uint8_t)rintf(v * 255.f);
+  }
+}
+
+}  // namespace pd
+
+using namespace pd;
+
+extern "C" int pd_abi_version(void) { return PD_ABI_VERSION; }
+extern "C" const char* pd_last_error(void) { return g_err; }
+
+extern "C" int pd_temb(const pd_temb_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_temb: null args");
+  PD_CHECK(a->rows > 0 && a->c0 > 0 && a->c0 % 2 == 0 && a->tdim > 0 && a->proj_dim > 0, PD_ERR_SHAPE, "pd_temb: bad dims");
+  PD_CHECK(a->timesteps && a->w1 && a->b1 && a->w2 && a->b2 && a->wp && a->bp && a->proj, PD_ERR_ARG, "pd_temb: null pointer");
+  PD_CHECK(!(a->labels && a->class_emb), PD_ERR_ARG, "pd_temb: both labels and class_emb given");
+  PD_CHECK(!(a->labels && !a->class_table), PD_ERR_ARG, "pd_temb: labels without class table");
+  const size_t sm = (size_t)(a->c0 + 2 * a->tdim) * sizeof(float);
+  PD_CHECK(sm <= 64 * 1024, PD_ERR_SHAPE, "pd_temb: tdim too large");
+  hipLaunchKernelGGL(temb_kernel, dim3(a->rows), dim3(256), sm, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_conv_in(const pd_conv_in_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_conv_in: null args");
+  PD_CHECK(a->Cin >= 1 && a->Cin <= 4 && a->Cout % 32 == 0 && a->Cout > 0, PD_ERR_SHAPE, "pd_conv_in: Cin=%d Cout=%d", a->Cin, a->Cout);
+  PD_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->x && a->w && a->bias && a->y, PD_ERR_ARG, "pd_conv_in: bad args");
+  const size_t total = (size_t)a->B * a->H * a->W * (a->Cout / 8);
+  const size_t sm = (size_t)a->Cout * a->Cin * 9 * sizeof(float);
+  PD_CHECK(sm <= 64 * 1024, PD_ERR_SHAPE, "pd_conv_in: weights do not fit LDS");
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(conv_in_kernel<float>, dim3(grid), dim3(256), sm, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(conv_in_kernel<bf16_t>, dim3(grid), dim3(256), sm, (hipStream_t)stream, *a);
+  else { set_error("pd_conv_in: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_gn_stats(const pd_gn_stats_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_gn_stats: null args");
+  const int C = a->C0 + a->C1;
+  PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C0 % 32 == 0 && a->C1 % 32 == 0 && a->C1 >= 0, PD_ERR_SHAPE, "pd_gn_stats: bad shape");
+  PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0 && C / 8 <= 256, PD_ERR_SHAPE, "pd_gn_stats: groups=%d C=%d", a->groups, C);
+  PD_CHECK(a->splits >= 1 && a->x0 && a->gamma && a->beta && a->partial && a->scale && a->shift, PD_ERR_ARG, "pd_gn_stats: null pointer");
+  PD_CHECK((a->C1 == 0) == (a->x1 == nullptr), PD_ERR_ARG, "pd_gn_stats: x1/C1 mismatch");
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
+  else { set_error("pd_gn_stats: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->B), dim3(256), 0, st, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_ddim_step(const pd_ddim_step_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_ddim_step: null args");
+  PD_CHECK(a->numel > 0 && a->sample && a->model_out && a->prev_sample, PD_ERR_ARG, "pd_ddim_step: bad args");
+  PD_CHECK(a->pred_type >= 0 && a->pred_type <= 2, PD_ERR_ARG, "pd_ddim_step: bad prediction type");
+  PD_CHECK(!a->uncond_out || a->w, PD_ERR_ARG, "pd_ddim_step: guidance without weights");
+  PD_CHECK(((uintptr_t)a->sample % 16 == 0) && ((uintptr_t)a->model_out % 16 == 0) && ((uintptr_t)a->prev_sample % 16 == 0),
+           PD_ERR_ARG, "pd_ddim_step: tensors must be 16-byte aligned");
+  const unsigned grid = (unsigned)((a->numel + 1023) / 1024);
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_add_noise(const pd_add_noise_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->numel > 0 && a->per_sample > 0 && a->x && a->noise && a->sa && a->sb && a->out, PD_ERR_ARG, "pd_add_noise: bad args");
+  hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)((a->numel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_postproc(const pd_postproc_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->B > 0 && a->C > 0 && a->H > 0 && a->W > 0 && a->x && (a->out_f32 || a->out_u8), PD_ERR_ARG, "pd_postproc: bad args");
+  const size_t total = (size_t)a->B * a->H * a->W;
+  hipLaunchKernelGGL(postproc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+// ---- hipGraph capture of the sampling loop ------------------------------------------------------------
+#define PD_HIP(call)                                                         \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) { set_error("%s: %s", #call, hipGetErrorString(e_)); return PD_ERR_LAUNCH; } \
+  } while (0)
+
+extern "C" int pd_graph_begin(void* stream) {
+  PD_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return PD_OK;
+}
+extern "C" int pd_graph_end(void* stream, void** graph_exec_out) {
+  PD_CHECK(graph_exec_out != nullptr, PD_ERR_ARG, "pd_graph_end: null out");
+  hipGraph_t g = nullptr;
+  PD_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return PD_ERR_LAUNCH; }
+  *graph_exec_out = (void*)ge;
+  return PD_OK;
+}
+extern "C" int pd_graph_launch(void* graph_exec, void* stream) {
+  PD_CHECK(graph_exec != nullptr, PD_ERR_ARG, "pd_graph_launch: null graph");
+  PD_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return PD_OK;
+}
+extern "C" int pd_graph_destroy(void* graph_exec) {
+  if (graph_exec) PD_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return PD_OK;
+}
+
+extern "C" int pd_event_create(void** ev) {
+  PD_CHECK(ev != nullptr, PD_ERR_ARG, "pd_event_create: null out");
+  hipEvent_t e;
+  PD_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return PD_OK;
+}
+extern "C" int pd_event_record(void* ev, void* stream) {
+  PD_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return PD_OK;
+}
+extern "C" int pd_event_elapsed_ms(void* start, void* stop, float* ms) {
+  PD_CHECK(ms != nullptr, PD_ERR_ARG, "pd_event_elapsed_ms: null out");
+  PD_HIP(hipEventSynchronize((hipEvent_t)stop));
+  PD_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return PD_OK;
+}
+extern "C" int pd_event_destroy(void* ev) {
+  if (ev) PD_HIP(hipEventDestroy((hipEvent_t)ev));
+  return PD_OK;
+}

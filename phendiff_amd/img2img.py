@@ -1,0 +1,197 @@
+"""DDIB class transfer: DDIM inversion under the original class -> denoising under the target class.
+
+Mirrors ``src/utils_Img2Img.py``: ``_inversion`` (``:763-800``), ``_ddib`` (``:566-612``), the binary
+class swap and batch sharding of ``perform_class_transfer_experiment`` (``:307-317,341-345``).
+
+Two execution modes, same arithmetic:
+  * eager  -- ``inversion`` / ``ddib`` walk the reference's Python loops over the drop-in objects;
+  * graph  -- :class:`DDIBGraph` captures the whole 2*S-step trajectory (time/class embedding table, 2*S UNet
+    evaluations, 2*S fused scheduler updates, post-processing) into ONE hipGraph and replays it per batch:
+    no host round trip, no Python launch cost (~120 launches x 2*S per batch otherwise).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+from .pipeline import ConditionalDDIMPipeline
+from .schedulers import DDIMInverseScheduler
+
+
+@torch.no_grad()
+def inversion(pipe, input_images: torch.Tensor, class_labels: torch.Tensor, num_inference_steps: int,
+              proc_idx: Optional[int] = None, variant: str = "0.18.2") -> torch.Tensor:
+    """``_inversion`` (utils_Img2Img.py:763-800)."""
+    gauss = input_images.clone().detach()
+    inv = DDIMInverseScheduler.from_config(pipe.scheduler.config, variant=variant)
+    inv.set_timesteps(num_inference_steps)
+    for t in inv.timesteps:
+        model_output = pipe.unet(gauss, t, class_labels).sample
+        gauss = inv.step(model_output, t, gauss).prev_sample
+    return gauss
+
+
+@torch.no_grad()
+def ddib(pipe, clean_images, orig_class_labels, target_class_labels, num_inference_steps: int,
+         process_idx: Optional[int] = None, variant: str = "0.18.2", output_type: str = "numpy"):
+    """``_ddib`` for :class:`ConditionalDDIMPipeline` (utils_Img2Img.py:566-599)."""
+    if not isinstance(pipe, ConditionalDDIMPipeline):
+        raise NotImplementedError("only the ConditionalDDIMPipeline branch is implemented")
+    inverted_gauss = inversion(pipe, clean_images, orig_class_labels, num_inference_steps, process_idx, variant)
+    return pipe(class_labels=target_class_labels, w=0, num_inference_steps=num_inference_steps,
+                start_image=inverted_gauss, add_forward_noise_to_image=False, frac_diffusion_skipped=0,
+                output_type=output_type).images
+
+
+def swap_binary_labels(orig_class_labels: torch.Tensor) -> torch.Tensor:
+    """``target = 1 - orig`` (utils_Img2Img.py:343-344): strictly binary datasets."""
+    return 1 - orig_class_labels
+
+
+def shard_batches(num_batches: int, rank: int, world_size: int, even_batches: bool = True) -> List[int]:
+    """Batch indices rank ``rank`` processes -- accelerate ``BatchSamplerShard`` semantics as reached through
+    ``accelerator.prepare(dataloader)`` (utils_Img2Img.py:316): rank r takes batches r, r+G, r+2G, ...; with
+    ``even_batches`` (accelerate's default) the tail is completed by wrapping around to the first batches so
+    that every rank runs the same number of iterations.  No collective on the data path."""
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError("bad rank / world_size")
+    mine = list(range(rank, num_batches, world_size))
+    if even_batches and num_batches > 0:
+        # accelerate completes the last round with the samples of the first batches, in order: the k-th filler
+        # batch is batch k (mod num_batches) and goes to the rank whose turn it is
+        idx, k = num_batches, 0
+        while idx % world_size != 0:
+            if idx % world_size == rank:
+                mine.append(k % num_batches)
+            idx += 1
+            k += 1
+    return mine
+
+
+class DDIBGraph:
+    """One hipGraph for the whole invert -> class-swap -> denoise trajectory of a batch.
+
+    ``run(images, orig_labels, target_labels)`` copies the batch into static buffers, replays the graph and
+    returns the float NHWC ``[0,1]`` images on the device (``.images``), the inverted latents (``.inverted``)
+    and optionally the uint8 quantisation."""
+
+    def __init__(self, pipe: ConditionalDDIMPipeline, batch_size: int, num_inference_steps: int, height: int = None,
+                 width: int = None, variant: str = "0.18.2", device=None, use_graph: bool = True):
+        self.pipe = pipe
+        unet = pipe.unet
+        self.device = torch.device(device) if device is not None else unet.device
+        ss = unet.config.sample_size
+        H = height or (ss if isinstance(ss, int) else ss[0])
+        W = width or (ss if isinstance(ss, int) else ss[1])
+        self.B, self.S, self.H, self.W = batch_size, num_inference_steps, H, W
+        B, S = self.B, self.S
+        dev = self.device
+        self.lib = L.lib()
+        self.plan = unet.plan_for(B, H, W, dev)
+        cin = unet.config.in_channels
+        # schedulers (host tables)
+        self.inv = DDIMInverseScheduler.from_config(pipe.scheduler.config, variant=variant)
+        self.inv.set_timesteps(S)
+        fwd = pipe.scheduler
+        fwd.set_timesteps(S)
+        # pipeline __call__ with frac_diffusion_skipped=0: timesteps <= N*(1-0) => all of them (:250-258)
+        gen_ts = fwd.timesteps[fwd.timesteps <= fwd.config.num_train_timesteps * (1 - 0)]
+        self.inv_ts = [int(t) for t in self.inv.timesteps]
+        self.gen_ts = [int(t) for t in gen_ts]
+        nsteps = len(self.inv_ts) + len(self.gen_ts)
+        # static device buffers
+        self.x = torch.empty((B, cin, H, W), dtype=torch.float32, device=dev)
+        self.model_out = torch.empty_like(self.x)
+        self.inverted = torch.empty_like(self.x)
+        self.images = torch.empty((B, H, W, cin), dtype=torch.float32, device=dev)
+        self.images_u8 = torch.empty((B, H, W, cin), dtype=torch.uint8, device=dev)
+        self.ts_rows = torch.empty((nsteps * B,), dtype=torch.float32, device=dev)
+        self.label_rows = torch.empty((nsteps * B,), dtype=torch.int64, device=dev)
+        ts_host = torch.tensor(self.inv_ts + self.gen_ts, dtype=torch.float32).repeat_interleave(B)
+        self.ts_rows.copy_(ts_host)
+        self.temb = torch.empty((nsteps * B, self.plan.w.proj_dim), dtype=torch.float32, device=dev)
+        # per-step scheduler args
+        self.step_args = []
+        for sched, ts in ((self.inv, self.inv_ts), (fwd, self.gen_ts)):
+            c = sched.config
+            for t in ts:
+                sa, sb, sap, dirc, _ = sched.step_coefficients(t, 0.0)
+                self.step_args.append(L.DdimStepArgs(
+                    numel=self.x.numel(), per_sample=self.x[0].numel(), pred_type=L.PD_PRED[c.prediction_type],
+                    clip=int(bool(c.clip_sample)), clip_range=float(c.clip_sample_range), use_clipped_model_output=0,
+                    sqrt_a=sa, sqrt_b=sb, sqrt_ap=sap, dir_coef=dirc, sample=self.x.data_ptr(),
+                    model_out=self.model_out.data_ptr(), uncond_out=None, w=None, w_per_sample=0, guidance_cfg=0,
+                    prev_sample=self.x.data_ptr(), pred_x0=None))
+        self.post_args = L.PostprocArgs(B=B, C=cin, H=H, W=W, x=self.x.data_ptr(), out_f32=self.images.data_ptr(),
+                                        out_u8=self.images_u8.data_ptr())
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph = C.c_void_p(None)
+        self.use_graph = use_graph
+        if use_graph:
+            self._capture()
+
+    # the trajectory, as launches on `st`
+    def _enqueue(self, st):
+        lib, plan, B = self.lib, self.plan, self.B
+        n_inv = len(self.inv_ts)
+        plan.temb_rows(self.ts_rows, self.label_rows, None, st, rows=self.ts_rows.numel(), out=self.temb)
+        row_bytes = plan.w.proj_dim * 4
+        for i, a in enumerate(self.step_args):
+            plan.run(self.x.data_ptr(), self.temb.data_ptr() + i * B * row_bytes, self.model_out.data_ptr(), st)
+            L.check(lib.pd_ddim_step(C.byref(a), st), "pd_ddim_step")
+            if i == n_inv - 1:
+                self._copy_inverted(st)
+        L.check(lib.pd_postproc(C.byref(self.post_args), st), "pd_postproc")
+
+    def _copy_inverted(self, st):
+        # device-to-device snapshot of the inverted latents via the add_noise kernel: 1*x + 0*x
+        a = L.AddNoiseArgs(numel=self.x.numel(), per_sample=self.x[0].numel(), velocity=0, x=self.x.data_ptr(),
+                           noise=self.x.data_ptr(), sa=self._ones.data_ptr(), sb=self._zeros.data_ptr(),
+                           out=self.inverted.data_ptr())
+        L.check(self.lib.pd_add_noise(C.byref(a), st), "pd_add_noise")
+
+    def _capture(self):
+        st = self.stream.cuda_stream
+        self._ones = torch.ones((self.B,), dtype=torch.float32, device=self.device)
+        self._zeros = torch.zeros((self.B,), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        L.check(self.lib.pd_graph_begin(st), "pd_graph_begin")
+        try:
+            self._enqueue(st)
+        finally:
+            rc = self.lib.pd_graph_end(st, C.byref(self.graph))
+        L.check(rc, "pd_graph_end")
+
+    @torch.no_grad()
+    def run(self, clean_images: torch.Tensor, orig_class_labels: torch.Tensor, target_class_labels: torch.Tensor):
+        B = self.B
+        if clean_images.shape != self.x.shape:
+            raise ValueError(f"expected images of shape {tuple(self.x.shape)}, got {tuple(clean_images.shape)}")
+        n_inv, n_gen = len(self.inv_ts), len(self.gen_ts)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(clean_images, non_blocking=True)
+            o = orig_class_labels.to(device=self.device, dtype=torch.int64)
+            t = target_class_labels.to(device=self.device, dtype=torch.int64)
+            self.label_rows[: n_inv * B].view(n_inv, B).copy_(o.view(1, B).expand(n_inv, B))
+            self.label_rows[n_inv * B:].view(n_gen, B).copy_(t.view(1, B).expand(n_gen, B))
+            if self.use_graph:
+                L.check(self.lib.pd_graph_launch(self.graph, self.stream.cuda_stream), "pd_graph_launch")
+            else:
+                if not hasattr(self, "_ones"):
+                    self._ones = torch.ones((B,), dtype=torch.float32, device=self.device)
+                    self._zeros = torch.zeros((B,), dtype=torch.float32, device=self.device)
+                self._enqueue(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return self
+
+    def __del__(self):
+        try:
+            if self.graph:
+                self.lib.pd_graph_destroy(self.graph)
+        except Exception:
+            pass

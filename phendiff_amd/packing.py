@@ -1,0 +1,26 @@
+"""Host-side weight packing into the MFMA fragment order ``pd_conv`` consumes
+(``include/phendiff_hip.h``: ``pd_conv_args.w_packed``)."""
+from __future__ import annotations
+
+import torch
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cout_pad: int | None = None) -> torch.Tensor:
+    """OIHW conv weight (or ``[out, in, 1, 1]`` linear) -> ``[Cout_pad/32][Cin/32][taps][2][64][8]``.
+
+    For lane ``l`` (``r = l & 31``, ``h = l >> 5``) of fragment ``(ct, chunk, tap, s)`` element ``j`` is
+    ``W[32*ct + r][32*chunk + 16*s + 8*h + j][tap]`` -- i.e. each wave reads one fragment as 1 KiB (bf16) /
+    2 KiB (fp32) of contiguous memory, already in the A-operand layout of ``v_mfma_f32_32x32x16_bf16``
+    (and, with the k order shared by A and B, of the 8 x ``v_mfma_f32_32x32x2_f32`` fp32 form).
+    """
+    assert w.ndim == 4 and w.shape[2] == w.shape[3]
+    cout, cin, k, _ = w.shape
+    assert cin % 32 == 0, "input channels must be a multiple of 32"
+    cp = cout_pad or cout
+    assert cp % 32 == 0 and cp >= cout
+    taps = k * k
+    wf = torch.zeros((cp, cin, taps), dtype=torch.float32)
+    wf[:cout] = w.reshape(cout, cin, taps).float()
+    # [ct, r, chunk, s, h, j, tap] -> [ct, chunk, tap, s, h, r, j]
+    wf = wf.reshape(cp // 32, 32, cin // 32, 2, 2, 8, taps).permute(0, 2, 6, 3, 4, 1, 5).contiguous()
+    return wf.reshape(cp // 32, cin // 32, taps, 2, 64, 8).to(dtype)

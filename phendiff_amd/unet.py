@@ -1,0 +1,519 @@
+"""``CustomCondUNet2DModel`` for MI355X: same call surface as the reference's
+``src/cond_unet_2d/cond_unet_2d.py:29-362`` (diffusers ``UNet2DModel`` + class conditioning), executed by
+hand-written HIP kernels through ``libphendiff_hip.so``.
+
+The module tree (names, shapes, construction order = diffusers 0.18.2) only *holds parameters*; no torch
+operator runs in ``forward``.  ``forward`` compiles, per input shape, a static launch plan
+(:class:`UNetPlan`): pre-packed MFMA weights, pre-allocated NHWC activation buffers and pre-filled C-ABI
+argument structs, so one UNet evaluation is ~120 asynchronous kernel launches on the current HIP stream
+with no allocation and no host sync -- capturable in a hipGraph (``phendiff_amd.img2img``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from types import SimpleNamespace
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .packing import pack_conv_weight
+
+_DT = {"f32": (L.PD_F32, torch.float32), "bf16": (L.PD_BF16, torch.bfloat16)}
+
+
+class UNet2DOutput(SimpleNamespace):
+    """``diffusers.models.unet_2d.UNet2DOutput`` stand-in: ``.sample``."""
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameter containers (diffusers state_dict names; cond_unet_2d.py:127-242 + diffusers unet_2d_blocks)
+# ---------------------------------------------------------------------------------------------------
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, cin, tdim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, tdim)
+        self.linear_2 = nn.Linear(tdim, tdim)
+
+
+class _Resnet(nn.Module):
+    def __init__(self, cin, cout, tdim, groups, eps):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(tdim, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+        self.in_channels, self.out_channels = cin, cout
+
+
+class _Attention(nn.Module):
+    def __init__(self, ch, heads, groups, eps):
+        super().__init__()
+        self.heads = heads
+        self.group_norm = nn.GroupNorm(groups, ch, eps=eps)
+        self.to_q = nn.Linear(ch, ch)
+        self.to_k = nn.Linear(ch, ch)
+        self.to_v = nn.Linear(ch, ch)
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Dropout(0.0)])
+
+
+class _Sampler(nn.Module):
+    def __init__(self, ch, stride=1, padding=1):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=stride, padding=padding)
+        self.padding = padding
+
+
+class _Block(nn.Module):
+    """Down / mid / up block container: ``.resnets``, ``.attentions``, ``.downsamplers`` / ``.upsamplers``."""
+
+    def __init__(self):
+        super().__init__()
+
+
+def _down_block(cin, cout, tdim, n, groups, eps, add_down, down_pad, head_dim):
+    b = _Block()
+    b.resnets = nn.ModuleList([_Resnet(cin if i == 0 else cout, cout, tdim, groups, eps) for i in range(n)])
+    if head_dim is not None:
+        b.attentions = nn.ModuleList([_Attention(cout, cout // head_dim, groups, eps) for _ in range(n)])
+    b.downsamplers = nn.ModuleList([_Sampler(cout, 2, down_pad)]) if add_down else None
+    return b
+
+
+def _up_block(cin, prev, cout, tdim, n, groups, eps, add_up, head_dim):
+    b = _Block()
+    rs = []
+    for i in range(n):
+        skip = cin if i == n - 1 else cout
+        rin = prev if i == 0 else cout
+        rs.append(_Resnet(rin + skip, cout, tdim, groups, eps))
+    b.resnets = nn.ModuleList(rs)
+    if head_dim is not None:
+        b.attentions = nn.ModuleList([_Attention(cout, cout // head_dim, groups, eps) for _ in range(n)])
+    b.upsamplers = nn.ModuleList([_Sampler(cout)]) if add_up else None
+    return b
+
+
+def _mid_block(ch, tdim, groups, eps, head_dim, add_attention):
+    b = _Block()
+    b.resnets = nn.ModuleList([_Resnet(ch, ch, tdim, groups, eps) for _ in range(2)])
+    b.attentions = nn.ModuleList([_Attention(ch, ch // head_dim, groups, eps) if add_attention else None])
+    return b
+
+
+_CONFIG_DEFAULTS = dict(
+    sample_size=None, in_channels=3, out_channels=3, center_input_sample=False, time_embedding_type="positional",
+    freq_shift=0, flip_sin_to_cos=True,
+    down_block_types=("DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"),
+    up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
+    block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1, downsample_padding=1,
+    act_fn="silu", attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, resnet_time_scale_shift="default",
+    add_attention=True, class_embed_type=None, num_class_embeds=None)
+
+
+class CustomCondUNet2DModel(nn.Module):
+    """Drop-in for ``src.cond_unet_2d.CustomCondUNet2DModel`` (constructor kwargs = its ``register_to_config``
+    keys, ``cond_unet_2d.py:74-107``).  ``compute_dtype``: ``"bf16"`` (bf16 activations/weights on MFMA, fp32
+    accumulate, fp32 GroupNorm statistics / softmax) or ``"f32"`` (exact-fp32 MFMA; parity mode)."""
+
+    def __init__(self, compute_dtype: str = "bf16", **kwargs):
+        super().__init__()
+        cfg = dict(_CONFIG_DEFAULTS)
+        unknown = set(kwargs) - set(cfg)
+        if unknown:
+            raise TypeError(f"unexpected config keys: {sorted(unknown)}")
+        cfg.update(kwargs)
+        cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
+        cfg["down_block_types"] = tuple(cfg["down_block_types"])
+        cfg["up_block_types"] = tuple(cfg["up_block_types"])
+        self.config = SimpleNamespace(**cfg)
+        c = self.config
+        if len(c.down_block_types) != len(c.up_block_types):  # cond_unet_2d.py:116-119
+            raise ValueError("Must provide the same number of `down_block_types` as `up_block_types`.")
+        if len(c.block_out_channels) != len(c.down_block_types):  # :121-124
+            raise ValueError("Must provide the same number of `block_out_channels` as `down_block_types`.")
+        # what the HIP path implements (everything the shipped configs use)
+        if c.time_embedding_type != "positional" or c.class_embed_type is not None or c.act_fn != "silu" \
+                or c.resnet_time_scale_shift != "default" or c.center_input_sample or c.mid_block_scale_factor != 1:
+            raise NotImplementedError("phendiff_amd: only positional time embedding / nn.Embedding class conditioning / "
+                                      "silu / default time-scale-shift are implemented on the HIP path")
+        for t in c.down_block_types + c.up_block_types:
+            if t not in ("DownBlock2D", "AttnDownBlock2D", "UpBlock2D", "AttnUpBlock2D"):
+                raise NotImplementedError(f"block type {t}")
+        boc = list(c.block_out_channels)
+        if any(ch % 32 for ch in boc):
+            raise NotImplementedError("block_out_channels must be multiples of 32 on the HIP path")
+        if compute_dtype not in _DT:
+            raise ValueError("compute_dtype must be 'bf16' or 'f32'")
+        self.compute_dtype = compute_dtype
+        self.sample_size = c.sample_size
+        tdim = boc[0] * 4
+        self.time_embed_dim = tdim  # cond_unet_2d.py:111-113
+        g, eps = c.norm_num_groups, c.norm_eps
+        self.conv_in = nn.Conv2d(c.in_channels, boc[0], 3, padding=1)
+        self.time_embedding = _TimestepEmbedding(boc[0], tdim)
+        self.class_embedding = nn.Embedding(c.num_class_embeds, tdim) if c.num_class_embeds is not None else None
+        self.down_blocks = nn.ModuleList()
+        out_ch = boc[0]
+        for i, t in enumerate(c.down_block_types):
+            in_ch, out_ch = out_ch, boc[i]
+            hd = None
+            if t == "AttnDownBlock2D":
+                hd = c.attention_head_dim if c.attention_head_dim is not None else out_ch
+            self.down_blocks.append(_down_block(in_ch, out_ch, tdim, c.layers_per_block, g, eps,
+                                                i != len(boc) - 1, c.downsample_padding, hd))
+        mid_hd = c.attention_head_dim if c.attention_head_dim is not None else boc[-1]
+        self.mid_block = _mid_block(boc[-1], tdim, g, eps, mid_hd, c.add_attention)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        out_ch = rev[0]
+        for i, t in enumerate(c.up_block_types):
+            prev, out_ch = out_ch, rev[i]
+            in_ch = rev[min(i + 1, len(boc) - 1)]
+            hd = None
+            if t == "AttnUpBlock2D":
+                hd = c.attention_head_dim if c.attention_head_dim is not None else out_ch
+            self.up_blocks.append(_up_block(in_ch, prev, out_ch, tdim, c.layers_per_block + 1, g, eps,
+                                            i != len(boc) - 1, hd))
+        self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
+        self._plans = {}
+        self._weights = None
+        self.requires_grad_(False)  # inference engine; training kernels are a later round
+
+    # ---- diffusers-like conveniences ------------------------------------------------------------
+    @classmethod
+    def load_config(cls, path):
+        with open(path) as f:
+            d = json.load(f)
+        return {k: v for k, v in d.items() if not k.startswith("_")}
+
+    @classmethod
+    def from_config(cls, config, compute_dtype="bf16", **overrides):
+        d = dict(config) if isinstance(config, dict) else dict(vars(config))
+        d = {k: v for k, v in d.items() if k in _CONFIG_DEFAULTS}
+        d.update(overrides)
+        return cls(compute_dtype=compute_dtype, **d)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def invalidate(self):
+        """Drop packed weights / plans (call after changing parameters in place)."""
+        self._plans = {}
+        self._weights = None
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
+                class_labels: Optional[torch.Tensor] = None, class_emb: Optional[torch.Tensor] = None,
+                return_dict: bool = True) -> Union[UNet2DOutput, Tuple]:
+        if class_labels is not None and class_emb is not None:  # cond_unet_2d.py:268-269
+            raise ValueError("Cannot specify both class_labels and class_emb")
+        if self.class_embedding is not None and class_labels is None and class_emb is None:  # :298-301
+            raise ValueError("either class_labels or class_emb should be provided when doing class conditioning")
+        if not sample.is_cuda:
+            raise L.PhenDiffHipError("phendiff_amd runs on MI355X only (no CPU fallback): move the model and inputs to 'cuda'")
+        B = sample.shape[0]
+        dev = sample.device
+        # cond_unet_2d.py:276-287: scalar / 0-dim / (B,) timesteps broadcast to the batch
+        if not torch.is_tensor(timestep):
+            ts = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
+        else:
+            ts = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+            if ts.numel() == 1:
+                ts = ts.expand(B)
+            ts = ts.contiguous()
+        plan = self.plan_for(B, sample.shape[2], sample.shape[3], dev)
+        x = sample.contiguous().to(torch.float32)
+        labels = class_labels.to(device=dev, dtype=torch.int64).contiguous() if class_labels is not None else None
+        cemb = class_emb.to(device=dev, dtype=torch.float32).contiguous() if class_emb is not None else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        temb = plan.temb_rows(ts, labels, cemb, stream)
+        out = torch.empty_like(x)
+        plan.run(x.data_ptr(), temb.data_ptr(), out.data_ptr(), stream)
+        plan.keepalive = (x, ts, labels, cemb)
+        if not return_dict:
+            return (out,)
+        return UNet2DOutput(sample=out)
+
+    def plan_for(self, B, H, W, device):
+        key = (B, H, W, str(device), self.compute_dtype)
+        p = self._plans.get(key)
+        if p is None:
+            if self._weights is None:
+                self._weights = _PackedWeights(self, device)
+            p = UNetPlan(self, self._weights, B, H, W, device)
+            self._plans[key] = p
+        return p
+
+
+# ---------------------------------------------------------------------------------------------------
+class _PackedWeights:
+    """Weights in kernel layouts (device).  Built once per model / device / dtype."""
+
+    def __init__(self, m: CustomCondUNet2DModel, device):
+        self.code, self.tdt = _DT[m.compute_dtype]
+        dev = device
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.conv_in_w, self.conv_in_b = f32(m.conv_in.weight), f32(m.conv_in.bias)
+        te = m.time_embedding
+        self.w1T, self.b1 = f32(te.linear_1.weight.t()), f32(te.linear_1.bias)
+        self.w2T, self.b2 = f32(te.linear_2.weight.t()), f32(te.linear_2.bias)
+        self.class_table = f32(m.class_embedding.weight) if m.class_embedding is not None else None
+        self.resnets = {}
+        self.attns = {}
+        self.samplers = {}
+        proj_w, proj_b, off = [], [], 0
+        for name, r in self._iter(m, _Resnet):
+            e = SimpleNamespace()
+            e.cin, e.cout = r.in_channels, r.out_channels
+            e.g1, e.be1 = f32(r.norm1.weight), f32(r.norm1.bias)
+            e.g2, e.be2 = f32(r.norm2.weight), f32(r.norm2.bias)
+            e.w1, e.b1 = self._pack(r.conv1.weight), f32(r.conv1.bias)
+            e.w2, e.b2 = self._pack(r.conv2.weight), f32(r.conv2.bias)
+            if r.conv_shortcut is not None:
+                e.ws, e.bs = self._pack(r.conv_shortcut.weight), f32(r.conv_shortcut.bias)
+            else:
+                e.ws = e.bs = None
+            e.eps = r.norm1.eps
+            e.temb_off = off
+            off += e.cout
+            proj_w.append(r.time_emb_proj.weight.detach())
+            proj_b.append(r.time_emb_proj.bias.detach())
+            self.resnets[name] = e
+        self.proj_dim = off
+        self.wpT = f32(torch.cat(proj_w, 0).t())
+        self.bp = f32(torch.cat(proj_b, 0))
+        for name, a in self._iter(m, _Attention):
+            e = SimpleNamespace()
+            e.heads = a.heads
+            e.g, e.be, e.eps = f32(a.group_norm.weight), f32(a.group_norm.bias), a.group_norm.eps
+            wqkv = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach()
+            e.wqkv = self._pack(wqkv[:, :, None, None])
+            e.bqkv = f32(torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias], 0))
+            e.wo, e.bo = self._pack(a.to_out[0].weight.detach()[:, :, None, None]), f32(a.to_out[0].bias)
+            self.attns[name] = e
+        for name, s in self._iter(m, _Sampler):
+            e = SimpleNamespace()
+            e.w, e.b, e.padding = self._pack(s.conv.weight), f32(s.conv.bias), s.padding
+            self.samplers[name] = e
+        self.gn_out = (f32(m.conv_norm_out.weight), f32(m.conv_norm_out.bias), m.conv_norm_out.eps)
+        co = m.conv_out.weight.shape[0]
+        self.conv_out_pad = ((co + 31) // 32) * 32
+        self.conv_out_w = self._pack(m.conv_out.weight, self.conv_out_pad)
+        b = torch.zeros(self.conv_out_pad, dtype=torch.float32)
+        b[:co] = m.conv_out.bias.detach().float().cpu()
+        self.conv_out_b = b.to(dev)
+
+    @staticmethod
+    def _iter(m, cls):
+        for name, mod in m.named_modules():
+            if isinstance(mod, cls):
+                yield name, mod
+
+    def _pack(self, w, cout_pad=None):
+        return pack_conv_weight(w.detach().float().cpu(), self.tdt, cout_pad).to(self.conv_in_w.device)
+
+
+class _Op:
+    __slots__ = ("fn", "args", "what")
+
+    def __init__(self, fn, args, what):
+        self.fn, self.args, self.what = fn, args, what
+
+
+class UNetPlan:
+    """Static launch plan of one UNet forward for a fixed (B, H, W)."""
+
+    def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, B, H, W, device):
+        self.lib = L.lib()
+        self.m, self.w = m, w
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.code, self.tdt = w.code, w.tdt
+        c = m.config
+        nlev = len(c.block_out_channels)
+        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
+            raise ValueError(f"sample size {(H, W)} must be a multiple of {1 << (nlev - 1)}")
+        self.ops = []
+        self.bufs = []          # keep every device buffer alive
+        self.groups = c.norm_num_groups
+        self.temb_args = None
+        self._temb_ptr_fields = []
+        self._in_args = None
+        self._out_args = None
+        self._build()
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def _act(self, h, w, ch):
+        t = torch.empty((self.B, h, w, ch), dtype=self.tdt, device=self.device)
+        self.bufs.append(t)
+        return t
+
+    def _f32(self, *shape):
+        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        self.bufs.append(t)
+        return t
+
+    # ---- op emitters -----------------------------------------------------------------------------
+    def _gn(self, x0, x1, gamma, beta, eps):
+        B, h, w, c0 = x0.shape
+        c1 = x1.shape[3] if x1 is not None else 0
+        C_ = c0 + c1
+        hw = h * w
+        splits = max(1, min(hw // 64, max(1, 2048 // self.B)))
+        partial = torch.empty((self.B, splits, C_, 2), dtype=torch.float64, device=self.device)
+        scale, shift = self._f32(self.B, C_), self._f32(self.B, C_)
+        self.bufs.append(partial)
+        a = L.GnStatsArgs(dtype=self.code, B=self.B, HW=hw, C0=c0, C1=c1, groups=self.groups, eps=eps,
+                          x0=x0.data_ptr(), x1=L.ptr(x1), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+                          partial=partial.data_ptr(), splits=splits, scale=scale.data_ptr(), shift=shift.data_ptr())
+        self.ops.append(_Op(self.lib.pd_gn_stats, a, "gn_stats"))
+        return scale, shift
+
+    def _conv(self, x0, x1, wpk, bias, cout, *, ksize=3, stride=1, pad=1, upsample=0, silu=0, gn=None, temb_off=None,
+              residual=None, out_mode=L.PD_OUT_NHWC, heads=0, cout_pad=None, y=None):
+        B, hin, win, c0 = x0.shape
+        c1 = x1.shape[3] if x1 is not None else 0
+        hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
+        extra = 1 if (ksize == 3 and pad == 0) else 0
+        hout = (hc + 2 * pad + extra - ksize) // stride + 1
+        wout = (wc + 2 * pad + extra - ksize) // stride + 1
+        cout_pad = cout_pad or cout
+        if y is None:
+            if out_mode == L.PD_OUT_NHWC:
+                y = self._act(hout, wout, cout)
+            elif out_mode == L.PD_OUT_QKV_HEADS:
+                y = torch.empty((3, B, heads, hout * wout, 8), dtype=self.tdt, device=self.device)
+                self.bufs.append(y)
+        a = L.ConvArgs(dtype=self.code, B=B, Hin=hin, Win=win, Hout=hout, Wout=wout, C0=c0, C1=c1, Cout=cout,
+                       Cout_pad=cout_pad, ksize=ksize, stride=stride, pad=pad, upsample=upsample, silu=silu,
+                       out_mode=out_mode, heads=heads, x0=x0.data_ptr(), x1=L.ptr(x1),
+                       scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None,
+                       w_packed=wpk.data_ptr(), bias=bias.data_ptr(), temb=None, temb_stride=self.w.proj_dim,
+                       residual=L.ptr(residual), y=L.ptr(y))
+        if temb_off is not None:
+            self._temb_ptr_fields.append((a, temb_off))
+        self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}"))
+        return y, a
+
+    def _resnet(self, name, x0, x1=None):
+        e = self.w.resnets[name]
+        gn1 = self._gn(x0, x1, e.g1, e.be1, e.eps)
+        h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=e.temb_off)
+        gn2 = self._gn(h1, None, e.g2, e.be2, e.eps)
+        if e.ws is not None:
+            sc, _ = self._conv(x0, x1, e.ws, e.bs, e.cout, ksize=1, pad=0)
+        else:
+            assert x1 is None
+            sc = x0
+        out, _ = self._conv(h1, None, e.w2, e.b2, e.cout, silu=1, gn=gn2, residual=sc)
+        return out
+
+    def _attn(self, name, x):
+        e = self.w.attns[name]
+        B, h, w, ch = x.shape
+        if ch != e.heads * 8:
+            raise NotImplementedError(f"pd_attn_d8 implements head_dim 8 only (got {ch // e.heads})")
+        gn = self._gn(x, None, e.g, e.be, e.eps)
+        qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, out_mode=L.PD_OUT_QKV_HEADS,
+                            heads=e.heads)
+        o = self._act(h, w, ch)
+        a = L.AttnArgs(dtype=self.code, B=B, heads=e.heads, N=h * w, q=qkv[0].data_ptr(), k=qkv[1].data_ptr(),
+                       v=qkv[2].data_ptr(), out=o.data_ptr())
+        self.ops.append(_Op(self.lib.pd_attn_d8, a, "attn_d8"))
+        out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
+        return out
+
+    def _build(self):
+        m, w, c = self.m, self.w, self.m.config
+        boc = c.block_out_channels
+        B, H, W = self.B, self.H, self.W
+        # temb (filled per call)
+        self.temb_args = L.TembArgs(rows=B, c0=boc[0], tdim=m.time_embed_dim, proj_dim=w.proj_dim,
+                                    flip_sin_to_cos=int(c.flip_sin_to_cos), freq_shift=float(c.freq_shift),
+                                    num_classes=(c.num_class_embeds or 0), w1=w.w1T.data_ptr(), b1=w.b1.data_ptr(),
+                                    w2=w.w2T.data_ptr(), b2=w.b2.data_ptr(), class_table=L.ptr(w.class_table),
+                                    wp=w.wpT.data_ptr(), bp=w.bp.data_ptr())
+        # conv_in
+        a0 = self._act(H, W, boc[0])
+        self._in_args = L.ConvInArgs(dtype=self.code, B=B, H=H, W=W, Cin=c.in_channels, Cout=boc[0],
+                                     x=None, w=w.conv_in_w.data_ptr(), bias=w.conv_in_b.data_ptr(), y=a0.data_ptr())
+        self.ops.append(_Op(self.lib.pd_conv_in, self._in_args, "conv_in"))
+        h = a0
+        skips = [a0]
+        for i, blk in enumerate(m.down_blocks):
+            has_attn = hasattr(blk, "attentions")
+            for j in range(len(blk.resnets)):
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h)
+                if has_attn:
+                    h = self._attn(f"down_blocks.{i}.attentions.{j}", h)
+                skips.append(h)
+            if blk.downsamplers is not None:
+                s = w.samplers[f"down_blocks.{i}.downsamplers.0"]
+                h, _ = self._conv(h, None, s.w, s.b, h.shape[3], stride=2, pad=s.padding)
+                skips.append(h)
+        h = self._resnet("mid_block.resnets.0", h)
+        if m.mid_block.attentions[0] is not None:
+            h = self._attn("mid_block.attentions.0", h)
+        h = self._resnet("mid_block.resnets.1", h)
+        for i, blk in enumerate(m.up_blocks):
+            has_attn = hasattr(blk, "attentions")
+            for j in range(len(blk.resnets)):
+                skip = skips.pop()
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", h, skip)
+                if has_attn:
+                    h = self._attn(f"up_blocks.{i}.attentions.{j}", h)
+            if blk.upsamplers is not None:
+                s = w.samplers[f"up_blocks.{i}.upsamplers.0"]
+                h, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+        g, be, eps = w.gn_out
+        gn = self._gn(h, None, g, be, eps)
+        _, self._out_args = self._conv(h, None, w.conv_out_w, w.conv_out_b, c.out_channels, silu=1, gn=gn,
+                                       out_mode=L.PD_OUT_NCHW_F32, cout_pad=w.conv_out_pad, y=None)
+        self._cur = (None, None, None)
+
+    # ---- execution -------------------------------------------------------------------------------
+    def temb_rows(self, ts, labels, class_emb, stream, rows=None, out=None):
+        """Launch pd_temb for ``rows`` (default B) (timestep, class) rows -> [rows][proj_dim] fp32 table."""
+        rows = rows or self.B
+        if out is None:
+            out = torch.empty((rows, self.w.proj_dim), dtype=torch.float32, device=self.device)
+        a = self.temb_args
+        a.rows = rows
+        a.timesteps, a.labels, a.class_emb = ts.data_ptr(), L.ptr(labels), L.ptr(class_emb)
+        a.emb, a.proj = None, out.data_ptr()
+        L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
+        return out
+
+    def run(self, x_ptr, temb_ptr, out_ptr, stream):
+        """One UNet evaluation: NCHW fp32 at ``x_ptr`` -> NCHW fp32 prediction at ``out_ptr``; ``temb_ptr`` is the
+        [B][proj_dim] fp32 table of this step.  Asynchronous, allocation-free."""
+        if self._cur != (x_ptr, temb_ptr, out_ptr):
+            self._in_args.x = x_ptr
+            self._out_args.y = out_ptr
+            for a, off in self._temb_ptr_fields:
+                a.temb = temb_ptr + 4 * off
+            self._cur = (x_ptr, temb_ptr, out_ptr)
+        byref, check = C.byref, L.check
+        for op in self.ops:
+            rc = op.fn(byref(op.args), stream)
+            if rc:
+                check(rc, op.what)

@@ -1,0 +1,57 @@
+"""Generates the committed golden vectors from the CPU oracle (run here, in the build container):
+
+    python tests/golden/make_golden.py
+
+The reference itself cannot produce fixtures (its hot path imports diffusers==0.18.2, absent offline; SURVEY.md
+section 8c), so these vectors pin the ORACLE's outputs: the GPU tests compare the HIP path with them, and the CPU
+tests re-derive them from the oracle to catch drift.  Weights: torch default init under manual_seed(0) in the
+oracle's construction order; inverse-scheduler variant "0.18.2".
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import (CondUNet2DRef, ConditionalDDIMPipelineRef, DDIMInverseSchedulerRef, DDIMSchedulerRef,  # noqa: E402
+                    UNET_CONFIGS, ddib_ref)
+
+SCHED_3K = dict(num_train_timesteps=3000, beta_start=1e-4, beta_end=0.02, beta_schedule="scaled_linear",
+                clip_sample=True, clip_sample_range=1.0, prediction_type="v_prediction",
+                rescale_betas_zero_snr=True, timestep_spacing="trailing")
+
+
+def synth_batch(B, size, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    labels = torch.arange(B) % 2
+    x = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    x = (x + 0.25 * (2 * labels.float() - 1).view(B, 1, 1, 1)).clamp(-1, 1)
+    return x, labels
+
+
+def main():
+    torch.manual_seed(0)
+    unet = CondUNet2DRef(**dict(UNET_CONFIGS["super_small"], sample_size=32)).eval()
+    sched = DDIMSchedulerRef(**SCHED_3K)
+    pipe = ConditionalDDIMPipelineRef(unet, sched)
+    x, labels = synth_batch(4, 32)
+    out, inverted = ddib_ref(pipe, x, labels, 1 - labels, 4)
+    with torch.no_grad():
+        eps = unet(x, 1500, class_labels=labels).sample
+    np.savez_compressed(os.path.join(HERE, "ddib_super_small_32_s4.npz"), images=x.numpy(), labels=labels.numpy(),
+                        inverted=inverted.numpy(), out_images=out, unet_out_t1500=eps.numpy())
+    # scheduler tables (int64 grids are bit-exact requirements)
+    sched.set_timesteps(50)
+    inv = DDIMInverseSchedulerRef.from_config(sched.config)
+    inv.set_timesteps(50)
+    np.savez_compressed(os.path.join(HERE, "scheduler_3k.npz"), alphas_cumprod=sched.alphas_cumprod.numpy(),
+                        timesteps_50=sched.timesteps.numpy(), inv_alphas_cumprod=inv.alphas_cumprod.numpy(),
+                        inv_timesteps_50=inv.timesteps.numpy())
+    print("wrote golden fixtures to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,291 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against plain PyTorch fp32 on the same seeded
+inputs (the torch ops are exactly what the oracle's modules dispatch to).  fp32 mode must agree to fp32
+round-off; bf16 mode to bf16 round-off of inputs/outputs (tolerances stated per test)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
+# relative L2 error bounds: fp32 MFMA is an exact fp32 fma chain; bf16 = 8-bit mantissa on inputs and outputs
+TOL = {"f32": 2e-5, "bf16": 1.2e-2}
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import phendiff_amd._lib as L
+    from phendiff_amd.packing import pack_conv_weight
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return L, L.lib(), pack_conv_weight, torch.device("cuda:0")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def nhwc(x, tdt):  # NCHW fp32 -> NHWC dtype (device)
+    return x.permute(0, 2, 3, 1).contiguous().to(tdt)
+
+
+def run_conv(env, mode, x0, w, b, *, x1=None, ksize=3, stride=1, pad=1, upsample=0, silu=0, scale=None, shift=None,
+             temb=None, residual=None, out_mode=0, heads=0, cout_pad=None):
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    B, _, hin, win = x0.shape
+    cout = w.shape[0]
+    cp = cout_pad or cout
+    hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
+    extra = 1 if (ksize == 3 and pad == 0) else 0
+    hout = (hc + 2 * pad + extra - ksize) // stride + 1
+    wout = (wc + 2 * pad + extra - ksize) // stride + 1
+    X0 = nhwc(x0.to(dev), tdt)
+    X1 = nhwc(x1.to(dev), tdt) if x1 is not None else None
+    wp = pack(w.float().cpu(), tdt, cp).to(dev)
+    bias = torch.zeros(cp)
+    bias[:cout] = b
+    bias = bias.to(dev)
+    if out_mode == 0:
+        y = torch.full((B, hout, wout, cout), float("nan"), dtype=tdt, device=dev)
+    elif out_mode == 1:
+        y = torch.full((B, cout, hout, wout), float("nan"), dtype=torch.float32, device=dev)
+    else:
+        y = torch.full((3, B, heads, hout * wout, 8), float("nan"), dtype=tdt, device=dev)
+    sc = scale.to(dev).float().contiguous() if scale is not None else None
+    sh = shift.to(dev).float().contiguous() if shift is not None else None
+    tb = temb.to(dev).float().contiguous() if temb is not None else None
+    res = nhwc(residual.to(dev), tdt) if residual is not None else None
+    a = L.ConvArgs(dtype=code, B=B, Hin=hin, Win=win, Hout=hout, Wout=wout, C0=x0.shape[1],
+                   C1=(x1.shape[1] if x1 is not None else 0), Cout=cout, Cout_pad=cp, ksize=ksize, stride=stride, pad=pad,
+                   upsample=upsample, silu=silu, out_mode=out_mode, heads=heads, x0=X0.data_ptr(), x1=L.ptr(X1),
+                   scale=L.ptr(sc), shift=L.ptr(sh), w_packed=wp.data_ptr(), bias=bias.data_ptr(), temb=L.ptr(tb),
+                   temb_stride=(tb.shape[1] if tb is not None else 0), residual=L.ptr(res), y=y.data_ptr())
+    L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+    torch.cuda.synchronize()
+    return y
+
+
+def bf16_round(t, mode):
+    return t.to(torch.bfloat16).float() if mode == "bf16" else t
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 32, 96, 16, 16), (3, 64, 32, 8, 8), (1, 64, 128, 40, 72),
+                                   (2, 128, 64, 5, 7)])
+def test_conv3x3_plain(env, mode, shape):
+    B, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, cin, h, w_, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    y = run_conv(env, mode, x, w, b)
+    ref = F.conv2d(bf16_round(x, mode), bf16_round(w, mode), b, padding=1)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_conv3x3_fused_prologue_epilogue(env, mode):
+    """GroupNorm-affine + SiLU prologue (zero padding AFTER the transform), concat of two sources,
+    + bias + temb + residual epilogue: ResnetBlock2D.conv1 / conv2 as fused."""
+    g = torch.Generator().manual_seed(2)
+    B, c0, c1, cout, h, w_ = 2, 64, 32, 64, 32, 32
+    x0, x1 = torch.randn(B, c0, h, w_, generator=g), torch.randn(B, c1, h, w_, generator=g)
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / ((c0 + c1) * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    scale, shift = torch.rand(B, c0 + c1, generator=g) + 0.5, torch.randn(B, c0 + c1, generator=g)
+    temb = torch.randn(B, 200, generator=g)
+    res = torch.randn(B, cout, h, w_, generator=g)
+    y = run_conv(env, mode, x0, w, b, x1=x1, silu=1, scale=scale, shift=shift, temb=temb[:, 17:], residual=res)
+    xin = torch.cat([bf16_round(x0, mode), bf16_round(x1, mode)], 1)
+    xin = bf16_round(F.silu(xin * scale[:, :, None, None] + shift[:, :, None, None]), mode)
+    ref = F.conv2d(xin, bf16_round(w, mode), b, padding=1) + temb[:, 17:17 + cout, None, None] + bf16_round(res, mode)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(32, 32), (16, 16), (64, 96), (8, 8)])
+def test_conv3x3_stride2(env, mode, hw):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, *hw, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g)
+    y = run_conv(env, mode, x, w, b, stride=2, pad=1)
+    ref = F.conv2d(bf16_round(x, mode), bf16_round(w, mode), b, stride=2, padding=1)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+    # Downsample2D(padding=0): zero-pad (0,1,0,1) then pad-0 stride-2 conv
+    y = run_conv(env, mode, x, w, b, stride=2, pad=0)
+    ref = F.conv2d(F.pad(bf16_round(x, mode), (0, 1, 0, 1)), bf16_round(w, mode), b, stride=2, padding=0)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(16, 16), (8, 8), (32, 48), (4, 4)])
+def test_conv3x3_upsample(env, mode, hw):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 64, *hw, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g)
+    y = run_conv(env, mode, x, w, b, upsample=1)
+    ref = F.conv2d(F.interpolate(bf16_round(x, mode), scale_factor=2.0, mode="nearest"), bf16_round(w, mode), b, padding=1)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_conv1x1_and_output_modes(env, mode):
+    g = torch.Generator().manual_seed(5)
+    B, cin, h, w_ = 2, 64, 16, 16
+    x = torch.randn(B, cin, h, w_, generator=g)
+    # 1x1 shortcut with residual
+    w = torch.randn(96, cin, 1, 1, generator=g) / 8.0
+    b = torch.randn(96, generator=g)
+    y = run_conv(env, mode, x, w, b, ksize=1, pad=0)
+    ref = F.conv2d(bf16_round(x, mode), bf16_round(w, mode), b)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+    # conv_out: Cout=3 padded to 32, NCHW fp32 output
+    w3 = torch.randn(3, cin, 3, 3, generator=g) / 24.0
+    b3 = torch.randn(3, generator=g)
+    y = run_conv(env, mode, x, w3, b3, out_mode=1, cout_pad=32)
+    ref = F.conv2d(bf16_round(x, mode), bf16_round(w3, mode), b3, padding=1)
+    assert rel(y, ref) < TOL[mode]
+    # QKV projection, head-major output [3][B][heads][N][8]
+    heads = cin // 8
+    wq = torch.randn(3 * cin, cin, 1, 1, generator=g) / 8.0
+    bq = torch.randn(3 * cin, generator=g)
+    y = run_conv(env, mode, x, wq, bq, ksize=1, pad=0, out_mode=2, heads=heads)
+    ref = F.conv2d(bf16_round(x, mode), bf16_round(wq, mode), bq)  # [B, 3C, h, w]
+    ref = ref.view(B, 3, heads, 8, h * w_).permute(1, 0, 2, 4, 3)
+    assert rel(y.float(), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 64, 0, 32 * 32), (2, 256, 128, 16 * 16), (1, 128, 64, 8 * 8), (3, 256, 256, 64)])
+def test_gn_stats(env, mode, cfg):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, c0, c1, hw = cfg
+    g = torch.Generator().manual_seed(6)
+    Cc = c0 + c1
+    x = torch.randn(B, Cc, hw, generator=g) * 2 + 0.7
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    xs = bf16_round(x, mode)
+    X0 = xs[:, :c0].permute(0, 2, 1).contiguous().to(tdt).to(dev)
+    X1 = xs[:, c0:].permute(0, 2, 1).contiguous().to(tdt).to(dev) if c1 else None
+    splits = 4
+    partial = torch.empty((B, splits, Cc, 2), dtype=torch.float64, device=dev)
+    scale = torch.empty((B, Cc), device=dev)
+    shift = torch.empty((B, Cc), device=dev)
+    gm, bt = gamma.to(dev), beta.to(dev)
+    a = L.GnStatsArgs(dtype=code, B=B, HW=hw, C0=c0, C1=c1, groups=32, eps=1e-5, x0=X0.data_ptr(), x1=L.ptr(X1),
+                      gamma=gm.data_ptr(), beta=bt.data_ptr(), partial=partial.data_ptr(), splits=splits,
+                      scale=scale.data_ptr(), shift=shift.data_ptr())
+    L.check(lib.pd_gn_stats(C.byref(a), stream()), "pd_gn_stats")
+    torch.cuda.synchronize()
+    ref = F.group_norm(xs, 32, gamma, beta, eps=1e-5)
+    got = xs * scale.cpu()[:, :, None] + shift.cpu()[:, :, None]
+    assert rel(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 4, 64), (1, 32, 1024), (2, 8, 200), (1, 2, 16)])
+def test_attention(env, mode, cfg):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, N = cfg
+    g = torch.Generator().manual_seed(7)
+    q, k, v = (bf16_round(torch.randn(B, heads, N, 8, generator=g) * 1.5, mode) for _ in range(3))
+    Q, K, V = (t.to(tdt).to(dev).contiguous() for t in (q, k, v))
+    out = torch.full((B, N, heads * 8), float("nan"), dtype=tdt, device=dev)
+    a = L.AttnArgs(dtype=code, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), out=out.data_ptr())
+    L.check(lib.pd_attn_d8(C.byref(a), stream()), "pd_attn_d8")
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, heads * 8)
+    assert rel(out.float(), ref) < (2e-5 if mode == "f32" else 1.5e-2)
+
+
+def test_attention_online_softmax_rescale(env):
+    """Force the running-max rescale branch: one key far above the rest late in the sequence (guide rule 26)."""
+    L, lib, _, dev = env
+    g = torch.Generator().manual_seed(8)
+    B, heads, N = 1, 2, 512
+    q, k, v = (torch.randn(B, heads, N, 8, generator=g) for _ in range(3))
+    k[:, :, 300] = q[:, :, 5] * 6.0   # spikes the score of query 5 (and others) at key 300
+    k[:, :, 77] = q[:, :, 130] * 9.0
+    Q, K, V = (t.to(dev).contiguous() for t in (q, k, v))
+    out = torch.empty((B, N, heads * 8), device=dev)
+    a = L.AttnArgs(dtype=0, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), out=out.data_ptr())
+    L.check(lib.pd_attn_d8(C.byref(a), stream()), "pd_attn_d8")
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).transpose(1, 2).reshape(B, N, heads * 8)
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-4
+
+
+def test_conv_in(env):
+    L, lib, _, dev = env
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 24, 40, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) / 5
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    for mode in ("f32", "bf16"):
+        code, tdt = DT[mode]
+        y = torch.empty((2, 24, 40, 64), dtype=tdt, device=dev)
+        X, W_, Bb = x.to(dev), w.to(dev), b.to(dev)
+        a = L.ConvInArgs(dtype=code, B=2, H=24, W=40, Cin=3, Cout=64, x=X.data_ptr(), w=W_.data_ptr(), bias=Bb.data_ptr(), y=y.data_ptr())
+        L.check(lib.pd_conv_in(C.byref(a), stream()), "pd_conv_in")
+        torch.cuda.synchronize()
+        assert rel(y.float().permute(0, 3, 1, 2), ref) < (1e-6 if mode == "f32" else 4e-3)
+
+
+@pytest.mark.parametrize("pt", ["epsilon", "sample", "v_prediction"])
+def test_ddim_step_matches_oracle(env, pt):
+    from oracle import DDIMSchedulerRef, DDIMInverseSchedulerRef
+    import phendiff_amd as P
+    dev = env[3]
+    cfg = dict(P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"], prediction_type=pt)
+    g = torch.Generator().manual_seed(10)
+    x, out = torch.randn(2, 3, 16, 16, generator=g), torch.randn(2, 3, 16, 16, generator=g)
+    for S in (4, 50):
+        ref, got = DDIMSchedulerRef(**cfg), P.DDIMScheduler(**cfg)
+        ref.set_timesteps(S); got.set_timesteps(S)
+        iref, igot = DDIMInverseSchedulerRef.from_config(ref.config), P.DDIMInverseScheduler.from_config(got.config)
+        iref.set_timesteps(S); igot.set_timesteps(S)
+        for r_, g_ in ((ref, got), (iref, igot)):
+            assert torch.equal(r_.timesteps, g_.timesteps)      # bit-exact step indexing
+            for t in r_.timesteps[1:-1:max(1, S // 4)].tolist() + [int(r_.timesteps[-1])]:
+                a = r_.step(out, torch.tensor(t), x)
+                b = g_.step(out.to(dev), torch.tensor(t), x.to(dev))
+                assert torch.allclose(b.prev_sample.cpu(), a.prev_sample, rtol=1e-5, atol=1e-6), (pt, S, t)
+                assert torch.allclose(b.pred_original_sample.cpu(), a.pred_original_sample, rtol=1e-5, atol=1e-6)
+    ts = torch.tensor([5, 1500])
+    noise = torch.randn(2, 3, 16, 16, generator=g)
+    assert torch.allclose(got.add_noise(x.to(dev), noise.to(dev), ts).cpu(), ref.add_noise(x, noise, ts), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(got.get_velocity(x.to(dev), noise.to(dev), ts).cpu(), ref.get_velocity(x, noise, ts), rtol=1e-6, atol=1e-6)
+
+
+def test_temb(env):
+    from oracle import CondUNet2DRef
+    import phendiff_amd as P
+    dev = env[3]
+    torch.manual_seed(0)
+    cfg = {k: v for k, v in P.UNET_CONFIGS["super_small"].items() if k in CondUNet2DRef.__init__.__code__.co_varnames}
+    r = CondUNet2DRef(**dict(cfg, sample_size=32)).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype="f32", **dict(P.UNET_CONFIGS["super_small"], sample_size=32))
+    m.load_state_dict(r.state_dict())
+    m.to(dev)
+    plan = m.plan_for(3, 32, 32, dev)
+    ts = torch.tensor([2999.0, 59.0, 1234.0], device=dev)
+    labels = torch.tensor([0, 1, 1], device=dev)
+    got = plan.temb_rows(ts, labels, None, stream())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        embs = torch.stack([r.embed(1, int(t), torch.tensor([int(l)]))[0] for t, l in zip(ts.cpu(), labels.cpu())])
+        ref = torch.cat([res.time_emb_proj(F.silu(embs)) for _, res in r.named_modules() if hasattr(res, "time_emb_proj")], 1)
+    assert got.shape == ref.shape == (3, 2752)
+    assert rel(got, ref) < 2e-5
