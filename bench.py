@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- img2img images/sec (50-step DDIM invert + 50-step denoise, 256x256), BASELINE.json's metric.
+
+One "step" = one DDIB class transfer of one synthetic batch per GPU: `super_small` UNet at
+sample_size 256, `3k_steps_clipping_rescaling` scheduler, S = 50 + 50, inputs resident in HBM when the timed
+region starts, output = float NHWC [0,1] images in HBM (PNG encode / dataset decode excluded).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Images are independent: each rank transfers its own batches, no collective on the data path ("scaling": "weak").
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# SURVEY.md 8(d) / BASELINE.md 2: algorithmic work per UNet forward per image, super_small @256^2
+FWD_GFLOP_PER_IMAGE = 376.0
+FWD_ACT_MB_PER_IMAGE_BF16 = 691.8
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
+
+
+def synth_batch(B, size, seed):
+    """x ~ U[-1,1] with a class-dependent offset, labels = arange(B) % 2."""
+    g = torch.Generator().manual_seed(seed)
+    labels = torch.arange(B) % 2
+    x = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    x = (x + 0.25 * (2 * labels.float() - 1).view(B, 1, 1, 1)).clamp(-1, 1)
+    return x, labels
+
+
+def cpu_baseline(model_name, size, S, state_dict, seconds_budget=30.0):
+    """The oracle (plain-PyTorch CPU fp32 restatement of the reference path) timed on this box's host cores on a
+    bounded sample: B = 1 image, the first k inversion + first k denoising steps of the S-step schedules (per-step
+    cost is step-independent), extrapolated to the 2*S-step trajectory."""
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef, DDIMInverseSchedulerRef, DDIMSchedulerRef
+    torch.set_num_threads(os.cpu_count() or 1)
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    unet = CondUNet2DRef(**{k: v for k, v in dict(P.UNET_CONFIGS[model_name], sample_size=size).items() if k in keys}).eval()
+    unet.load_state_dict(state_dict)
+    fwd = DDIMSchedulerRef(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+    fwd.set_timesteps(S)
+    inv = DDIMInverseSchedulerRef.from_config(fwd.config)
+    inv.set_timesteps(S)
+    x, labels = synth_batch(1, size, 1234)
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        unet(x, 0, class_labels=labels)  # page in / warm the allocator (untimed)
+        k = 0
+        while k < 3 or (time.time() - t_start < seconds_budget * 0.6 and k < 6):
+            for sched, ts, lab in ((inv, inv.timesteps, labels), (fwd, fwd.timesteps, 1 - labels)):
+                t0 = time.perf_counter()
+                out = unet(x, ts[k], class_labels=lab).sample
+                x2 = sched.step(out, ts[k], x).prev_sample
+                times.append(time.perf_counter() - t0)
+            k += 1
+            del x2
+    times.sort()
+    t_step = times[len(times) // 2]
+    return {"value": 1.0 / (2 * S * t_step), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (CPU fp32 torch), B=1 @{size}x{size}, median of {len(times)} UNet+scheduler steps "
+                      f"({k} inversion + {k} denoising of the S={S} schedules), extrapolated to {2 * S} steps; "
+                      f"t_step={t_step:.3f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--model", default="super_small")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import phendiff_amd as P
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    B, S, size = args.batch, args.inference_steps, args.size
+    torch.manual_seed(0)  # identical random-init weights on every rank (no checkpoint: no network)
+    unet = P.CustomCondUNet2DModel(compute_dtype=args.dtype, **dict(P.UNET_CONFIGS[args.model], sample_size=size))
+    state_dict = {k: v.clone() for k, v in unet.state_dict().items()}
+    pipe = P.ConditionalDDIMPipeline(unet.to(dev), P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
+    runner = P.DDIBGraph(pipe, batch_size=B, num_inference_steps=S, use_graph=not args.no_graph)
+    x, labels = synth_batch(B, size, 1234 + rank)
+    x, labels = x.to(dev), labels.to(dev)
+    target = P.swap_binary_labels(labels)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        runner.run(x, labels, target)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.run(x, labels, target)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(runner.images).all()
+
+    images = world * B * args.steps
+    value = images / elapsed
+    res = {
+        "metric": "img2img images/sec (50-step DDIM invert+denoise, 256x256)", "value": round(value, 4), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"configs[2]: {size}x{size} pipeline_conditional_ddim invert->class-swap->denoise, "
+                               f"{S}+{S} DDIM steps, {args.model} UNet (random init, seed 0), 3k_steps_clipping_rescaling, "
+                               f"{B} images/GPU/step sharded over {world} GPU(s), no collectives",
+                   "batch_per_gpu": B, "global_batch": B * world, "inference_steps": S, "image_size": size,
+                   "hipgraph": not args.no_graph},
+    }
+    # whole-step roofline numbers the north_star asks for (per GPU): algorithmic activation bytes / flops per image
+    per_gpu = value / world
+    esz = 1.0 if args.dtype == "bf16" else 2.0
+    if args.model == "super_small" and size == 256:
+        res["step_rooflines"] = {
+            "hbm_frac": round(per_gpu * 2 * S * FWD_ACT_MB_PER_IMAGE_BF16 * esz / 1000.0 / PEAK_HBM_GBS, 4),
+            "mfma_frac": round(per_gpu * 2 * S * FWD_GFLOP_PER_IMAGE / 1000.0 / PEAK_MFMA_TFLOPS[args.dtype], 4),
+            "note": "algorithmic bytes (691.8 MB bf16 act./forward/image) and FLOPs (376 GF/forward/image) x images/s/GPU "
+                    "over 8 TB/s HBM and the dense MFMA peak"}
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel, timed live with HIP events on the launch stream (same inputs, same buffers)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        prof = runner.plan.profile(runner.x.data_ptr(), runner.temb.data_ptr(), runner.model_out.data_ptr(), st, reps=3)
+        torch.cuda.synchronize(dev)
+        total_ms = sum(d["ms"] for d in prof.values())
+        kind, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        bound = "mfma" if kind.startswith("conv") else ("mfma" if kind == "attn_d8" else "hbm")
+        if bound == "mfma":
+            ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS[args.dtype], "TFLOP/s"
+        else:
+            ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        res["roofline"] = {"kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                           "frac": round(ach / peak, 4), "traffic": None,
+                           "launches_per_forward": round(d["launches"]), "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                           "share_of_forward": round(d["ms"] / total_ms, 3),
+                           "method": "HIP events on the launch stream between consecutive launches of one UNet forward "
+                                     "(eager replay of the same plan, B and buffers as the timed region), 3 reps",
+                           "per_kernel_ms_per_forward": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                           "per_kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["ms"] > 0},
+                           "per_kernel_gbs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items() if v["ms"] > 0}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.model, size, S, state_dict)
+        res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

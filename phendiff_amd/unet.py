@@ -334,10 +334,12 @@ class _PackedWeights:
 
 
 class _Op:
-    __slots__ = ("fn", "args", "what")
+    """One kernel launch of the plan; ``flops`` / ``bytes`` are its ALGORITHMIC work (logical shapes, each tensor
+    read or written once), used by bench.py's roofline leg."""
+    __slots__ = ("fn", "args", "what", "flops", "bytes")
 
-    def __init__(self, fn, args, what):
-        self.fn, self.args, self.what = fn, args, what
+    def __init__(self, fn, args, what, flops=0.0, nbytes=0.0):
+        self.fn, self.args, self.what, self.flops, self.bytes = fn, args, what, float(flops), float(nbytes)
 
 
 class UNetPlan:
@@ -385,7 +387,8 @@ class UNetPlan:
         a = L.GnStatsArgs(dtype=self.code, B=self.B, HW=hw, C0=c0, C1=c1, groups=self.groups, eps=eps,
                           x0=x0.data_ptr(), x1=L.ptr(x1), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
                           partial=partial.data_ptr(), splits=splits, scale=scale.data_ptr(), shift=shift.data_ptr())
-        self.ops.append(_Op(self.lib.pd_gn_stats, a, "gn_stats"))
+        esz = 2 if self.code == L.PD_BF16 else 4
+        self.ops.append(_Op(self.lib.pd_gn_stats, a, "gn_stats", 3.0 * self.B * hw * C_, self.B * hw * C_ * esz))
         return scale, shift
 
     def _conv(self, x0, x1, wpk, bias, cout, *, ksize=3, stride=1, pad=1, upsample=0, silu=0, gn=None, temb_off=None,
@@ -411,7 +414,14 @@ class UNetPlan:
                        residual=L.ptr(residual), y=L.ptr(y))
         if temb_off is not None:
             self._temb_ptr_fields.append((a, temb_off))
-        self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}"))
+        esz = 2 if self.code == L.PD_BF16 else 4
+        cin = c0 + c1
+        flops = 2.0 * B * hout * wout * cout * cin * ksize * ksize
+        nbytes = (B * hin * win * cin + B * hout * wout * cout * (2 if residual is not None else 1)) * esz \
+            + cout * cin * ksize * ksize * esz
+        if out_mode == L.PD_OUT_NCHW_F32:
+            nbytes += B * hout * wout * cout * (4 - esz)
+        self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}", flops, nbytes))
         return y, a
 
     def _resnet(self, name, x0, x1=None):
@@ -438,7 +448,9 @@ class UNetPlan:
         o = self._act(h, w, ch)
         a = L.AttnArgs(dtype=self.code, B=B, heads=e.heads, N=h * w, q=qkv[0].data_ptr(), k=qkv[1].data_ptr(),
                        v=qkv[2].data_ptr(), out=o.data_ptr())
-        self.ops.append(_Op(self.lib.pd_attn_d8, a, "attn_d8"))
+        esz = 2 if self.code == L.PD_BF16 else 4
+        N = h * w
+        self.ops.append(_Op(self.lib.pd_attn_d8, a, "attn_d8", 4.0 * B * e.heads * N * N * 8, 4.0 * B * N * ch * esz))
         out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
         return out
 
@@ -456,7 +468,9 @@ class UNetPlan:
         a0 = self._act(H, W, boc[0])
         self._in_args = L.ConvInArgs(dtype=self.code, B=B, H=H, W=W, Cin=c.in_channels, Cout=boc[0],
                                      x=None, w=w.conv_in_w.data_ptr(), bias=w.conv_in_b.data_ptr(), y=a0.data_ptr())
-        self.ops.append(_Op(self.lib.pd_conv_in, self._in_args, "conv_in"))
+        esz = 2 if self.code == L.PD_BF16 else 4
+        self.ops.append(_Op(self.lib.pd_conv_in, self._in_args, "conv_in", 2.0 * B * H * W * boc[0] * c.in_channels * 9,
+                            B * H * W * (c.in_channels * 4 + boc[0] * esz)))
         h = a0
         skips = [a0]
         for i, blk in enumerate(m.down_blocks):
@@ -502,6 +516,36 @@ class UNetPlan:
         a.emb, a.proj = None, out.data_ptr()
         L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
         return out
+
+    def profile(self, x_ptr, temb_ptr, out_ptr, stream, reps=3):
+        """Per-kernel-kind device time of one UNet evaluation, measured with HIP events recorded on the launch
+        stream between consecutive launches (``pd_event_*``).  Returns {kind: dict(ms, launches, flops, bytes)}
+        averaged over ``reps`` evaluations."""
+        lib = self.lib
+        self.run(x_ptr, temb_ptr, out_ptr, stream)  # warm (also sets the pointers)
+        nev = len(self.ops) + 1
+        evs = []
+        for _ in range(nev):
+            e = C.c_void_p()
+            L.check(lib.pd_event_create(C.byref(e)), "pd_event_create")
+            evs.append(e)
+        acc = {}
+        for _ in range(reps):
+            for i, op in enumerate(self.ops):
+                L.check(lib.pd_event_record(evs[i], stream), "pd_event_record")
+                L.check(op.fn(C.byref(op.args), stream), op.what)
+            L.check(lib.pd_event_record(evs[-1], stream), "pd_event_record")
+            ms = C.c_float()
+            for i, op in enumerate(self.ops):
+                L.check(lib.pd_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)), "pd_event_elapsed_ms")
+                d = acc.setdefault(op.what, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+                d["ms"] += ms.value / reps
+                d["launches"] += 1.0 / reps
+                d["flops"] += op.flops / reps
+                d["bytes"] += op.bytes / reps
+        for e in evs:
+            lib.pd_event_destroy(e)
+        return acc
 
     def run(self, x_ptr, temb_ptr, out_ptr, stream):
         """One UNet evaluation: NCHW fp32 at ``x_ptr`` -> NCHW fp32 prediction at ``out_ptr``; ``temb_ptr`` is the
