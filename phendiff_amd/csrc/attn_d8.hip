@@ -28,11 +28,11 @@ template <> struct AttnOps<bf16_t> {
     return f;
   }
   // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
-  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q) {
+  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q, const f32x16& c) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     s16x8 a = (s16x8)(0);
     if (h == 0) a = *(const s16x8*)(klds + key * 16);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, q.v), (f32x16)(0.f), 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, q.v), c, 0, 0, 0);
   }
   // O^T += A . P^T for the 32 keys starting at key0; p = exponentiated tile (fp32 accumulator layout)
   static __device__ __forceinline__ f32x16 pv(const unsigned char* vlds, int key0, int r, int h, const f32x16& p, f32x16 o) {
@@ -65,9 +65,8 @@ template <> struct AttnOps<float> {
     f.v *= scale;
     return f;
   }
-  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q) {
+  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q, f32x16 c) {
     const f32x4 a = *(const f32x4*)(klds + key * 32 + h * 16);   // d = 4h + i
-    f32x16 c = (f32x16)(0.f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], q.v[i], c, 0, 0, 0);
     return c;
@@ -110,8 +109,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   const typename Ops::QF qf = Ops::load_q(qp + (size_t)qclamp * 8, h, qscale);
 
   f32x16 o = (f32x16)(0.f);
-  float m = -INFINITY;
-
+  // Deferred-rescale online softmax.  `m` is the reference maximum (log2 domain) shared by both lane halves of a
+  // query; -m rides in the C operand of the QK^T MFMA, so s' = S - m leaves the matrix pipe ready for exp2.  m is
+  // only raised when some s' exceeds RESCALE_THR (p <= 2^THR otherwise): the common path has no cross-lane traffic,
+  // no subtraction and no accumulator rescale.
+  constexpr float RESCALE_THR = 6.0f;
+  float m = 0.f;
+  f32x16 negm = (f32x16)(0.f);
+  bool first = true;
   // staging: thread t < 128 owns K row t, thread t >= 128 owns V row t-128 of the tile
   const int srow = tid & 127;
   const bool is_v = tid >= 128;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
     for (int sub = 0; sub < KT / 32; ++sub) {
       const int kb = sub * 32;
       if (k0 + kb >= N) break;
-      f32x16 s = Ops::qk(klds, kb + r, h, qf);
+      f32x16 s = Ops::qk(klds, kb + r, h, qf, negm);
       // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
       if (k0 + kb + 32 > N) {
 #pragma unroll
@@ -154,15 +159,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
       float tmax = s[0];
 #pragma unroll
       for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m, tmax);           // finite: every tile has at least one valid key
-      const float alpha = exp2f(m - m_new);         // m = -inf on the first tile -> 0
+      if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR)) {   // wave-uniform, rare after the first tile
+        const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));             // finite: the first tile holds key 0
+        const float delta = first ? t2 : fmaxf(t2, 0.f);
+        const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = exp2f(s[i] - m_new);
-      // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
+        for (int i = 0; i < 8; ++i) o[i] *= sc;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] *= alpha;
-      m = m_new;
+        for (int i = 0; i < 16; ++i) s[i] -= delta;
+        m += delta;
+        negm = (f32x16)(-m);
+        first = false;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
       o = Ops::pv(vlds, kb, r, h, s, o);
     }
   }

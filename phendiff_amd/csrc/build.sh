@@ -10,7 +10,10 @@ pids=()
 for f in conv_igemm attn_d8 small_kernels; do
   if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_common.h" -nt "$HERE/build/$f.o" ] \
      || [ "$HERE/../../include/phendiff_hip.h" -nt "$HERE/build/$f.o" ]; then
-    $HIPCC $FLAGS $EXTRA_HIPCC_FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
+    X=""
+    # attention: keep MFMA accumulators in VGPRs (the softmax works on them; AGPR form costs a copy per register)
+    if [ "$f" = "attn_d8" ]; then X="-mllvm -amdgpu-mfma-vgpr-form"; fi
+    $HIPCC $FLAGS $X $EXTRA_HIPCC_FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
     pids+=($!)
   fi
 done
