@@ -1,15 +1,20 @@
 // pd_conv: implicit-GEMM convolution on gfx950 MFMA, NHWC, LDS-staged halo tiles.
 //
 // GEMM view:  D[co][pixel] = sum_k W[co][k] * X[k][pixel],  k = (tap, ci).
-//   A operand = packed weights   (lane: row = co,    8 consecutive ci)   -> straight from global/L2, 1 KiB coalesced per wave
-//   B operand = activation tile  (lane: col = pixel, 8 consecutive ci)   -> ds_read_b128 from the LDS halo tile
+//   A operand = packed weights   (lane: row = co,    8 consecutive ci)   -> straight from global/L2, 1 KiB coalesced per wave,
+//                                                                           prefetched two k-steps ahead in registers
+//   B operand = activation tile  (lane: col = pixel, 8 consecutive ci)   -> ds_read_b128 from the LDS halo tile, one k-step ahead
 //   D         : lane owns one pixel and 16 output channels (4 runs of 4 consecutive co) -> 8/16-byte NHWC stores
 // Workgroup = 256 threads = 4 waves = 2 (pixel halves) x 2 (co halves of 32); tile = TH*TW pixels x 64 co.
 // K loop: chunks of 32 input channels; per chunk the halo tile is staged global -> regs -> (GroupNorm affine,
 // SiLU, zero padding) -> LDS once and reused by all KS*KS taps (9x LDS reuse instead of 9x global re-reads).
-// The next chunk's global loads are issued before the MFMA phase and written to LDS after it (latency hidden).
+// Software pipeline (DB = double-buffered LDS): while the MFMAs of chunk c run out of LDS[c&1], the same waves
+// transform the registers of chunk c+1 and write LDS[(c+1)&1] BETWEEN the MFMAs (matrix and vector pipes overlap),
+// then issue the global loads of chunk c+2; one barrier per chunk.
 // LDS pixel pitch = 32 ch + 16 B pad: an odd number of 16-B slots, so a wave's 32 consecutive pixels hit 16
 // distinct slots per ds_read_b128 lane group (conflict-free for TW = 32).
+#include <type_traits>
+#include <stdio.h>
 #include "pd_common.h"
 
 namespace pd {
@@ -19,6 +24,7 @@ struct ConvP {
   int C0, C1, Cout, Cout_pad;
   int pad, upsample, silu, out_mode, heads;
   int tiles_x, tiles_y, n_pix_tiles, n_co_tiles, nchunks;
+  unsigned bytes0, bytes1;
   const void* x0; const void* x1;
   const float* scale; const float* shift;
   const void* w;
@@ -28,10 +34,80 @@ struct ConvP {
   void* y;
 };
 
-template <typename T, int KS, int STRIDE, int TH, int TW>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Ablation switches for diagnostic builds (scripts/ablate_conv.sh); never defined in the shipped library.
+#ifdef PD_ABL_W0
+#define PD_WIDX(i) 0            /* every weight fragment load hits fragment 0 (L1-resident): prices the weight stream */
+#else
+#define PD_WIDX(i) (i)
+#endif
+#ifdef PD_STAMPS   // diagnostic build only (scripts/stamp_conv.py): phase timestamps of the first workgroups
+__device__ unsigned long long pd_conv_stamps[4096 * 8];
+#define PD_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t_;                                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) pd_conv_stamps[blockIdx.x * 8 + (k)] = t_;            \
+  } while (0)
+#else
+#define PD_STAMP(k) do {} while (0)
+#endif
+constexpr unsigned OOB_OFF = 0xC0000000u;   // > any tensor we accept (< 2 GiB): buffer loads return 0
+
+template <typename T> struct Stage;
+template <> struct Stage<bf16_t> {
+  struct R { u32x4 v; };
+  static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    R r; r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); return r;
+  }
+  // y = silu?(x*sc + sh) on 8 packed bf16, zeroed when !valid
+  static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
+                                                     bool affine, bool silu, bool valid) {
+    u32x4 o = in.v;
+    if (affine || silu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = __uint_as_float(in.v[j] << 16), hi = __uint_as_float(in.v[j] & 0xffff0000u);
+        if (affine) { lo = lo * sc[2 * j] + sh[2 * j]; hi = hi * sc[2 * j + 1] + sh[2 * j + 1]; }
+        if (silu) { lo = silu_fast(lo); hi = silu_fast(hi); }
+        o[j] = pack2bf(lo, hi);
+      }
+      if (!valid) o = (u32x4)(0u);
+    }
+    *(u32x4*)dst = o;
+  }
+};
+template <> struct Stage<float> {
+  struct R { u32x4 a, b; };
+  static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    R r; r.a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); r.b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+    return r;
+  }
+  static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
+                                                     bool affine, bool silu, bool valid) {
+    u32x4 oa = in.a, ob = in.b;
+    if (affine || silu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = __uint_as_float(in.a[j]), y = __uint_as_float(in.b[j]);
+        if (affine) { x = x * sc[j] + sh[j]; y = y * sc[4 + j] + sh[4 + j]; }
+        if (silu) { x = silu_f(x); y = silu_f(y); }   // parity mode: accurate division
+        oa[j] = __float_as_uint(x); ob[j] = __float_as_uint(y);
+      }
+      if (!valid) { oa = (u32x4)(0u); ob = (u32x4)(0u); }
+    }
+    *(u32x4*)dst = oa; *((u32x4*)dst + 1) = ob;
+  }
+};
+
+template <typename T, int KS, int STRIDE, int TH, int TW, bool DB>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   using E = Elem<T>;
   using Frag = typename E::Frag;
+  using SR = typename Stage<T>::R;
   constexpr int TP = TH * TW;              // pixels per workgroup tile
   constexpr int NF = TP / 64;              // 32-pixel fragments per wave
   constexpr int RPF = 32 / TW;             // tile rows per fragment (TW == 32 -> 1)
@@ -41,6 +117,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   constexpr int PITCH = 32 * E::BYTES + 16;
   constexpr int NIT = (NPIX * 4 + 255) / 256;
   constexpr int TAPS = KS * KS;
+  constexpr int KSTEPS = TAPS * 2;
+  constexpr int LDS_TILE = ((NPIX * PITCH + 15) / 16) * 16;
   static_assert(RPF >= 1 && TW * RPF == 32, "TW must divide 32");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -51,6 +129,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   const int co_t = jj % p.n_co_tiles;
   const int pt = (jj / p.n_co_tiles) * 8 + xcd;
   if (pt >= p.n_pix_tiles) return;
+  PD_STAMP(0);
   const int tx = pt % p.tiles_x;
   const int ty = (pt / p.tiles_x) % p.tiles_y;
   const int n = pt / (p.tiles_x * p.tiles_y);
@@ -64,20 +143,21 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   const int ct32 = co_t * 2 + wc;                      // this wave's 32-co tile
   const bool wave_active = (ct32 * 32) < p.Cout_pad;   // wave-uniform
 
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0, 0, p.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1 ? p.x1 : p.x0), 0, p.bytes1, 0x00020000);
+
   // ---- staging bookkeeping: this thread's pieces (pixel, 8-channel sub-block)
   const int sub = tid & 3;
   const int Hc = p.upsample ? p.Hin * 2 : p.Hin;
   const int Wc = p.upsample ? p.Win * 2 : p.Win;
-  int spix[NIT];   // linear source pixel index (n, sy, sx) or -1 (zero padding) / -2 (no such piece)
+  int spix[NIT];   // linear source pixel index (n, sy, sx) or -1 (zero padding / no such piece)
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int idx = tid + 256 * i;
-    const int pix = idx >> 2;
-    int v = -2;
+    const int pix = (tid + 256 * i) >> 2;
+    int v = -1;
     if (pix < NPIX) {
       const int u = pix / IN_TW, vv = pix - u * IN_TW;
       const int iy = y0 * STRIDE - p.pad + u, ix = x0 * STRIDE - p.pad + vv;
-      v = -1;
       if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) {
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
         v = (n * p.Hin + sy) * p.Win + sx;
@@ -85,50 +165,38 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
     }
     spix[i] = v;
   }
+  const bool affine = p.scale != nullptr;
+  const bool do_silu = p.silu != 0;
+  const int cin = p.C0 + p.C1;
 
-  Frag stage[NIT];
+  SR stage[NIT];
+  float sc[8], sh[8];
   auto issue_loads = [&](int chunk) {
     const int cch = chunk * 32;
-    const T* src; int cs, coff;
-    if (cch < p.C0) { src = (const T*)p.x0; cs = p.C0; coff = cch; }
-    else            { src = (const T*)p.x1; cs = p.C1; coff = cch - p.C0; }
+    const bool s0 = cch < p.C0;
+    const unsigned cs = s0 ? p.C0 : p.C1;
+    const unsigned coff = (s0 ? cch : cch - p.C0) + sub * 8;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      if (spix[i] >= 0) stage[i] = E::load(src + (size_t)spix[i] * cs + coff + sub * 8);
-      else stage[i] = E::zero();
+#ifdef PD_ABL_X0
+      const unsigned off = OOB_OFF;   // ablation: no activation traffic
+#else
+      const unsigned off = spix[i] >= 0 ? ((unsigned)spix[i] * cs + coff) * E::BYTES : OOB_OFF;
+#endif
+      stage[i] = s0 ? Stage<T>::load(rs0, off) : Stage<T>::load(rs1, off);
     }
-  };
-  auto write_lds = [&](int chunk) {
-    float sc[8], sh[8];
-    const bool affine = p.scale != nullptr;
     if (affine) {
-      const int cin = p.C0 + p.C1;
-      const float* ps = p.scale + (size_t)n * cin + chunk * 32 + sub * 8;
-      const float* pb = p.shift + (size_t)n * cin + chunk * 32 + sub * 8;
-      f32x4 a0 = *(const f32x4*)ps, a1 = *((const f32x4*)ps + 1);
-      f32x4 b0 = *(const f32x4*)pb, b1 = *((const f32x4*)pb + 1);
+      const float* ps = p.scale + (size_t)n * cin + cch + sub * 8;
+      const float* pb = p.shift + (size_t)n * cin + cch + sub * 8;
+      const f32x4 a0 = *(const f32x4*)ps, a1 = *((const f32x4*)ps + 1);
+      const f32x4 b0 = *(const f32x4*)pb, b1 = *((const f32x4*)pb + 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { sc[j] = a0[j]; sc[4 + j] = a1[j]; sh[j] = b0[j]; sh[4 + j] = b1[j]; }
     }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      if (spix[i] == -2) continue;
-      Frag f = stage[i];
-      if (spix[i] >= 0 && (affine || p.silu)) {
-        float v[8];
-        E::unpack(f, v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float t = v[j];
-          if (affine) t = t * sc[j] + sh[j];
-          if (p.silu) t = silu_f(t);
-          v[j] = t;
-        }
-        f = E::pack(v);
-      }
-      const int pix = (tid + 256 * i) >> 2;
-      E::store(lds + pix * PITCH + sub * 8 * E::BYTES, f);
-    }
+  };
+  auto write_piece = [&](int i, unsigned char* buf) {
+    const int pix = (tid + 256 * i) >> 2;
+    if (pix < NPIX) Stage<T>::xform_store(buf + pix * PITCH + sub * 8 * E::BYTES, stage[i], sc, sh, affine, do_silu, spix[i] >= 0);
   };
 
   // ---- per-lane LDS read bases for the B (activation) fragments
@@ -141,92 +209,208 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   }
 
   f32x16 acc[NF];
+  const T* wbase = (const T*)p.w + (size_t)ct32 * p.nchunks * (KSTEPS * 512) + lane * 8;
+
+  // Weight (A) fragments live in a register ring of AR entries, prefetched AD k-steps ahead and CONTINUOUSLY across
+  // chunk boundaries (a chunk's fragments are contiguous with the next chunk's), so L2 latency (~600-800 cycles under
+  // load) is covered by AD x 4 MFMAs.  The ring index is static because AR divides KSTEPS.  The MFMA loop is kept
+  // free of branches (prefetch index clamped, not guarded; have_next / wave_active are compile-time) so that it stays
+  // ONE scheduling region with counted waits.
+  constexpr int AR = (KSTEPS % 3 == 0) ? 3 : 2;
+  constexpr int AD = AR - 1;
+  Frag aring[AR];
+  const int last_kstep = p.nchunks * KSTEPS - 1;
+
+  // one chunk of MFMAs out of `buf`; when DB, pieces of the NEXT chunk are transformed + written to `nbuf` in between
+  auto mma_chunk = [&](int chunk, const unsigned char* buf, unsigned char* nbuf, auto have_next_c, auto active_c) {
+    constexpr bool HAVE_NEXT = decltype(have_next_c)::value;
+    constexpr bool ACTIVE = decltype(active_c)::value;
+    const int g0 = chunk * KSTEPS;
+    Frag bc[NF], bn[NF];                   // activation fragments, prefetched 1 k-step ahead
+    if constexpr (ACTIVE) {
 #pragma unroll
-  for (int f = 0; f < NF; ++f) acc[f] = (f32x16)(0.f);
+      for (int f = 0; f < NF; ++f) bc[f] = E::load(buf + rbase[f]);
+    }
+    int piece = 0;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if constexpr (ACTIVE) {
+        aring[(ks + AD) % AR] = E::load(wbase + (size_t)PD_WIDX(min(g0 + ks + AD, last_kstep)) * 512);
+        if (ks + 1 < KSTEPS) {
+          const int tap = (ks + 1) >> 1, s = (ks + 1) & 1;
+          const int toff = ((tap / KS) * IN_TW + (tap % KS)) * PITCH + s * 16 * E::BYTES;
+#pragma unroll
+          for (int f = 0; f < NF; ++f) bn[f] = E::load(buf + rbase[f] + toff);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[f] = E::mma(aring[ks % AR], bc[f], acc[f]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) bc[f] = bn[f];
+      }
+      if constexpr (DB && HAVE_NEXT) {
+        // spread the NIT pieces of the next chunk evenly over the k-steps
+        const int due = ((ks + 1) * NIT) / KSTEPS;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+          if (i >= piece && i < due) write_piece(i, nbuf);
+        piece = due;
+      }
+    }
+  };
+  // chunk driver: the last chunk is peeled (HAVE_NEXT = false) so the accumulators flow through two call sites
+  // instead of an if/else diamond (which made the register allocator keep two accumulator sets)
+  using std::true_type; using std::false_type;
 
-  const T* wbase = (const T*)p.w + (size_t)ct32 * p.nchunks * (TAPS * 2 * 512) + lane * 8;
-
-  issue_loads(0);
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    if (chunk > 0) __syncthreads();
-    write_lds(chunk);
-    __syncthreads();
-    if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+  issue_loads(0);                      // first: everything below overlaps the HBM latency of chunk 0
+  // accumulators start at bias[co] + temb[n][co] (lane (pixel, h), register i <-> co = 8(i>>2) + 4h + (i&3)):
+  // the epilogue then has no per-channel loads at all
+  {
+    f32x16 init = (f32x16)(0.f);
     if (wave_active) {
-      const T* wc_ptr = wbase + (size_t)chunk * (TAPS * 2 * 512);
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int ky = tap / KS, kx = tap % KS;
+      for (int g = 0; g < 4; ++g) {
+        const int co = ct32 * 32 + 8 * g + 4 * h;
+        f32x4 bb = *(const f32x4*)(p.bias + co);
+        if (p.temb) {
+          const float* tp = p.temb + (size_t)n * p.temb_stride + co;
+          if (ct32 * 32 + 32 <= p.Cout) {          // wave-uniform: all 32 channels real
+            const f32x4 tv = *(const f32x4*)tp;
+            bb += tv;
+          } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const Frag a = E::load(wc_ptr + (tap * 2 + s) * 512);
-          const int toff = (ky * IN_TW + kx) * PITCH + s * 16 * E::BYTES;
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            const Frag b = E::load(lds + rbase[f] + toff);
-            acc[f] = E::mma(a, b, acc[f]);
+            for (int i = 0; i < 4; ++i) if (co + i < p.Cout) bb[i] += tp[i];
           }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) init[4 * g + i] = bb[i];
       }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = init;
+  }
+
+  if (wave_active) {
+#pragma unroll
+    for (int i = 0; i < AD; ++i) aring[i] = E::load(wbase + (size_t)PD_WIDX(min(i, last_kstep)) * 512);
+  }
+  if (DB) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) write_piece(i, lds);
+    if (p.nchunks > 1) issue_loads(1);
+    PD_STAMP(1);
+    __syncthreads();
+    PD_STAMP(2);
+    int chunk = 0;
+    for (; chunk + 1 < p.nchunks; ++chunk) {
+      unsigned char* buf = lds + (chunk & 1) * LDS_TILE;
+      unsigned char* nbuf = lds + ((chunk + 1) & 1) * LDS_TILE;
+      if (wave_active) mma_chunk(chunk, buf, nbuf, true_type{}, true_type{});
+      else mma_chunk(chunk, buf, nbuf, true_type{}, false_type{});
+      if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+      if (chunk == 0) PD_STAMP(3);
+      __syncthreads();
+      if (chunk == 0) PD_STAMP(4);
+    }
+    if (wave_active) mma_chunk(chunk, lds + (chunk & 1) * LDS_TILE, lds, false_type{}, true_type{});
+    __syncthreads();
+    PD_STAMP(5);
+  } else {
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+      if (chunk > 0) __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) write_piece(i, lds);
+      __syncthreads();
+      if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+      if (wave_active) mma_chunk(chunk, lds, lds, false_type{}, true_type{});
     }
   }
 
-  if (!wave_active) return;
-  // ---- epilogue: + bias + temb + residual, store
+  // ---- epilogue ------------------------------------------------------------------------------------------
   const int co_w = ct32 * 32;
+  if (p.out_mode == PD_OUT_NCHW_F32) {
+    // conv_out: <= 4 real channels, fp32 planes; lanes (pixels) are contiguous along x
+    if (!wave_active) return;
 #pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const int fi = wp * NF + f;
-    const int py = fi * RPF + r / TW, px = r % TW;
-    const int oy = y0 + py, ox = x0 + px;
-    if (oy >= p.Hout || ox >= p.Wout) continue;
-    const size_t opix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
+    for (int f = 0; f < NF; ++f) {
+      const int fi = wp * NF + f;
+      const int oy = y0 + fi * RPF + r / TW, ox = x0 + r % TW;
+      if (oy >= p.Hout || ox >= p.Wout) continue;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = co_w + 8 * g + 4 * h;
-      float v[4];
-      const f32x4 bb = *(const f32x4*)(p.bias + co);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = acc[f][4 * g + i] + bb[i];
-      if (p.temb) {
-        const float* tp = p.temb + (size_t)n * p.temb_stride + co;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (co + i < p.Cout) v[i] += tp[i];
-      }
-      if (p.out_mode == PD_OUT_NHWC) {
-        if (co >= p.Cout) continue;
-        if (p.residual) {
-          float rr[4];
-          load4((const T*)p.residual + opix * p.Cout + co, rr);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += rr[i];
-        }
-        store4((T*)p.y + opix * p.Cout + co, v[0], v[1], v[2], v[3]);
-      } else if (p.out_mode == PD_OUT_NCHW_F32) {
+      for (int g = 0; g < 4; ++g) {
+        const int co = co_w + 8 * g + 4 * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (co + i < p.Cout) ((float*)p.y)[(((size_t)n * p.Cout + co + i) * p.Hout + oy) * p.Wout + ox] = v[i];
+          if (co + i < p.Cout) ((float*)p.y)[(((size_t)n * p.Cout + co + i) * p.Hout + oy) * p.Wout + ox] = acc[f][4 * g + i];
+      }
+    }
+    return;
+  }
+  // NHWC / head-major: stage the 64-channel tile through LDS as [pixel][co] so that the residual add and the
+  // stores are fully coalesced 16-byte accesses (a pixel's 64 channels = one 128-B line in bf16).
+  constexpr int EP_PITCH = 64 * E::BYTES + 16;
+  if (!DB) __syncthreads();                 // DB: the chunk loop already ended on a barrier
+  if (wave_active) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int plin = (wp * NF + f) * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        store4((T*)(lds + plin * EP_PITCH) + wc * 32 + 8 * g + 4 * h, acc[f][4 * g], acc[f][4 * g + 1], acc[f][4 * g + 2], acc[f][4 * g + 3]);
+    }
+  }
+  __syncthreads();
+  constexpr int EPC = 16 / E::BYTES;           // channels per 16-byte piece
+  constexpr int PPP = 64 / EPC;                // pieces per pixel
+  constexpr int PXI = 256 / PPP;               // pixels per iteration
+  const int piece = tid % PPP, prow = tid / PPP;
+  const int co = co_t * 64 + piece * EPC;
+  if (co < p.Cout) {
+#pragma unroll
+    for (int it = 0; it < TP / PXI; ++it) {
+      const int plin = it * PXI + prow;
+      const int oy = y0 + plin / TW, ox = x0 + plin % TW;
+      if (oy >= p.Hout || ox >= p.Wout) continue;
+      u32x4 v = *(const u32x4*)(lds + plin * EP_PITCH + piece * 16);
+      const size_t opix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
+      if (p.out_mode == PD_OUT_NHWC) {
+        if (p.residual) {
+          const u32x4 rr = *(const u32x4*)((const T*)p.residual + opix * p.Cout + co);
+          if (E::BYTES == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = __uint_as_float(v[j] << 16) + __uint_as_float(rr[j] << 16);
+              const float hi = __uint_as_float(v[j] & 0xffff0000u) + __uint_as_float(rr[j] & 0xffff0000u);
+              v[j] = pack2bf(lo, hi);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(__uint_as_float(v[j]) + __uint_as_float(rr[j]));
+          }
+        }
+        *(u32x4*)((T*)p.y + opix * p.Cout + co) = v;
       } else {  // PD_OUT_QKV_HEADS: [which][B][heads][N][8]
-        if (co >= p.Cout) continue;
-        const int C = p.heads * 8;
-        const int which = co / C, cc = co - which * C;
-        const int head = cc >> 3, d = cc & 7;
+        const int Cq = p.heads * 8;
+        const int which = co / Cq, cc = co - which * Cq;
         const size_t N = (size_t)p.Hout * p.Wout;
         const size_t tok = (size_t)oy * p.Wout + ox;
-        T* dst = (T*)p.y + ((((size_t)which * p.B + n) * p.heads + head) * N + tok) * 8 + d;
-        store4(dst, v[0], v[1], v[2], v[3]);
+        *(u32x4*)((T*)p.y + ((((size_t)which * p.B + n) * p.heads + (cc >> 3)) * N + tok) * 8 + (cc & 7)) = v;
       }
     }
   }
+  PD_STAMP(6);
 }
 
 template <typename T, int KS, int STRIDE, int TH, int TW>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int IN_TH = (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
-  constexpr int LDS_BYTES = IN_TH * IN_TW * PITCH;
+  constexpr int LDS_TILE = ((IN_TH * IN_TW * PITCH + 15) / 16) * 16;
+  constexpr bool DB = 2 * LDS_TILE <= 100 * 1024;       // double-buffer when two tiles fit comfortably
+  constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16);
+  constexpr int LDS_MAIN = DB ? 2 * LDS_TILE : LDS_TILE;
+  constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
-  auto kern = conv_kernel<T, KS, STRIDE, TH, TW>;
+  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB>;
   if (LDS_BYTES > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -279,7 +463,7 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   PD_CHECK(a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0, PD_ERR_SHAPE,
            "pd_conv: C0=%d C1=%d must be multiples of 32", a->C0, a->C1);
   PD_CHECK(a->Cout > 0 && a->Cout_pad >= a->Cout && a->Cout_pad % 32 == 0, PD_ERR_SHAPE, "pd_conv: bad Cout/Cout_pad");
-  PD_CHECK(a->Cout % 4 == 0 || a->out_mode == PD_OUT_NCHW_F32, PD_ERR_SHAPE, "pd_conv: NHWC output needs Cout %% 4 == 0");
+  PD_CHECK(a->Cout % 8 == 0 || a->out_mode == PD_OUT_NCHW_F32, PD_ERR_SHAPE, "pd_conv: NHWC / head-major output needs Cout %% 8 == 0");
   PD_CHECK(a->x0 && a->w_packed && a->bias && a->y, PD_ERR_ARG, "pd_conv: null pointer");
   PD_CHECK((a->C1 == 0) == (a->x1 == nullptr), PD_ERR_ARG, "pd_conv: x1/C1 mismatch");
   PD_CHECK((a->scale == nullptr) == (a->shift == nullptr), PD_ERR_ARG, "pd_conv: scale/shift mismatch");
@@ -296,14 +480,38 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   if (a->out_mode == PD_OUT_QKV_HEADS)
     PD_CHECK(a->heads > 0 && a->Cout == 3 * a->heads * 8, PD_ERR_SHAPE, "pd_conv: QKV mode needs Cout == 3*heads*8");
   PD_CHECK(a->out_mode == PD_OUT_NHWC || a->residual == nullptr, PD_ERR_UNSUPPORTED, "pd_conv: residual needs NHWC output");
+  const size_t esz = a->dtype == PD_F32 ? 4 : 2;
+  const size_t bytes0 = (size_t)a->B * a->Hin * a->Win * a->C0 * esz, bytes1 = (size_t)a->B * a->Hin * a->Win * a->C1 * esz;
+  PD_CHECK(bytes0 < 0x80000000ull && bytes1 < 0x80000000ull, PD_ERR_SHAPE,
+           "pd_conv: source tensor exceeds 2 GiB (32-bit buffer offsets); split the batch");
   ConvP p{};
   p.B = a->B; p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout;
   p.C0 = a->C0; p.C1 = a->C1; p.Cout = a->Cout; p.Cout_pad = a->Cout_pad;
   p.pad = a->pad; p.upsample = a->upsample; p.silu = a->silu; p.out_mode = a->out_mode; p.heads = a->heads;
   p.nchunks = (a->C0 + a->C1) / 32;
+  p.bytes0 = (unsigned)bytes0; p.bytes1 = (unsigned)(a->x1 ? bytes1 : bytes0);
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.w = a->w_packed; p.bias = a->bias;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.residual = a->residual; p.y = a->y;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PD_F32) return dispatch_conv<float>(p, a->ksize, a->stride, st);
   return dispatch_conv<bf16_t>(p, a->ksize, a->stride, st);
 }
+
+#ifdef PD_STAMPS
+extern "C" int pd_debug_conv_occupancy(int lds_bytes) {
+  int nb = -1;
+  auto kern = pd::conv_kernel<pd::bf16_t, 3, 1, 8, 32, true>;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, (size_t)lds_bytes);
+  hipFuncAttributes fa;
+  hipFuncGetAttributes(&fa, (const void*)kern);
+  printf("occupancy API: %d blocks/CU at %d B dyn LDS (err %d); numRegs %d sharedStatic %zu maxDyn %d\n", nb, lds_bytes, (int)e,
+         fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+  hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+  printf("device: sharedMemPerBlock %zu sharedMemPerMultiprocessor %zu regsPerBlock %d CUs %d maxThreadsPerMP %d\n", pr.sharedMemPerBlock,
+         pr.sharedMemPerMultiprocessor, pr.regsPerBlock, pr.multiProcessorCount, pr.maxThreadsPerMultiProcessor);
+  return nb;
+}
+extern "C" int pd_debug_read_conv_stamps(unsigned long long* host, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pd::pd_conv_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif

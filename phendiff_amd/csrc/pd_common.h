@@ -45,6 +45,10 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// throughput form: v_exp_f32 + v_rcp_f32 (1 ulp each), 5 VALU ops instead of ~15 for the IEEE division
+__device__ __forceinline__ float silu_fast(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 
 // ---- element traits: an "8-element fragment" is what one lane feeds to one MFMA k16-step ----------
 template <typename T> struct Elem;
