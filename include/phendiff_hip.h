@@ -135,8 +135,26 @@ typedef struct {
   const float* temb; int temb_stride;       /* temb[n*temb_stride + co] or NULL */
   const void* residual;     /* NHWC [B][Hout][Wout][Cout] or NULL */
   void* y;
+  float* stats_out;         /* NULL, or [B][pd_conv_stat_tiles()][Cout][2]: per-tile per-channel (sum, sum of squares) of the
+                               stored output -- the GroupNorm statistics of the CONSUMER, produced for free here */
+  int im2col3;              /* 0, or n <= 3: x0 is an NCHW fp32 tensor with n channels (the UNet input sample) and the op is
+                               the 3x3 pad-1 conv_in run as a 1x1 conv over 32 virtual channels k = ci*9 + ky*3 + kx
+                               (ksize must be 1, C0 = 32, weights packed accordingly) */
 } pd_conv_args;
 int pd_conv(const pd_conv_args* a, void* stream);
+/* number of statistic tiles per sample pd_conv writes for this shape (depends on the kernel's tile choice) */
+int pd_conv_stat_tiles(int Hout, int Wout, int ksize, int stride);
+
+/* pd_gn_finalize: per-tile channel sums (pd_conv stats_out) of one or two tensors (channel concat [x0 | x1]) ->
+ * GroupNorm scale/shift per (sample, channel):  scale = rstd*gamma, shift = beta - mean*rstd*gamma  (fp64 combine). */
+typedef struct {
+  int B, HW, groups; float eps;
+  int C0, T0; const float* stats0;     /* [B][T0][C0][2] */
+  int C1, T1; const float* stats1;     /* [B][T1][C1][2] or NULL (C1 = 0) */
+  const float* gamma; const float* beta;
+  float* scale; float* shift;          /* out [B][C0+C1] */
+} pd_gn_finalize_args;
+int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pd_attn_d8: softmax(q k^T / sqrt(8)) v for head_dim 8 (attention_head_dim=8, cond_unet_2d.py:176-178),

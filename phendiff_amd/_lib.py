@@ -43,7 +43,13 @@ class ConvArgs(C.Structure):
                 ("C0", C.c_int), ("C1", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("ksize", C.c_int),
                 ("stride", C.c_int), ("pad", C.c_int), ("upsample", C.c_int), ("silu", C.c_int), ("out_mode", C.c_int),
                 ("heads", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("w_packed", vp), ("bias", vp),
-                ("temb", vp), ("temb_stride", C.c_int), ("residual", vp), ("y", vp)]
+                ("temb", vp), ("temb_stride", C.c_int), ("residual", vp), ("y", vp), ("stats_out", vp), ("im2col3", C.c_int)]
+
+
+class GnFinalizeArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("HW", C.c_int), ("groups", C.c_int), ("eps", C.c_float),
+                ("C0", C.c_int), ("T0", C.c_int), ("stats0", vp), ("C1", C.c_int), ("T1", C.c_int), ("stats1", vp),
+                ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -76,6 +82,8 @@ SYMBOLS = {
     "pd_conv_in": (C.c_int, [C.POINTER(ConvInArgs), vp]),
     "pd_gn_stats": (C.c_int, [C.POINTER(GnStatsArgs), vp]),
     "pd_conv": (C.c_int, [C.POINTER(ConvArgs), vp]),
+    "pd_conv_stat_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pd_gn_finalize": (C.c_int, [C.POINTER(GnFinalizeArgs), vp]),
     "pd_attn_d8": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "pd_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), vp]),
     "pd_add_noise": (C.c_int, [C.POINTER(AddNoiseArgs), vp]),

@@ -30,15 +30,13 @@ template <> struct AttnOps<bf16_t> {
   // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
   static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q, const f32x16& c) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    s16x8 a = (s16x8)(0);
-    if (h == 0) a = *(const s16x8*)(klds + key * 16);
+    const s16x8 a = *(const s16x8*)(klds + key * 32 + h * 16);   // h == 1 reads the zero half of the row
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, q.v), c, 0, 0, 0);
   }
   // O^T += A . P^T for the 32 keys starting at key0; p = exponentiated tile (fp32 accumulator layout)
-  static __device__ __forceinline__ f32x16 pv(const unsigned char* vlds, int key0, int r, int h, const f32x16& p, f32x16 o) {
+  static __device__ __forceinline__ f32x16 pv(const unsigned char* vrow, int key0, const f32x16& p, f32x16 o) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    const bool ones = (r & 8) != 0;
-    const unsigned char* row = vlds + (r & 7) * VT_PITCH + (key0 + 4 * h) * 2;
+    const unsigned char* row = vrow + key0 * 2;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // B fragment: element j <-> key 16s + 8(j>>2) + 4h + (j&3) == accumulator register 8s + j
@@ -50,7 +48,6 @@ template <> struct AttnOps<bf16_t> {
       uint2 a0 = *(const uint2*)(row + (16 * s) * 2);
       uint2 a1 = *(const uint2*)(row + (16 * s + 8) * 2);
       u32x4 av = {a0.x, a0.y, a1.x, a1.y};
-      if (ones) av = (u32x4)(0x3F803F80u);
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), o, 0, 0, 0);
     }
     return o;
@@ -71,13 +68,11 @@ template <> struct AttnOps<float> {
     for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], q.v[i], c, 0, 0, 0);
     return c;
   }
-  static __device__ __forceinline__ f32x16 pv(const unsigned char* vlds, int key0, int r, int h, const f32x16& p, f32x16 o) {
-    const bool ones = (r & 8) != 0;
-    const unsigned char* row = vlds + (r & 7) * VT_PITCH + (key0 + 4 * h) * 4;
+  static __device__ __forceinline__ f32x16 pv(const unsigned char* vrow, int key0, const f32x16& p, f32x16 o) {
+    const unsigned char* row = vrow + key0 * 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 a = *(const f32x4*)(row + (8 * g) * 4);   // keys 8g + 4h + (0..3)  == accumulator registers 4g + (0..3)
-      if (ones) a = (f32x4)(1.f);
+      const f32x4 a = *(const f32x4*)(row + (8 * g) * 4);   // keys 8g + 4h + (0..3)  == accumulator registers 4g + (0..3)
 #pragma unroll
       for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], p[4 * g + i], o, 0, 0, 0);
     }
@@ -89,9 +84,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   using E = Elem<T>;
   using Ops = AttnOps<T>;
-  constexpr int KROW = 8 * E::BYTES;                 // bytes per K row
+  constexpr int KROW = 32;                           // bytes per K row: fp32 8 x 4 B; bf16 8 x 2 B + 16 zero bytes (the
+                                                     // unused k-slots 8..15 of the 32x32x16 MFMA, read by lanes h == 1)
   __shared__ __attribute__((aligned(16))) unsigned char klds[KT * KROW];
-  __shared__ __attribute__((aligned(16))) unsigned char vlds[8 * Ops::VT_PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char vlds[9 * Ops::VT_PITCH];   // rows 0..7 = V^T, row 8 = 1.0
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -107,6 +103,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   // fold softmax scale 8^-1/2 and log2(e) into q: p = exp2(s' - m')
   const float qscale = 0.35355339059327373f * 1.4426950408889634f;
   const typename Ops::QF qf = Ops::load_q(qp + (size_t)qclamp * 8, h, qscale);
+
+  // constant LDS content, written once: zero half of the bf16 K rows, all-ones row 8 of V^T (A rows 8..15 -> l)
+  if (E::BYTES == 2) *(f32x4*)(klds + (tid & 127) * KROW + 16) = (f32x4)(0.f);
+  for (int i = tid; i < KT; i += 256) *(T*)(vlds + 8 * Ops::VT_PITCH + i * E::BYTES) = E::from_f(1.0f);
+  const unsigned char* vrow = vlds + ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + 4 * h * E::BYTES;
 
   f32x16 o = (f32x16)(0.f);
   // Deferred-rescale online softmax.  `m` is the reference maximum (log2 domain) shared by both lane halves of a
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
-      o = Ops::pv(vlds, kb, r, h, s, o);
+      o = Ops::pv(vrow, kb, s, o);
     }
   }
 

@@ -32,6 +32,9 @@ struct ConvP {
   const float* temb; int temb_stride;
   const void* residual;
   void* y;
+  float* stats;        // [B][tiles][Cout][2] per-tile channel (sum, sumsq) of the stored output, or null
+  int im2col3;         // source is NCHW fp32 with C0r <= 3..4 real channels: 3x3 taps gathered into 32 virtual channels
+  int C0r;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -199,6 +202,38 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
     if (pix < NPIX) Stage<T>::xform_store(buf + pix * PITCH + sub * 8 * E::BYTES, stage[i], sc, sh, affine, do_silu, spix[i] >= 0);
   };
 
+  // conv_in (cond_unet_2d.py:127-129): the 3x3 conv over <= 3 fp32 NCHW channels is run as a 1x1 conv over 32 virtual
+  // channels k = ci*9 + ky*3 + kx (27 real, rest zero) gathered here straight into the LDS tile; thread = pixel.
+  auto stage_im2col = [&](unsigned char* buf) {
+    if constexpr (KS == 1 && STRIDE == 1) {
+      const int py = tid / TW, px = tid % TW;
+      const int oy = y0 + py, ox = x0 + px;
+      const float* src = (const float*)p.x0;
+      float v[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) v[k] = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (ci < p.C0r && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
+              v[ci * 9 + ky * 3 + kx] = src[(((size_t)n * p.C0r + ci) * p.Hin + iy) * p.Win + ix];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[q * 8 + j];
+        E::store(buf + tid * PITCH + q * 8 * E::BYTES, E::pack(o));
+      }
+    }
+  };
+
   // ---- per-lane LDS read bases for the B (activation) fragments
   int rbase[NF];
 #pragma unroll
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   // instead of an if/else diamond (which made the register allocator keep two accumulator sets)
   using std::true_type; using std::false_type;
 
-  issue_loads(0);                      // first: everything below overlaps the HBM latency of chunk 0
+  if (!p.im2col3) issue_loads(0);      // first: everything below overlaps the HBM latency of chunk 0
   // accumulators start at bias[co] + temb[n][co] (lane (pixel, h), register i <-> co = 8(i>>2) + 4h + (i&3)):
   // the epilogue then has no per-channel loads at all
   {
@@ -294,8 +329,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
     for (int i = 0; i < AD; ++i) aring[i] = E::load(wbase + (size_t)PD_WIDX(min(i, last_kstep)) * 512);
   }
   if (DB) {
+    if (p.im2col3) {
+      stage_im2col(lds);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) write_piece(i, lds);
+      for (int i = 0; i < NIT; ++i) write_piece(i, lds);
+    }
     if (p.nchunks > 1) issue_loads(1);
     PD_STAMP(1);
     __syncthreads();
@@ -364,6 +403,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   constexpr int PXI = 256 / PPP;               // pixels per iteration
   const int piece = tid % PPP, prow = tid / PPP;
   const int co = co_t * 64 + piece * EPC;
+  float ssum[EPC], ssq[EPC];                   // GroupNorm statistics of what is stored (consumer's norm input)
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   if (co < p.Cout) {
 #pragma unroll
     for (int it = 0; it < TP / PXI; ++it) {
@@ -388,12 +430,51 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
           }
         }
         *(u32x4*)((T*)p.y + opix * p.Cout + co) = v;
+        if (p.stats) {
+          if (E::BYTES == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+              ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float x = __uint_as_float(v[j]); ssum[j] += x; ssq[j] += x * x; }
+          }
+        }
       } else {  // PD_OUT_QKV_HEADS: [which][B][heads][N][8]
         const int Cq = p.heads * 8;
         const int which = co / Cq, cc = co - which * Cq;
         const size_t N = (size_t)p.Hout * p.Wout;
         const size_t tok = (size_t)oy * p.Wout + ox;
         *(u32x4*)((T*)p.y + ((((size_t)which * p.B + n) * p.heads + (cc >> 3)) * N + tok) * 8 + (cc & 7)) = v;
+      }
+    }
+  }
+  if (p.stats) {   // kernel-uniform
+    // lanes sharing a piece differ in the prow bits of the lane id: butterfly over those bits, then across waves via LDS
+    float* red = (float*)(lds + TP * EP_PITCH);           // [4 waves][64 ch][2]
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+#pragma unroll
+      for (int m = PPP; m < 64; m <<= 1) { ssum[j] += __shfl_xor(ssum[j], m); ssq[j] += __shfl_xor(ssq[j], m); }
+    }
+    if (lane < PPP) {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        red[(wave * 64 + piece * EPC + j) * 2] = ssum[j];
+        red[(wave * 64 + piece * EPC + j) * 2 + 1] = ssq[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid >> 1, which = tid & 1;
+      const int cog = co_t * 64 + c;
+      if (cog < p.Cout) {
+        const float tot = red[(0 * 64 + c) * 2 + which] + red[(1 * 64 + c) * 2 + which] + red[(2 * 64 + c) * 2 + which] +
+                          red[(3 * 64 + c) * 2 + which];
+        const int tile = ty * p.tiles_x + tx;
+        p.stats[(((size_t)n * (p.tiles_x * p.tiles_y) + tile) * p.Cout + cog) * 2 + which] = tot;
       }
     }
   }
@@ -406,7 +487,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
   constexpr int LDS_TILE = ((IN_TH * IN_TW * PITCH + 15) / 16) * 16;
   constexpr bool DB = 2 * LDS_TILE <= 100 * 1024;       // double-buffer when two tiles fit comfortably
-  constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16);
+  constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 2048;   // output tile + stats scratch
   constexpr int LDS_MAIN = DB ? 2 * LDS_TILE : LDS_TILE;
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
@@ -428,6 +509,13 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, st, q);
   PD_LAUNCH_CHECK();
   return PD_OK;
+}
+
+// tile shape by output width: 32-wide rows when possible (bank-conflict-free), else squarer tiles
+static void tile_shape(int ksize, int stride, int wout, int* th, int* tw) {
+  const int tp = (ksize == 3 && stride == 2) ? 128 : 256;
+  *tw = wout >= 32 ? 32 : (wout >= 16 ? 16 : 8);
+  *th = tp / *tw;
 }
 
 template <typename T>
@@ -480,6 +568,11 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   if (a->out_mode == PD_OUT_QKV_HEADS)
     PD_CHECK(a->heads > 0 && a->Cout == 3 * a->heads * 8, PD_ERR_SHAPE, "pd_conv: QKV mode needs Cout == 3*heads*8");
   PD_CHECK(a->out_mode == PD_OUT_NHWC || a->residual == nullptr, PD_ERR_UNSUPPORTED, "pd_conv: residual needs NHWC output");
+  if (a->im2col3) {
+    PD_CHECK(a->im2col3 <= 3 && a->ksize == 1 && a->C0 == 32 && a->C1 == 0 && !a->scale && !a->upsample && a->pad == 0,
+             PD_ERR_UNSUPPORTED, "pd_conv: im2col3 mode needs ksize=1, C0=32 (27 real), <= 3 source channels, no GroupNorm");
+  }
+  PD_CHECK(!a->stats_out || a->out_mode == PD_OUT_NHWC, PD_ERR_UNSUPPORTED, "pd_conv: stats_out needs NHWC output");
   const size_t esz = a->dtype == PD_F32 ? 4 : 2;
   const size_t bytes0 = (size_t)a->B * a->Hin * a->Win * a->C0 * esz, bytes1 = (size_t)a->B * a->Hin * a->Win * a->C1 * esz;
   PD_CHECK(bytes0 < 0x80000000ull && bytes1 < 0x80000000ull, PD_ERR_SHAPE,
@@ -492,6 +585,7 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   p.bytes0 = (unsigned)bytes0; p.bytes1 = (unsigned)(a->x1 ? bytes1 : bytes0);
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.w = a->w_packed; p.bias = a->bias;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.residual = a->residual; p.y = a->y;
+  p.stats = a->stats_out; p.im2col3 = a->im2col3 ? 1 : 0; p.C0r = a->im2col3;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PD_F32) return dispatch_conv<float>(p, a->ksize, a->stride, st);
   return dispatch_conv<bf16_t>(p, a->ksize, a->stride, st);
@@ -515,3 +609,9 @@ extern "C" int pd_debug_read_conv_stamps(unsigned long long* host, size_t bytes)
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pd::pd_conv_stamps), bytes, 0, hipMemcpyDeviceToHost);
 }
 #endif
+
+extern "C" int pd_conv_stat_tiles(int Hout, int Wout, int ksize, int stride) {
+  int th, tw;
+  pd::tile_shape(ksize, stride, Wout, &th, &tw);
+  return ((Hout + th - 1) / th) * ((Wout + tw - 1) / tw);
+}

@@ -175,6 +175,58 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const pd_gn_stats_args
   }
 }
 
+// pd_gn_finalize: per-tile channel sums written by pd_conv epilogues -> scale / shift.  One block per sample;
+// thread (channel-in-block-of-64, tile slice) streams the tile axis with coalesced 512-B rows; fp64 combine.
+__global__ __launch_bounds__(1024) void gn_finalize2_kernel(const pd_gn_finalize_args a) {
+  __shared__ double chs[1024], chq[1024];
+  __shared__ double part[16][64][2];
+  __shared__ float mean_s[64], rstd_s[64];
+  const int C = a.C0 + a.C1;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int cl = tid & 63, sl = tid >> 6;        // 64 channels x 16 tile slices
+  for (int cb = 0; cb < C; cb += 64) {
+    const int c = cb + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+      const bool first = c < a.C0;
+      const float* st = first ? a.stats0 : a.stats1;
+      const int Cs = first ? a.C0 : a.C1, T = first ? a.T0 : a.T1, cc = first ? c : c - a.C0;
+      const float* base = st + ((size_t)n * T * Cs + cc) * 2;
+      for (int t = sl; t < T; t += 16) {
+        const float2 v = *(const float2*)(base + (size_t)t * Cs * 2);
+        s += (double)v.x; q += (double)v.y;
+      }
+    }
+    part[sl][cl][0] = s; part[sl][cl][1] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      double ts = 0.0, tq = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { ts += part[k][cl][0]; tq += part[k][cl][1]; }
+      chs[c] = ts; chq[c] = tq;
+    }
+    __syncthreads();
+  }
+  const int gs = C / a.groups;
+  if (tid < a.groups) {
+    double ds = 0.0, dq = 0.0;
+    for (int c = tid * gs; c < (tid + 1) * gs; ++c) { ds += chs[c]; dq += chq[c]; }
+    const double cnt = (double)gs * (double)a.HW;
+    const double mean = ds / cnt;
+    double var = dq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    const int g = c / gs;
+    const float sc = rstd_s[g] * a.gamma[c];
+    a.scale[(size_t)n * C + c] = sc;
+    a.shift[(size_t)n * C + c] = a.beta[c] - mean_s[g] * sc;
+  }
+}
+
 // ================================================================================================
 // pd_ddim_step / pd_add_noise / pd_postproc: elementwise on fp32 NCHW
 // ================================================================================================
@@ -292,6 +344,18 @@ extern "C" int pd_gn_stats(const pd_gn_stats_args* a, void* stream) {
   else { set_error("pd_gn_stats: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->B), dim3(256), 0, st, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_gn_finalize: null args");
+  const int C = a->C0 + a->C1;
+  PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C1 >= 0 && C <= 1024 && a->T0 > 0, PD_ERR_SHAPE, "pd_gn_finalize: bad shape (C=%d)", C);
+  PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0, PD_ERR_SHAPE, "pd_gn_finalize: groups=%d C=%d", a->groups, C);
+  PD_CHECK(a->stats0 && a->gamma && a->beta && a->scale && a->shift, PD_ERR_ARG, "pd_gn_finalize: null pointer");
+  PD_CHECK((a->C1 == 0) == (a->stats1 == nullptr) && (a->C1 == 0 || a->T1 > 0), PD_ERR_ARG, "pd_gn_finalize: stats1/C1 mismatch");
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->B), dim3(1024), 0, (hipStream_t)stream, *a);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

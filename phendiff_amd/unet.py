@@ -274,6 +274,13 @@ class _PackedWeights:
         dev = device
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.conv_in_w, self.conv_in_b = f32(m.conv_in.weight), f32(m.conv_in.bias)
+        cin = m.conv_in.weight.shape[1]
+        if cin > 3:
+            raise NotImplementedError("conv_in on the HIP path takes <= 3 input channels (pixel-space UNet)")
+        # conv_in as a 1x1 conv over 32 virtual channels k = ci*9 + ky*3 + kx (pd_conv im2col3 mode)
+        wv = torch.zeros((m.conv_in.weight.shape[0], 32, 1, 1), dtype=torch.float32)
+        wv[:, :cin * 9, 0, 0] = m.conv_in.weight.detach().float().cpu().reshape(-1, cin * 9)
+        self.conv_in_wv = pack_conv_weight(wv, self.tdt).to(dev)
         te = m.time_embedding
         self.w1T, self.b1 = f32(te.linear_1.weight.t()), f32(te.linear_1.bias)
         self.w2T, self.b2 = f32(te.linear_2.weight.t()), f32(te.linear_2.bias)
@@ -356,6 +363,7 @@ class UNetPlan:
             raise ValueError(f"sample size {(H, W)} must be a multiple of {1 << (nlev - 1)}")
         self.ops = []
         self.bufs = []          # keep every device buffer alive
+        self.stats = {}         # id(NHWC activation) -> (per-tile channel sums [B][T][C][2], T) written by its producer
         self.groups = c.norm_num_groups
         self.temb_args = None
         self._temb_ptr_fields = []
@@ -376,24 +384,24 @@ class UNetPlan:
 
     # ---- op emitters -----------------------------------------------------------------------------
     def _gn(self, x0, x1, gamma, beta, eps):
+        """GroupNorm(32) of [x0 | x1] -> per-(sample, channel) scale/shift, from the statistics the producers of x0 / x1
+        emitted in their epilogues (no pass over the tensors)."""
         B, h, w, c0 = x0.shape
         c1 = x1.shape[3] if x1 is not None else 0
         C_ = c0 + c1
-        hw = h * w
-        splits = max(1, min(hw // 64, max(1, 2048 // self.B)))
-        partial = torch.empty((self.B, splits, C_, 2), dtype=torch.float64, device=self.device)
+        st0, t0 = self.stats[id(x0)]
+        st1, t1 = self.stats[id(x1)] if x1 is not None else (None, 0)
         scale, shift = self._f32(self.B, C_), self._f32(self.B, C_)
-        self.bufs.append(partial)
-        a = L.GnStatsArgs(dtype=self.code, B=self.B, HW=hw, C0=c0, C1=c1, groups=self.groups, eps=eps,
-                          x0=x0.data_ptr(), x1=L.ptr(x1), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
-                          partial=partial.data_ptr(), splits=splits, scale=scale.data_ptr(), shift=shift.data_ptr())
-        esz = 2 if self.code == L.PD_BF16 else 4
-        self.ops.append(_Op(self.lib.pd_gn_stats, a, "gn_stats", 3.0 * self.B * hw * C_, self.B * hw * C_ * esz))
+        a = L.GnFinalizeArgs(B=self.B, HW=h * w, groups=self.groups, eps=eps, C0=c0, T0=t0, stats0=st0.data_ptr(),
+                             C1=c1, T1=t1, stats1=L.ptr(st1), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+                             scale=scale.data_ptr(), shift=shift.data_ptr())
+        self.ops.append(_Op(self.lib.pd_gn_finalize, a, "gn_finalize", 0.0, self.B * (t0 * c0 + t1 * c1) * 8.0))
         return scale, shift
 
     def _conv(self, x0, x1, wpk, bias, cout, *, ksize=3, stride=1, pad=1, upsample=0, silu=0, gn=None, temb_off=None,
-              residual=None, out_mode=L.PD_OUT_NHWC, heads=0, cout_pad=None, y=None):
-        B, hin, win, c0 = x0.shape
+              residual=None, out_mode=L.PD_OUT_NHWC, heads=0, cout_pad=None, y=None, stats=True, im2col3=0, src_ptr=None,
+              src_shape=None):
+        B, hin, win, c0 = src_shape if src_shape is not None else x0.shape
         c1 = x1.shape[3] if x1 is not None else 0
         hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
         extra = 1 if (ksize == 3 and pad == 0) else 0
@@ -406,12 +414,17 @@ class UNetPlan:
             elif out_mode == L.PD_OUT_QKV_HEADS:
                 y = torch.empty((3, B, heads, hout * wout, 8), dtype=self.tdt, device=self.device)
                 self.bufs.append(y)
+        st = None
+        if stats and out_mode == L.PD_OUT_NHWC:
+            T = self.lib.pd_conv_stat_tiles(hout, wout, ksize, stride)
+            st = self._f32(B, T, cout, 2)
+            self.stats[id(y)] = (st, T)
         a = L.ConvArgs(dtype=self.code, B=B, Hin=hin, Win=win, Hout=hout, Wout=wout, C0=c0, C1=c1, Cout=cout,
                        Cout_pad=cout_pad, ksize=ksize, stride=stride, pad=pad, upsample=upsample, silu=silu,
-                       out_mode=out_mode, heads=heads, x0=x0.data_ptr(), x1=L.ptr(x1),
+                       out_mode=out_mode, heads=heads, x0=(x0.data_ptr() if x0 is not None else src_ptr), x1=L.ptr(x1),
                        scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None,
                        w_packed=wpk.data_ptr(), bias=bias.data_ptr(), temb=None, temb_stride=self.w.proj_dim,
-                       residual=L.ptr(residual), y=L.ptr(y))
+                       residual=L.ptr(residual), y=L.ptr(y), stats_out=L.ptr(st), im2col3=im2col3)
         if temb_off is not None:
             self._temb_ptr_fields.append((a, temb_off))
         esz = 2 if self.code == L.PD_BF16 else 4
@@ -430,7 +443,7 @@ class UNetPlan:
         h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=e.temb_off)
         gn2 = self._gn(h1, None, e.g2, e.be2, e.eps)
         if e.ws is not None:
-            sc, _ = self._conv(x0, x1, e.ws, e.bs, e.cout, ksize=1, pad=0)
+            sc, _ = self._conv(x0, x1, e.ws, e.bs, e.cout, ksize=1, pad=0, stats=False)
         else:
             assert x1 is None
             sc = x0
@@ -464,13 +477,12 @@ class UNetPlan:
                                     num_classes=(c.num_class_embeds or 0), w1=w.w1T.data_ptr(), b1=w.b1.data_ptr(),
                                     w2=w.w2T.data_ptr(), b2=w.b2.data_ptr(), class_table=L.ptr(w.class_table),
                                     wp=w.wpT.data_ptr(), bp=w.bp.data_ptr())
-        # conv_in
-        a0 = self._act(H, W, boc[0])
-        self._in_args = L.ConvInArgs(dtype=self.code, B=B, H=H, W=W, Cin=c.in_channels, Cout=boc[0],
-                                     x=None, w=w.conv_in_w.data_ptr(), bias=w.conv_in_b.data_ptr(), y=a0.data_ptr())
-        esz = 2 if self.code == L.PD_BF16 else 4
-        self.ops.append(_Op(self.lib.pd_conv_in, self._in_args, "conv_in", 2.0 * B * H * W * boc[0] * c.in_channels * 9,
-                            B * H * W * (c.in_channels * 4 + boc[0] * esz)))
+        # conv_in (cond_unet_2d.py:127-129,313): NCHW fp32 sample -> NHWC, MFMA 1x1 conv over 32 im2col channels
+        a0, self._in_args = self._conv(None, None, w.conv_in_wv, w.conv_in_b, boc[0], ksize=1, pad=0,
+                                       im2col3=c.in_channels, src_shape=(B, H, W, 32))
+        self.ops[-1].what = "conv_in"
+        self.ops[-1].flops = 2.0 * B * H * W * boc[0] * c.in_channels * 9
+        self.ops[-1].bytes = B * H * W * (c.in_channels * 4 + boc[0] * (2 if self.code == L.PD_BF16 else 4))
         h = a0
         skips = [a0]
         for i, blk in enumerate(m.down_blocks):
@@ -551,7 +563,7 @@ class UNetPlan:
         """One UNet evaluation: NCHW fp32 at ``x_ptr`` -> NCHW fp32 prediction at ``out_ptr``; ``temb_ptr`` is the
         [B][proj_dim] fp32 table of this step.  Asynchronous, allocation-free."""
         if self._cur != (x_ptr, temb_ptr, out_ptr):
-            self._in_args.x = x_ptr
+            self._in_args.x0 = x_ptr
             self._out_args.y = out_ptr
             for a, off in self._temb_ptr_fields:
                 a.temb = temb_ptr + 4 * off

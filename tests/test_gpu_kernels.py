@@ -289,3 +289,71 @@ def test_temb(env):
         ref = torch.cat([res.time_emb_proj(F.silu(embs)) for _, res in r.named_modules() if hasattr(res, "time_emb_proj")], 1)
     assert got.shape == ref.shape == (3, 2752)
     assert rel(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 40, 72, 3, 1), (1, 32, 96, 16, 16, 3, 1), (2, 64, 64, 32, 32, 3, 2), (2, 64, 128, 8, 8, 1, 1)])
+def test_conv_fused_gn_statistics(env, mode, shape):
+    """pd_conv(stats_out) + pd_gn_finalize == GroupNorm statistics of the stored conv output (also for a channel
+    concat of two producers, and with groups straddling the two sources: 64 + 32 channels -> 3 per group)."""
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    B, cin, cout, h, w_, ks, stride = shape
+    g = torch.Generator().manual_seed(11)
+    outs, stats, tiles = [], [], []
+    for co in (cout, 32):
+        x = torch.randn(B, cin, h, w_, generator=g) + 0.3
+        w = torch.randn(co, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+        b = torch.randn(co, generator=g)
+        pad = 1 if ks == 3 else 0
+        ho, wo = (h + 2 * pad - ks) // stride + 1, (w_ + 2 * pad - ks) // stride + 1
+        T = lib.pd_conv_stat_tiles(ho, wo, ks, stride)
+        X = nhwc(x.to(dev), tdt); wp = pack(w, tdt).to(dev); bb = b.to(dev)
+        y = torch.empty((B, ho, wo, co), dtype=tdt, device=dev)
+        st = torch.full((B, T, co, 2), float("nan"), device=dev)
+        a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=ho, Wout=wo, C0=cin, C1=0, Cout=co, Cout_pad=co, ksize=ks,
+                       stride=stride, pad=pad, upsample=0, silu=0, out_mode=0, heads=0, x0=X.data_ptr(), x1=None, scale=None,
+                       shift=None, w_packed=wp.data_ptr(), bias=bb.data_ptr(), temb=None, temb_stride=0, residual=None,
+                       y=y.data_ptr(), stats_out=st.data_ptr(), im2col3=0)
+        L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+        outs.append(y); stats.append(st); tiles.append(T)
+    torch.cuda.synchronize()
+    ycat = torch.cat([o.float().permute(0, 3, 1, 2) for o in outs], 1).cpu()
+    Cc = ycat.shape[1]
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    gm, bt = gamma.to(dev), beta.to(dev)
+    scale, shift = torch.empty((B, Cc), device=dev), torch.empty((B, Cc), device=dev)
+    a = L.GnFinalizeArgs(B=B, HW=ycat.shape[2] * ycat.shape[3], groups=32, eps=1e-5, C0=cout, T0=tiles[0], stats0=stats[0].data_ptr(),
+                         C1=32, T1=tiles[1], stats1=stats[1].data_ptr(), gamma=gm.data_ptr(), beta=bt.data_ptr(),
+                         scale=scale.data_ptr(), shift=shift.data_ptr())
+    L.check(lib.pd_gn_finalize(C.byref(a), stream()), "pd_gn_finalize")
+    torch.cuda.synchronize()
+    ref = F.group_norm(ycat, 32, gamma, beta, eps=1e-5)
+    got = ycat * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
+    assert rel(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(24, 40), (32, 32), (8, 8), (64, 64)])
+def test_conv_in_im2col_mode(env, mode, hw):
+    """conv_in (cond_unet_2d.py:127-129) as pd_conv(im2col3): NCHW fp32 sample -> NHWC, + output statistics."""
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    g = torch.Generator().manual_seed(12)
+    h, w_ = hw
+    x = torch.randn(2, 3, h, w_, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) / 5
+    b = torch.randn(64, generator=g)
+    wv = torch.zeros(64, 32, 1, 1)
+    wv[:, :27, 0, 0] = w.reshape(64, 27)
+    wp = pack(wv, tdt).to(dev)
+    X, bb = x.to(dev), b.to(dev)
+    y = torch.empty((2, h, w_, 64), dtype=tdt, device=dev)
+    a = L.ConvArgs(dtype=code, B=2, Hin=h, Win=w_, Hout=h, Wout=w_, C0=32, C1=0, Cout=64, Cout_pad=64, ksize=1, stride=1, pad=0,
+                   upsample=0, silu=0, out_mode=0, heads=0, x0=X.data_ptr(), x1=None, scale=None, shift=None,
+                   w_packed=wp.data_ptr(), bias=bb.data_ptr(), temb=None, temb_stride=0, residual=None, y=y.data_ptr(),
+                   stats_out=None, im2col3=3)
+    L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+    torch.cuda.synchronize()
+    ref = F.conv2d(bf16_round(x, mode), bf16_round(w, mode), b, padding=1)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
