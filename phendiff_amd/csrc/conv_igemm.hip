@@ -452,27 +452,25 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
     }
   }
   if (p.stats) {   // kernel-uniform
-    // lanes sharing a piece differ in the prow bits of the lane id: butterfly over those bits, then across waves via LDS
-    float* red = (float*)(lds + TP * EP_PITCH);           // [4 waves][64 ch][2]
+    // per-thread partials -> LDS [thread][2*EPC]; then (channel, sum|sumsq) threads add the PXI pixel-rows in a fixed
+    // order (deterministic, conflict-free: for one prow the 128 readers cover 512 contiguous bytes)
+    float* red = (float*)(lds + TP * EP_PITCH);
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) {
+    for (int q = 0; q < 2 * EPC / 4; ++q) {
+      f32x4 v4;
 #pragma unroll
-      for (int m = PPP; m < 64; m <<= 1) { ssum[j] += __shfl_xor(ssum[j], m); ssq[j] += __shfl_xor(ssq[j], m); }
-    }
-    if (lane < PPP) {
-#pragma unroll
-      for (int j = 0; j < EPC; ++j) {
-        red[(wave * 64 + piece * EPC + j) * 2] = ssum[j];
-        red[(wave * 64 + piece * EPC + j) * 2 + 1] = ssq[j];
-      }
+      for (int j = 0; j < 4; ++j) { const int e = q * 4 + j; v4[j] = e < EPC ? ssum[e] : ssq[e - EPC]; }
+      *(f32x4*)(red + tid * (2 * EPC) + q * 4) = v4;
     }
     __syncthreads();
     if (tid < 128) {
       const int c = tid >> 1, which = tid & 1;
+      const int pc = c / EPC, j = c % EPC;
       const int cog = co_t * 64 + c;
+      float tot = 0.f;
+#pragma unroll 8
+      for (int pr = 0; pr < PXI; ++pr) tot += red[(pr * PPP + pc) * (2 * EPC) + which * EPC + j];
       if (cog < p.Cout) {
-        const float tot = red[(0 * 64 + c) * 2 + which] + red[(1 * 64 + c) * 2 + which] + red[(2 * 64 + c) * 2 + which] +
-                          red[(3 * 64 + c) * 2 + which];
         const int tile = ty * p.tiles_x + tx;
         p.stats[(((size_t)n * (p.tiles_x * p.tiles_y) + tile) * p.Cout + cog) * 2 + which] = tot;
       }
@@ -487,7 +485,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
   constexpr int LDS_TILE = ((IN_TH * IN_TW * PITCH + 15) / 16) * 16;
   constexpr bool DB = 2 * LDS_TILE <= 100 * 1024;       // double-buffer when two tiles fit comfortably
-  constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 2048;   // output tile + stats scratch
+  constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 256 * 64;   // output tile + stats scratch [256][2*EPC] fp32
   constexpr int LDS_MAIN = DB ? 2 * LDS_TILE : LDS_TILE;
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
