@@ -40,13 +40,48 @@ def synth_batch(B, size, seed):
     return x, labels
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    host's cores, which oversubscribes a quota-limited container badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2
+            quota, period = f.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # v1
+                quota, period = int(f.read()), int(g.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(model_name, size, S, state_dict, seconds_budget=30.0):
     """The oracle (plain-PyTorch CPU fp32 restatement of the reference path) timed on this box's host cores on a
     bounded sample: B = 1 image, the first k inversion + first k denoising steps of the S-step schedules (per-step
     cost is step-independent), extrapolated to the 2*S-step trajectory."""
     import phendiff_amd as P
     from oracle import CondUNet2DRef, DDIMInverseSchedulerRef, DDIMSchedulerRef
-    torch.set_num_threads(os.cpu_count() or 1)
+    # thread count: the fastest of {8, 16, 32, 64, usable} on a small conv probe (a quota-limited container may report
+    # far more cores than it can run; oversubscription costs >10x)
+    import torch.nn.functional as F
+    probe_x, probe_w = torch.randn(1, 64, 128, 128), torch.randn(64, 64, 3, 3)
+    best = (float("inf"), 1)
+    for nthr in sorted({c for c in (8, 16, 32, 64, usable_cores()) if c <= usable_cores()} or {1}):
+        torch.set_num_threads(nthr)
+        F.conv2d(probe_x, probe_w, padding=1)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            F.conv2d(probe_x, probe_w, padding=1)
+        dt = time.perf_counter() - t0
+        if dt < best[0] * 0.95:
+            best = (dt, nthr)
+    cores = best[1]
+    torch.set_num_threads(cores)
     keys = CondUNet2DRef.__init__.__code__.co_varnames
     unet = CondUNet2DRef(**{k: v for k, v in dict(P.UNET_CONFIGS[model_name], sample_size=size).items() if k in keys}).eval()
     unet.load_state_dict(state_dict)
@@ -58,21 +93,21 @@ def cpu_baseline(model_name, size, S, state_dict, seconds_budget=30.0):
     times = []
     t_start = time.time()
     with torch.no_grad():
-        unet(x, 0, class_labels=labels)  # page in / warm the allocator (untimed)
         k = 0
-        while k < 3 or (time.time() - t_start < seconds_budget * 0.6 and k < 6):
+        while k < S and (len(times) < 3 or time.time() - t_start < seconds_budget):
             for sched, ts, lab in ((inv, inv.timesteps, labels), (fwd, fwd.timesteps, 1 - labels)):
                 t0 = time.perf_counter()
                 out = unet(x, ts[k], class_labels=lab).sample
-                x2 = sched.step(out, ts[k], x).prev_sample
+                sched.step(out, ts[k], x)
                 times.append(time.perf_counter() - t0)
             k += 1
-            del x2
+    if len(times) > 2:
+        times = times[1:]            # the first step pages in the allocator / thread pool
     times.sort()
     t_step = times[len(times) // 2]
-    return {"value": 1.0 / (2 * S * t_step), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (CPU fp32 torch), B=1 @{size}x{size}, median of {len(times)} UNet+scheduler steps "
-                      f"({k} inversion + {k} denoising of the S={S} schedules), extrapolated to {2 * S} steps; "
+    return {"value": 1.0 / (2 * S * t_step), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU fp32 torch, {cores} threads), B=1 @{size}x{size}, median of {len(times)} UNet+scheduler "
+                      f"steps ({k} inversion + {k} denoising of the S={S} schedules), extrapolated to {2 * S} steps; "
                       f"t_step={t_step:.3f}s"}
 
 

@@ -56,10 +56,11 @@ typedef struct {
   const float* timesteps;   /* [rows] fp32 (integer-valued) */
   const int64_t* labels;    /* [rows] or NULL */
   const float* class_emb;   /* [rows][tdim] or NULL (zeros => unconditional, cond_unet_2d.py:306-309) */
-  const float* w1; const float* b1;   /* time_embedding.linear_1 [tdim][c0], [tdim] */
-  const float* w2; const float* b2;   /* time_embedding.linear_2 [tdim][tdim], [tdim] */
+  /* all Linear weights are passed TRANSPOSED ([in][out], i.e. weight.t().contiguous()) so thread `out` streams coalesced */
+  const float* w1; const float* b1;   /* time_embedding.linear_1^T [c0][tdim], [tdim] */
+  const float* w2; const float* b2;   /* time_embedding.linear_2^T [tdim][tdim], [tdim] */
   const float* class_table;           /* class_embedding.weight [num_classes][tdim] or NULL */
-  const float* wp; const float* bp;   /* stacked time_emb_proj [proj_dim][tdim], [proj_dim] */
+  const float* wp; const float* bp;   /* stacked time_emb_proj^T [tdim][proj_dim], [proj_dim] */
   float* emb;               /* out [rows][tdim] (may be NULL) */
   float* proj;              /* out [rows][proj_dim] */
 } pd_temb_args;
@@ -85,7 +86,8 @@ int pd_conv_in(const pd_conv_in_args* a, void* stream);
  * Attention.group_norm and conv_norm_out (cond_unet_2d.py:175,195,221,236).  The input may be the
  * channel concatenation [x0 | x1] of two NHWC tensors (skip connections, cond_unet_2d.py:333-343),
  * (statistics are invariant under the nearest x2 upsample, so Upsample2D needs no flag here).
- * Two launches: partial sums (fp64 combine) and finalize.
+ * Two launches: partial sums (fp64 combine) and finalize.  Standalone form (one extra read of the tensor); the UNet
+ * plan uses the fused form instead: pd_conv(stats_out) in the producer + pd_gn_finalize.
  */
 typedef struct {
   int dtype;
@@ -95,7 +97,7 @@ typedef struct {
   float eps;
   const void* x0; const void* x1;
   const float* gamma; const float* beta;   /* [C0+C1] */
-  double* partial;          /* workspace [B][groups][splits][2] */
+  double* partial;          /* workspace [B][splits][C0+C1][2] */
   int splits;               /* partial blocks per (sample, group); >= 1 */
   float* scale; float* shift;   /* out [B][C0+C1] */
 } pd_gn_stats_args;

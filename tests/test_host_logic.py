@@ -1,0 +1,162 @@
+"""Host-side logic of the product (no GPU): scheduler tables / grids / coefficients against the oracle and the
+golden fixtures (bit-exact where integer), weight packing layout, module tree = diffusers names, config validation,
+batch sharding, and the no-CPU-fallback rule."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import phendiff_amd as P
+from oracle import CondUNet2DRef, DDIMInverseSchedulerRef, DDIMSchedulerRef
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(P.SCHEDULER_CONFIGS))
+def test_scheduler_tables_bit_exact_vs_oracle(name):
+    cfg = P.SCHEDULER_CONFIGS[name]
+    got, ref = P.DDIMScheduler(**cfg), DDIMSchedulerRef(**cfg)
+    assert torch.equal(got.alphas_cumprod, ref.alphas_cumprod)
+    assert float(got.final_alpha_cumprod) == float(ref.final_alpha_cumprod)
+    igot, iref = P.DDIMInverseScheduler.from_config(got.config), DDIMInverseSchedulerRef.from_config(ref.config)
+    assert torch.equal(igot.alphas_cumprod, iref.alphas_cumprod)
+    assert float(igot.final_alpha_cumprod) == float(iref.final_alpha_cumprod)
+    for S in (1, 4, 50, 100, 999):
+        got.set_timesteps(S); ref.set_timesteps(S); igot.set_timesteps(S); iref.set_timesteps(S)
+        assert got.timesteps.dtype == torch.int64 and torch.equal(got.timesteps, ref.timesteps)
+        assert torch.equal(igot.timesteps, iref.timesteps)
+    for variant in ("0.18.2", "0.20+"):
+        a = P.DDIMInverseScheduler.from_config(got.config, variant=variant)
+        b = DDIMInverseSchedulerRef.from_config(ref.config, variant=variant)
+        a.set_timesteps(50); b.set_timesteps(50)
+        assert torch.equal(a.timesteps, b.timesteps) and torch.equal(a.alphas_cumprod, b.alphas_cumprod)
+
+
+def test_scheduler_golden_fixture():
+    d = np.load(os.path.join(GOLDEN, "scheduler_3k.npz"))
+    s = P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+    s.set_timesteps(50)
+    assert np.array_equal(s.alphas_cumprod.numpy(), d["alphas_cumprod"])
+    assert np.array_equal(s.timesteps.numpy(), d["timesteps_50"])
+    inv = P.DDIMInverseScheduler.from_config(s.config)
+    inv.set_timesteps(50)
+    assert np.array_equal(inv.alphas_cumprod.numpy(), d["inv_alphas_cumprod"])
+    assert np.array_equal(inv.timesteps.numpy(), d["inv_timesteps_50"])
+
+
+def test_step_coefficients_match_oracle_arithmetic():
+    """The four fp32 coefficients handed to pd_ddim_step reproduce the oracle's update exactly on CPU."""
+    cfg = P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]
+    got, ref = P.DDIMScheduler(**cfg), DDIMSchedulerRef(**cfg)
+    got.set_timesteps(50); ref.set_timesteps(50)
+    g = torch.Generator().manual_seed(0)
+    x, v = torch.randn(2, 3, 8, 8, generator=g), torch.randn(2, 3, 8, 8, generator=g)
+    for t in ref.timesteps[::7]:
+        sa, sb, sap, dirc, sigma = got.step_coefficients(t)
+        x0 = (torch.tensor(sa) * x - torch.tensor(sb) * v).clamp(-1, 1)
+        eps = torch.tensor(sa) * v + torch.tensor(sb) * x
+        mine = torch.tensor(sap) * x0 + torch.tensor(dirc) * eps
+        assert torch.equal(mine, ref.step(v, t, x).prev_sample)
+        assert sigma == 0.0
+
+
+def test_no_cpu_fallback():
+    s = P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+    s.set_timesteps(4)
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(P.PhenDiffHipError):
+        s.step(x, s.timesteps[0], x)
+    with pytest.raises(P.PhenDiffHipError):
+        s.add_noise(x, x, torch.tensor([3]))
+    m = P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], sample_size=32))
+    with pytest.raises(P.PhenDiffHipError):
+        m(x.expand(1, 3, 32, 32) if False else torch.zeros(1, 3, 32, 32), 1, class_labels=torch.tensor([0]))
+    import phendiff_amd._lib as L
+    import inspect
+    for mod in (P.unet, P.schedulers, P.pipeline, P.img2img, L):
+        assert "oracle" not in inspect.getsource(mod).replace("the oracle", "").replace("CPU oracle", ""), mod.__name__
+
+
+def test_pack_conv_weight_layout():
+    from phendiff_amd.packing import pack_conv_weight
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(40, 64, 3, 3, generator=g)
+    p = pack_conv_weight(w, torch.float32, 64)
+    assert p.shape == (2, 2, 9, 2, 64, 8)
+    for (ct, ch, tap, s, lane, j) in [(0, 0, 0, 0, 0, 0), (1, 1, 8, 1, 63, 7), (0, 1, 4, 0, 37, 3), (1, 0, 2, 1, 5, 6)]:
+        r, h = lane & 31, lane >> 5
+        co, ci = 32 * ct + r, 32 * ch + 16 * s + 8 * h + j
+        want = w[co, ci, tap // 3, tap % 3] if co < 40 else 0.0
+        assert float(p[ct, ch, tap, s, lane, j]) == float(want)
+    pb = pack_conv_weight(w, torch.bfloat16, 64)
+    assert pb.dtype == torch.bfloat16 and torch.equal(pb.float(), p.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("name", ["super_small", "small_denoiser_config"])
+def test_module_tree_matches_diffusers_names(name):
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    torch.manual_seed(0)
+    ref = CondUNet2DRef(**{k: v for k, v in P.UNET_CONFIGS[name].items() if k in keys})
+    torch.manual_seed(0)
+    got = P.CustomCondUNet2DModel(**P.UNET_CONFIGS[name])
+    rs, gs = ref.state_dict(), got.state_dict()
+    assert list(rs) == list(gs)
+    assert all(rs[k].shape == gs[k].shape for k in rs)
+    assert all(torch.equal(rs[k], gs[k]) for k in rs)       # same construction order => same default init
+    assert got.time_embed_dim == 4 * P.UNET_CONFIGS[name]["block_out_channels"][0]
+    assert sum(p.numel() for p in got.parameters()) == {"super_small": 15_725_443, "small_denoiser_config": 62_826_243}[name]
+    # surface the reference touches: train.py:215-220 (.attentions on sub-modules), inspect.signature (class_emb)
+    import inspect
+    assert "class_emb" in inspect.signature(got.forward).parameters
+    assert any(hasattr(mod, "attentions") for mod in got.modules())
+    assert got.config.sample_size == 128 and got.config.in_channels == 3
+
+
+def test_config_validation():
+    with pytest.raises(ValueError):
+        P.CustomCondUNet2DModel(down_block_types=("DownBlock2D",), up_block_types=("UpBlock2D", "UpBlock2D"), block_out_channels=(64,))
+    with pytest.raises(ValueError):
+        P.CustomCondUNet2DModel(down_block_types=("DownBlock2D",), up_block_types=("UpBlock2D",), block_out_channels=(64, 128))
+    with pytest.raises(NotImplementedError):
+        P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], time_embedding_type="fourier"))
+    with pytest.raises(TypeError):
+        P.CustomCondUNet2DModel(bogus=1)
+    with pytest.raises(ValueError):
+        P.DDIMScheduler(prediction_type="nope")
+    with pytest.raises(ValueError):
+        P.DDIMInverseScheduler(variant="1.0")
+
+
+def test_pipeline_check_inputs_like_reference():
+    pipe = P.ConditionalDDIMPipeline(P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], sample_size=32)),
+                                     P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
+    assert isinstance(pipe.scheduler, P.DDIMScheduler) and set(pipe.components) == {"unet", "scheduler"}
+    lab = torch.tensor([0, 1])
+    pipe.check_inputs(lab, None, 2.5, None, 0.5, torch.zeros(2, 3, 32, 32))
+    with pytest.raises(AssertionError):
+        pipe.check_inputs(lab, torch.zeros(2, 256))                      # both labels and emb
+    with pytest.raises(AssertionError):
+        pipe.check_inputs(lab, None, None, None, 0.5, None)             # frac without start image
+    with pytest.raises(AssertionError):
+        pipe.check_inputs(lab, None, torch.ones(3))                     # w of the wrong batch size
+    with pytest.raises(ValueError):
+        pipe.check_inputs(lab, None, None, [torch.Generator()])         # generator list of the wrong length
+    with pytest.raises(AssertionError):
+        pipe.check_inputs(lab, None, None, None, 1.5, torch.zeros(2, 3, 32, 32))
+
+
+def test_shard_batches_batchsamplershard_semantics():
+    assert P.shard_batches(8, 1, 4) == [1, 5]
+    assert [P.shard_batches(5, r, 4) for r in range(4)] == [[0, 4], [1, 0], [2, 1], [3, 2]]   # tail wraps to the start
+    assert [P.shard_batches(2, r, 4) for r in range(4)] == [[0], [1], [0], [1]]
+    assert P.shard_batches(5, 1, 4, even_batches=False) == [1]
+    assert P.shard_batches(0, 0, 2) == []
+    for n in range(1, 20):
+        for g in (1, 2, 3, 8):
+            shards = [P.shard_batches(n, r, g) for r in range(g)]
+            assert len({len(s) for s in shards}) == 1                     # every rank runs the same number of steps
+            assert set(range(n)) <= {b for s in shards for b in s}      # every batch is processed
+    assert torch.equal(P.swap_binary_labels(torch.tensor([0, 1, 1])), torch.tensor([1, 0, 0]))
+    with pytest.raises(ValueError):
+        P.shard_batches(4, 2, 2)
