@@ -6,17 +6,18 @@
 //        softmax is lane-local (one cross-half exchange per tile), and the exponentiated tile is ALREADY the
 //        B operand of the next product (rows of D == k index of B), no LDS round trip:
 //   O^T[row][query] += A[row][key] . P^T[key][query]  A rows 0..7 = V^T (d), rows 8..15 = 1.0  (=> row sum l for free)
-// Workgroup = 4 waves = 128 queries; K and V^T tiles of 128 keys are staged through LDS (V transposed on the way).
+// Workgroup = 4 waves = 128 queries; K and V^T tiles of 256 keys are staged through double-buffered LDS (V transposed on
+// the way, next tile's global loads in flight during the current tile's math, one barrier per tile).
 #include "pd_common.h"
 
 namespace pd {
 
-constexpr int KT = 128;   // keys per LDS tile
+constexpr int KT = 256;   // keys per LDS tile (double-buffered: one barrier per tile)
 
 template <typename T> struct AttnOps;
 
 template <> struct AttnOps<bf16_t> {
-  static constexpr int VT_PITCH = (KT + 8) * 2;   // bytes per V^T row (pad -> 8 rows on distinct banks)
+  static constexpr int VT_PITCH = (KT + 8) * 2;   // bytes per V^T row (pad -> rows on distinct banks)
   struct QF { s16x8 v; };
   static __device__ __forceinline__ QF load_q(const bf16_t* q, int h, float scale) {
     QF f; f.v = (s16x8)(0);
@@ -26,6 +27,12 @@ template <> struct AttnOps<bf16_t> {
       for (int j = 0; j < 8; ++j) f.v[j] = (short)f2bf(bf2f((bf16_t)raw[j]) * scale);
     }
     return f;
+  }
+  static __device__ __forceinline__ float q_norm2(const QF& q) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = bf2f((bf16_t)q.v[j]); t += v * v; }
+    return t;
   }
   // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
   static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q, const f32x16& c) {
@@ -62,6 +69,9 @@ template <> struct AttnOps<float> {
     f.v *= scale;
     return f;
   }
+  static __device__ __forceinline__ float q_norm2(const QF& q) {
+    return q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3];
+  }
   static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q, f32x16 c) {
     const f32x4 a = *(const f32x4*)(klds + key * 32 + h * 16);   // d = 4h + i
 #pragma unroll
@@ -86,8 +96,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   using Ops = AttnOps<T>;
   constexpr int KROW = 32;                           // bytes per K row: fp32 8 x 4 B; bf16 8 x 2 B + 16 zero bytes (the
                                                      // unused k-slots 8..15 of the 32x32x16 MFMA, read by lanes h == 1)
-  __shared__ __attribute__((aligned(16))) unsigned char klds[KT * KROW];
-  __shared__ __attribute__((aligned(16))) unsigned char vlds[9 * Ops::VT_PITCH];   // rows 0..7 = V^T, row 8 = 1.0
+  constexpr int VBYTES = 9 * Ops::VT_PITCH;          // rows 0..7 = V^T, row 8 = 1.0
+  __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char vlds[2][VBYTES];
+  __shared__ float knmax[2][KT / 32];                // max |k| over each 32-key sub-tile (Cauchy-Schwarz score bound)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -105,78 +117,117 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   const typename Ops::QF qf = Ops::load_q(qp + (size_t)qclamp * 8, h, qscale);
 
   // constant LDS content, written once: zero half of the bf16 K rows, all-ones row 8 of V^T (A rows 8..15 -> l)
-  if (E::BYTES == 2) *(f32x4*)(klds + (tid & 127) * KROW + 16) = (f32x4)(0.f);
-  for (int i = tid; i < KT; i += 256) *(T*)(vlds + 8 * Ops::VT_PITCH + i * E::BYTES) = E::from_f(1.0f);
-  const unsigned char* vrow = vlds + ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + 4 * h * E::BYTES;
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) {
+    if (E::BYTES == 2) *(f32x4*)(klds[b2] + tid * KROW + 16) = (f32x4)(0.f);
+    *(T*)(vlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(1.0f);
+  }
+  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + 4 * h * E::BYTES;
 
   f32x16 o = (f32x16)(0.f);
   // Deferred-rescale online softmax.  `m` is the reference maximum (log2 domain) shared by both lane halves of a
   // query; -m rides in the C operand of the QK^T MFMA, so s' = S - m leaves the matrix pipe ready for exp2.  m is
   // only raised when some s' exceeds RESCALE_THR (p <= 2^THR otherwise): the common path has no cross-lane traffic,
   // no subtraction and no accumulator rescale.
-  constexpr float RESCALE_THR = 6.0f;
+  // A tile needs the exact row max only if some score COULD exceed m + THR.  s = q.k <= |q| * max|k|, so when
+  // |q| * max|k| - m <= THR the max / ballot / branch are skipped altogether (the usual case once m has settled).
+#ifdef PD_ABL_THR
+  constexpr float RESCALE_THR = 1e30f;   // ablation only: never take the exact-max path after the first tile
+#else
+  constexpr float RESCALE_THR = 16.0f;
+#endif
+  float qn = Ops::q_norm2(qf);
+  qn += __shfl_xor(qn, 32);
+  qn = sqrtf(qn) * 1.00001f + 1e-6f;
   float m = 0.f;
   f32x16 negm = (f32x16)(0.f);
   bool first = true;
-  // staging: thread t < 128 owns K row t, thread t >= 128 owns V row t-128 of the tile
-  const int srow = tid & 127;
-  const bool is_v = tid >= 128;
-  typename E::Frag st;
+  // staging: thread t owns K row t and V row t of the 256-key tile
+  typename E::Frag stk, stv;
   auto issue = [&](int k0) {
-    const int key = k0 + srow;
-    if (key < N) st = E::load((is_v ? vp : kp) + (size_t)key * 8);
-    else st = E::zero();
+    const int key = k0 + tid;
+    if (key < N) { stk = E::load(kp + (size_t)key * 8); stv = E::load(vp + (size_t)key * 8); }
+    else { stk = E::zero(); stv = E::zero(); }
   };
-  auto commit = [&]() {
-    if (!is_v) {
-      E::store(klds + srow * KROW, st);
-    } else {
-      float v[8];
-      E::unpack(st, v);
+  auto commit = [&](int b2) {
+    E::store(klds[b2] + tid * KROW, stk);
+    float kv[8], n2 = 0.f;
+    E::unpack(stk, kv);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) *(T*)(vlds + d * Ops::VT_PITCH + srow * E::BYTES) = E::from_f(v[d]);
-    }
+    for (int d = 0; d < 8; ++d) n2 += kv[d] * kv[d];
+#pragma unroll
+    for (int msk = 16; msk >= 1; msk >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, msk));
+    if ((tid & 31) == 0) knmax[b2][tid >> 5] = sqrtf(n2) * 1.00001f;
+    float v[8];
+    E::unpack(stv, v);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) *(T*)(vlds[b2] + d * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(v[d]);
   };
 
   issue(0);
-  for (int k0 = 0; k0 < N; k0 += KT) {
-    if (k0 > 0) __syncthreads();
-    commit();
-    __syncthreads();
-    if (k0 + KT < N) issue(k0 + KT);
+  commit(0);
+  if (KT < N) issue(KT);
+  __syncthreads();
+  for (int k0 = 0, cur = 0; k0 < N; k0 += KT, cur ^= 1) {
+    const unsigned char* kl = klds[cur];
+    const unsigned char* vrow = vlds[cur] + vrow_off;
+    // one bound for the whole 256-key tile: if even |q| * max|k| cannot push a score above m + THR, the 8 sub-tiles
+    // run the check-free body (QK^T MFMA -> 16 x v_exp -> 8 x cvt_pk -> 2 PV MFMAs, nothing else)
+    float kn8 = knmax[cur][0];
 #pragma unroll
-    for (int sub = 0; sub < KT / 32; ++sub) {
-      const int kb = sub * 32;
-      if (k0 + kb >= N) break;
-      f32x16 s = Ops::qk(klds, kb + r, h, qf, negm);
-      // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
-      if (k0 + kb + 32 > N) {
+    for (int i = 1; i < KT / 32; ++i) kn8 = fmaxf(kn8, knmax[cur][i]);
+    const bool full_tile = k0 + KT <= N;
+    if (full_tile && !__builtin_amdgcn_ballot_w64(first || qn * kn8 - m > RESCALE_THR)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = k0 + kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (key >= N) s[i] = -INFINITY;
+      for (int sub = 0; sub < KT / 32; ++sub) {
+        f32x16 s = Ops::qk(kl, sub * 32 + r, h, qf, negm);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+        o = Ops::pv(vrow, sub * 32, s, o);
+      }
+    } else {
+#pragma unroll 1
+      for (int sub = 0; sub < KT / 32; ++sub) {
+        const int kb = sub * 32;
+        if (k0 + kb >= N) break;
+        f32x16 s = Ops::qk(kl, kb + r, h, qf, negm);
+        // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
+        if (k0 + kb + 32 > N) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = k0 + kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (key >= N) s[i] = -INFINITY;
+          }
         }
+        const float bound = qn * knmax[cur][sub] - m;   // upper bound of every s' of this lane in this sub-tile
+        if (__builtin_amdgcn_ballot_w64(first || bound > RESCALE_THR)) {   // wave-uniform
+          float tmax = s[0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+          if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR)) {
+            const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));           // finite: the first tile holds key 0
+            const float delta = first ? t2 : fmaxf(t2, 0.f);
+            const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] *= sc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] -= delta;
+            m += delta;
+            negm = (f32x16)(-m);
+            first = false;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+        o = Ops::pv(vrow, kb, s, o);
       }
-      float tmax = s[0];
-#pragma unroll
-      for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-      if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR)) {   // wave-uniform, rare after the first tile
-        const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));             // finite: the first tile holds key 0
-        const float delta = first ? t2 : fmaxf(t2, 0.f);
-        const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-        // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] *= sc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] -= delta;
-        m += delta;
-        negm = (f32x16)(-m);
-        first = false;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
-      o = Ops::pv(vrow, kb, s, o);
     }
+    if (k0 + KT < N) {
+      commit(cur ^ 1);                       // tile k0+KT: loaded during the previous tile's math
+      if (k0 + 2 * KT < N) issue(k0 + 2 * KT);
+    }
+    __syncthreads();
   }
 
   if (query < N) {
