@@ -511,7 +511,11 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
 
 // tile shape by output width: 32-wide rows when possible (bank-conflict-free), else squarer tiles
 static void tile_shape(int ksize, int stride, int wout, int* th, int* tw) {
+#ifdef PD_EXP_TP128
+  const int tp = (ksize == 3) ? 128 : 256;
+#else
   const int tp = (ksize == 3 && stride == 2) ? 128 : 256;
+#endif
   *tw = wout >= 32 ? 32 : (wout >= 16 ? 16 : 8);
   *th = tp / *tw;
 }
@@ -521,9 +525,15 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
   // tile shape by output width: 32-wide rows when possible (bank-conflict-free), else squarer tiles
   const int w = p.Wout;
   if (ksize == 3 && stride == 1) {
+#ifdef PD_EXP_TP128
+    if (w >= 32) return launch_conv<T, 3, 1, 4, 32>(p, st);
+    if (w >= 16) return launch_conv<T, 3, 1, 8, 16>(p, st);
+    return launch_conv<T, 3, 1, 16, 8>(p, st);
+#else
     if (w >= 32) return launch_conv<T, 3, 1, 8, 32>(p, st);
     if (w >= 16) return launch_conv<T, 3, 1, 16, 16>(p, st);
     return launch_conv<T, 3, 1, 32, 8>(p, st);
+#endif
   }
   if (ksize == 3 && stride == 2) {
     if (w >= 32) return launch_conv<T, 3, 2, 4, 32>(p, st);

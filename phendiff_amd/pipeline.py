@@ -62,6 +62,19 @@ class ConditionalDDIMPipeline:
         self.unet.to(*args, **kwargs)
         return self
 
+    @classmethod
+    def from_pretrained(cls, path, compute_dtype="bf16", **kwargs):
+        """``ConditionalDDIMPipeline.from_pretrained(<folder>)`` (utils_models.py:144, DDIM.yaml:3-5)."""
+        import os
+        from .unet import CustomCondUNet2DModel
+        unet = kwargs.pop("unet", None) or CustomCondUNet2DModel.from_pretrained(os.path.join(path, "unet"), compute_dtype=compute_dtype)
+        scheduler = kwargs.pop("scheduler", None) or DDIMScheduler.from_pretrained(os.path.join(path, "scheduler"))
+        return cls(unet=unet, scheduler=scheduler)
+
+    def save_pretrained(self, path, safe_serialization=True):
+        from .checkpoint import save_pipeline
+        save_pipeline(self, path, safe_serialization)
+
     def set_progress_bar_config(self, **kwargs):
         self._progress_bar_config = kwargs
 

@@ -73,6 +73,16 @@ class _SchedulerBase:
         d.update(overrides)
         return cls(**d)
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **overrides):
+        import os
+        from .checkpoint import load_scheduler
+        return load_scheduler(cls, os.path.join(path, subfolder) if subfolder else path, **overrides)
+
+    def save_pretrained(self, path):
+        from .checkpoint import save_scheduler
+        save_scheduler(self, path)
+
     def scale_model_input(self, sample, timestep=None):
         return sample
 

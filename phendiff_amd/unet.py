@@ -200,6 +200,17 @@ class CustomCondUNet2DModel(nn.Module):
         d.update(overrides)
         return cls(compute_dtype=compute_dtype, **d)
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, compute_dtype="bf16", **overrides):
+        """diffusers folder layout (``config.json`` + ``diffusion_pytorch_model.{safetensors,bin}``)."""
+        import os
+        from .checkpoint import load_unet
+        return load_unet(cls, os.path.join(path, subfolder) if subfolder else path, compute_dtype, **overrides)
+
+    def save_pretrained(self, path, safe_serialization=True):
+        from .checkpoint import save_unet
+        save_unet(self, path, safe_serialization)
+
     @property
     def dtype(self):
         return self.conv_in.weight.dtype

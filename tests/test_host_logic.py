@@ -160,3 +160,33 @@ def test_shard_batches_batchsamplershard_semantics():
     assert torch.equal(P.swap_binary_labels(torch.tensor([0, 1, 1])), torch.tensor([1, 0, 0]))
     with pytest.raises(ValueError):
         P.shard_batches(4, 2, 2)
+
+
+def test_pretrained_folder_roundtrip_and_deprecated_attention_keys(tmp_path):
+    """diffusers save_pretrained layout incl. the 0.18 on-disk attention aliases."""
+    import json
+    from phendiff_amd.checkpoint import remap_deprecated_attention_keys
+    torch.manual_seed(1)
+    unet = P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], sample_size=32))
+    pipe = P.ConditionalDDIMPipeline(unet, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
+    pipe.save_pretrained(str(tmp_path / "pipe"))
+    idx = json.load(open(tmp_path / "pipe" / "model_index.json"))
+    assert idx["unet"] == ["src.cond_unet_2d.cond_unet_2d", "CustomCondUNet2DModel"]
+    back = P.ConditionalDDIMPipeline.from_pretrained(str(tmp_path / "pipe"), compute_dtype="f32")
+    assert back.unet.compute_dtype == "f32" and back.unet.config.sample_size == 32
+    assert all(torch.equal(a, b) for a, b in zip(unet.state_dict().values(), back.unet.state_dict().values()))
+    assert vars(back.scheduler.config) == vars(pipe.scheduler.config)
+    assert torch.equal(back.scheduler.alphas_cumprod, pipe.scheduler.alphas_cumprod)
+    # a 0.18-style .bin with query/key/value/proj_attn names loads into to_q/to_k/to_v/to_out.0
+    sd = unet.state_dict()
+    old = {}
+    for k, v in sd.items():
+        for new, dep in ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn.")):
+            k = k.replace(new, dep)
+        old[k] = v
+    assert any(".query." in k for k in old) and set(remap_deprecated_attention_keys(old)) == set(sd)
+    folder = tmp_path / "old_unet"
+    unet.save_pretrained(str(folder), safe_serialization=False)
+    torch.save(old, folder / "diffusion_pytorch_model.bin")
+    legacy = P.CustomCondUNet2DModel.from_pretrained(str(folder))
+    assert all(torch.equal(a, b) for a, b in zip(sd.values(), legacy.state_dict().values()))
