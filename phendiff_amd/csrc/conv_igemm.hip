@@ -23,7 +23,7 @@ struct ConvP {
   int B, Hin, Win, Hout, Wout;
   int C0, C1, Cout, Cout_pad;
   int pad, upsample, silu, out_mode, heads;
-  int tiles_x, tiles_y, n_pix_tiles, n_co_tiles, nchunks;
+  int tiles_x, tiles_y, tiles_x_shift, n_co_tiles, nchunks;
   unsigned bytes0, bytes1;
   const void* x0; const void* x1;
   const float* scale; const float* shift;
@@ -45,15 +45,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #else
 #define PD_WIDX(i) (i)
 #endif
+__device__ __forceinline__ unsigned pd_lin_block() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
 #ifdef PD_STAMPS   // diagnostic build only (scripts/stamp_conv.py): phase timestamps of the first workgroups
-__device__ unsigned long long pd_conv_stamps[4096 * 8];
+__device__ unsigned long long pd_conv_stamps[4096 * 16];
 #define PD_STAMP(k)                                                                                   \
   do {                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     unsigned long long t_;                                                                            \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) pd_conv_stamps[blockIdx.x * 8 + (k)] = t_;            \
+    if (threadIdx.x == 0 && pd_lin_block() < 4096) pd_conv_stamps[pd_lin_block() * 16 + (k)] = t_;            \
   } while (0)
 #else
 #define PD_STAMP(k) do {} while (0)
@@ -126,16 +127,14 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
-  // ---- block -> (pixel tile, co tile); blocks b and b+8 share an XCD (L2): co tiles of one pixel tile go there
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, jj = bid >> 3;
-  const int co_t = jj % p.n_co_tiles;
-  const int pt = (jj / p.n_co_tiles) * 8 + xcd;
-  if (pt >= p.n_pix_tiles) return;
+  // ---- block -> (pixel tile, co tile, sample) = (x, y, z): the co tiles of one pixel tile are tiles-per-image blocks
+  // apart in dispatch order, i.e. on the same XCD / L2 whenever tiles-per-image % 8 == 0 (speed only)
+  const int co_t = blockIdx.y;
+  const int n = blockIdx.z;
+  int tx, ty;
+  if (p.tiles_x_shift >= 0) { tx = blockIdx.x & (p.tiles_x - 1); ty = blockIdx.x >> p.tiles_x_shift; }
+  else { ty = blockIdx.x / p.tiles_x; tx = blockIdx.x - ty * p.tiles_x; }
   PD_STAMP(0);
-  const int tx = pt % p.tiles_x;
-  const int ty = (pt / p.tiles_x) % p.tiles_y;
-  const int n = pt / (p.tiles_x * p.tiles_y);
   const int y0 = ty * TH, x0 = tx * TW;
 
   const int tid = threadIdx.x;
@@ -174,17 +173,25 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
 
   SR stage[NIT];
   float sc[8], sh[8];
+  unsigned soff[NIT];     // byte offset of (pixel, sub-block) in the CURRENT source; OOB_OFF for padding
+  int soff_src = -1;
   auto issue_loads = [&](int chunk) {
     const int cch = chunk * 32;
     const bool s0 = cch < p.C0;
-    const unsigned cs = s0 ? p.C0 : p.C1;
-    const unsigned coff = (s0 ? cch : cch - p.C0) + sub * 8;
+    if (soff_src != (s0 ? 0 : 1)) {      // (re)computed once per source: at most twice per tile
+      soff_src = s0 ? 0 : 1;
+      const unsigned cs = s0 ? p.C0 : p.C1;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+        soff[i] = spix[i] >= 0 ? ((unsigned)spix[i] * cs + sub * 8) * E::BYTES : OOB_OFF;
+    }
+    const unsigned cbytes = (unsigned)(s0 ? cch : cch - p.C0) * E::BYTES;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
 #ifdef PD_ABL_X0
       const unsigned off = OOB_OFF;   // ablation: no activation traffic
 #else
-      const unsigned off = spix[i] >= 0 ? ((unsigned)spix[i] * cs + coff) * E::BYTES : OOB_OFF;
+      const unsigned off = soff[i] + (spix[i] >= 0 ? cbytes : 0u);
 #endif
       stage[i] = s0 ? Stage<T>::load(rs0, off) : Stage<T>::load(rs1, off);
     }
@@ -296,44 +303,54 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   // instead of an if/else diamond (which made the register allocator keep two accumulator sets)
   using std::true_type; using std::false_type;
 
-  if (!p.im2col3) issue_loads(0);      // first: everything below overlaps the HBM latency of chunk 0
+  PD_STAMP(7);
+  // bias / temb first: they are older than the HBM loads below in the in-order vmcnt queue, so initialising the
+  // accumulators does not wait for the activation tile
+  f32x4 bt[4];
+  if (wave_active) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = ct32 * 32 + 8 * g + 4 * h;
+      bt[g] = *(const f32x4*)(p.bias + co);
+      if (p.temb) {
+        const float* tp = p.temb + (size_t)n * p.temb_stride + co;
+        if (ct32 * 32 + 32 <= p.Cout) {          // wave-uniform: all 32 channels real
+          bt[g] += *(const f32x4*)tp;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (co + i < p.Cout) bt[g][i] += tp[i];
+        }
+      }
+    }
+  }
+  if (!p.im2col3) issue_loads(0);      // everything below overlaps the HBM latency of chunk 0
+  PD_STAMP(8);
   // accumulators start at bias[co] + temb[n][co] (lane (pixel, h), register i <-> co = 8(i>>2) + 4h + (i&3)):
   // the epilogue then has no per-channel loads at all
   {
     f32x16 init = (f32x16)(0.f);
     if (wave_active) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = ct32 * 32 + 8 * g + 4 * h;
-        f32x4 bb = *(const f32x4*)(p.bias + co);
-        if (p.temb) {
-          const float* tp = p.temb + (size_t)n * p.temb_stride + co;
-          if (ct32 * 32 + 32 <= p.Cout) {          // wave-uniform: all 32 channels real
-            const f32x4 tv = *(const f32x4*)tp;
-            bb += tv;
-          } else {
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (co + i < p.Cout) bb[i] += tp[i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) init[4 * g + i] = bb[i];
-      }
+        for (int i = 0; i < 4; ++i) init[4 * g + i] = bt[g][i];
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = init;
   }
-
   if (wave_active) {
 #pragma unroll
     for (int i = 0; i < AD; ++i) aring[i] = E::load(wbase + (size_t)PD_WIDX(min(i, last_kstep)) * 512);
   }
+  PD_STAMP(9);
   if (DB) {
     if (p.im2col3) {
       stage_im2col(lds);
     } else {
+      write_piece(0, lds);
+      PD_STAMP(10);
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) write_piece(i, lds);
+      for (int i = 1; i < NIT; ++i) write_piece(i, lds);
     }
     if (p.nchunks > 1) issue_loads(1);
     PD_STAMP(1);
@@ -501,10 +518,10 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   ConvP q = p;
   q.tiles_x = (p.Wout + TW - 1) / TW;
   q.tiles_y = (p.Hout + TH - 1) / TH;
-  q.n_pix_tiles = p.B * q.tiles_x * q.tiles_y;
+  q.tiles_x_shift = -1;
+  for (int sft = 0; sft < 16; ++sft) if ((1 << sft) == q.tiles_x) q.tiles_x_shift = sft;
   q.n_co_tiles = (p.Cout_pad + 63) / 64;
-  const int grid = ((q.n_pix_tiles + 7) / 8) * 8 * q.n_co_tiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, st, q);
+  hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.n_co_tiles, p.B), dim3(256), LDS_BYTES, st, q);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

@@ -9,14 +9,18 @@ torch.cuda.synchronize()
 lib = L.lib()
 for nb in (27200, 54400, 65536, 81920):
     lib.pd_debug_conv_occupancy(nb)
-buf = (C.c_ulonglong * (4096 * 8))()
+buf = (C.c_ulonglong * (4096 * 16))()
 rc = lib.pd_debug_read_conv_stamps(buf, C.c_size_t(C.sizeof(buf)))
 assert rc == 0, rc
-a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16).astype(np.int64)
 a = a[a[:, 6] > 0]
 d = np.diff(a[:, :7], axis=1)
 names = ["setup+load0+write0", "barrier0", "chunk0 mma(+write1)", "barrier1", "rest chunks", "epilogue"]
 print("workgroups:", len(a), " s_memtime ticks per WG: median", np.median(a[:, 6] - a[:, 0]), " span of all:", a[:, 6].max() - a[:, 0].min())
+pro = [("index setup", 0, 7), ("issue loads(0)", 7, 8), ("acc init + weight ring", 8, 9), ("wait loads + piece 0", 9, 10), ("pieces 1..5 + issue loads(1)", 10, 1)]
+for n, i0, i1 in pro:
+    dd = a[:, i1] - a[:, i0]
+    print(f"    prologue/{n:30s} median {np.median(dd):9.0f}  p90 {np.percentile(dd, 90):9.0f}")
 for i, n in enumerate(names):
     print(f"  {n:22s} median {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
 # effective concurrency per XCD group (blocks b and b+8 share an XCD; s_memtime is per-XCD)
