@@ -35,11 +35,21 @@ template <> struct AttnOps<bf16_t> {
     return t;
   }
   // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
-  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q, const f32x16& c) {
+  static constexpr int KROW = 16;                 // bytes per K row in LDS
+  static constexpr int KSTEP = 32 * KROW;         // bytes between consecutive 32-key sub-tiles
+  // lane's K-fragment address for sub-tile 0: h == 0 -> row r; h == 1 -> the shared all-zero slot after the tile
+  // (k-slots 8..15 of the 32x32x16 MFMA are unused at head_dim 8); kstep = 0 keeps h == 1 lanes on that slot
+  static __device__ __forceinline__ int kaddr(int r, int h) { return h ? KT * KROW : r * KROW; }
+  static __device__ __forceinline__ int kstep(int h) { return h ? 0 : KSTEP; }
+  static __device__ __forceinline__ f32x16 qk(const unsigned char* ka, const QF& q, const f32x16& c) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 a = *(const s16x8*)(klds + key * 32 + h * 16);   // h == 1 reads the zero half of the row
+    const s16x8 a = *(const s16x8*)ka;
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, q.v), c, 0, 0, 0);
   }
+  // V^T row position of key t: within each 16-key block the middle two groups of 4 are swapped, so the 8 keys one lane
+  // feeds to a PV k-step (16s + 4h + {0..3}, 16s + 8 + 4h + {0..3}) are 16 contiguous bytes -> one ds_read_b128
+  static __device__ __forceinline__ int vpos(int t) { return t ^ ((((t >> 2) ^ (t >> 3)) & 1) * 12); }
+  static __device__ __forceinline__ int vlane_off(int h) { return h * 16; }
   // O^T += A . P^T for the 32 keys starting at key0; p = exponentiated tile (fp32 accumulator layout)
   static __device__ __forceinline__ f32x16 pv(const unsigned char* vrow, int key0, const f32x16& p, f32x16 o) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -52,9 +62,7 @@ template <> struct AttnOps<bf16_t> {
       for (int j = 0; j < 4; ++j) bw[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       u32x4 bv = {bw[0], bw[1], bw[2], bw[3]};
-      uint2 a0 = *(const uint2*)(row + (16 * s) * 2);
-      uint2 a1 = *(const uint2*)(row + (16 * s + 8) * 2);
-      u32x4 av = {a0.x, a0.y, a1.x, a1.y};
+      const u32x4 av = *(const u32x4*)(row + (16 * s) * 2);
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), o, 0, 0, 0);
     }
     return o;
@@ -72,8 +80,14 @@ template <> struct AttnOps<float> {
   static __device__ __forceinline__ float q_norm2(const QF& q) {
     return q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3];
   }
-  static __device__ __forceinline__ f32x16 qk(const unsigned char* klds, int key, int h, const QF& q, f32x16 c) {
-    const f32x4 a = *(const f32x4*)(klds + key * 32 + h * 16);   // d = 4h + i
+  static constexpr int KROW = 32;
+  static constexpr int KSTEP = 32 * KROW;
+  static __device__ __forceinline__ int kaddr(int r, int h) { return r * KROW + h * 16; }   // d = 4h + i
+  static __device__ __forceinline__ int kstep(int) { return KSTEP; }
+  static __device__ __forceinline__ int vpos(int t) { return t; }
+  static __device__ __forceinline__ int vlane_off(int h) { return h * 16; }
+  static __device__ __forceinline__ f32x16 qk(const unsigned char* ka, const QF& q, f32x16 c) {
+    const f32x4 a = *(const f32x4*)ka;
 #pragma unroll
     for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], q.v[i], c, 0, 0, 0);
     return c;
@@ -94,10 +108,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   using E = Elem<T>;
   using Ops = AttnOps<T>;
-  constexpr int KROW = 32;                           // bytes per K row: fp32 8 x 4 B; bf16 8 x 2 B + 16 zero bytes (the
-                                                     // unused k-slots 8..15 of the 32x32x16 MFMA, read by lanes h == 1)
+  constexpr int KROW = Ops::KROW;
   constexpr int VBYTES = 9 * Ops::VT_PITCH;          // rows 0..7 = V^T, row 8 = 1.0
-  __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW + 16];   // + one all-zero 16-B slot
   __shared__ __attribute__((aligned(16))) unsigned char vlds[2][VBYTES];
   __shared__ float knmax[2][KT / 32];                // max |k| over each 32-key sub-tile (Cauchy-Schwarz score bound)
 
@@ -119,10 +132,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   // constant LDS content, written once: zero half of the bf16 K rows, all-ones row 8 of V^T (A rows 8..15 -> l)
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
-    if (E::BYTES == 2) *(f32x4*)(klds[b2] + tid * KROW + 16) = (f32x4)(0.f);
+    if (tid == 0) *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f);
     *(T*)(vlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(1.0f);
   }
-  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + 4 * h * E::BYTES;
+  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
+  const int ka0 = Ops::kaddr(r, h), kst = Ops::kstep(h);
 
   f32x16 o = (f32x16)(0.f);
   // Deferred-rescale online softmax.  `m` is the reference maximum (log2 domain) shared by both lane halves of a
@@ -160,8 +174,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
     if ((tid & 31) == 0) knmax[b2][tid >> 5] = sqrtf(n2) * 1.00001f;
     float v[8];
     E::unpack(stv, v);
+    const int vp_ = Ops::vpos(tid);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) *(T*)(vlds[b2] + d * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(v[d]);
+    for (int d = 0; d < 8; ++d) *(T*)(vlds[b2] + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(v[d]);
   };
 
   issue(0);
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
     if (full_tile && !__builtin_amdgcn_ballot_w64(first || qn * kn8 - m > RESCALE_THR)) {
 #pragma unroll
       for (int sub = 0; sub < KT / 32; ++sub) {
-        f32x16 s = Ops::qk(kl, sub * 32 + r, h, qf, negm);
+        f32x16 s = Ops::qk(kl + ka0 + sub * kst, qf, negm);
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
         o = Ops::pv(vrow, sub * 32, s, o);
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
       for (int sub = 0; sub < KT / 32; ++sub) {
         const int kb = sub * 32;
         if (k0 + kb >= N) break;
-        f32x16 s = Ops::qk(kl, kb + r, h, qf, negm);
+        f32x16 s = Ops::qk(kl + ka0 + sub * kst, qf, negm);
         // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
         if (k0 + kb + 32 > N) {
 #pragma unroll
