@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--model", default="super_small")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many concurrently replayed "
+                    "trajectories (separate HIP streams): MFMA-bound convs of one overlap VALU-bound attention of another")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -148,10 +150,22 @@ def main():
     unet = P.CustomCondUNet2DModel(compute_dtype=args.dtype, **dict(P.UNET_CONFIGS[args.model], sample_size=size))
     state_dict = {k: v.clone() for k, v in unet.state_dict().items()}
     pipe = P.ConditionalDDIMPipeline(unet.to(dev), P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
-    runner = P.DDIBGraph(pipe, batch_size=B, num_inference_steps=S, use_graph=not args.no_graph)
+    assert B % args.streams == 0
+    Bs = B // args.streams
+    # each concurrent trajectory owns its activation buffers (private_plan)
+    runners = [P.DDIBGraph(pipe, batch_size=Bs, num_inference_steps=S, use_graph=not args.no_graph, private_plan=i > 0)
+               for i in range(args.streams)]
+    runner = runners[0]
     x, labels = synth_batch(B, size, 1234 + rank)
     x, labels = x.to(dev), labels.to(dev)
     target = P.swap_binary_labels(labels)
+
+    class _Multi:
+        def run(self, x, labels, target):
+            for i, r_ in enumerate(runners):
+                sl = slice(i * Bs, (i + 1) * Bs)
+                r_.run(x[sl], labels[sl], target[sl])
+    multi = _Multi()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -160,11 +174,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        runner.run(x, labels, target)
+        multi.run(x, labels, target)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner.run(x, labels, target)
+        multi.run(x, labels, target)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -183,7 +197,7 @@ def main():
                                f"{S}+{S} DDIM steps, {args.model} UNet (random init, seed 0), 3k_steps_clipping_rescaling, "
                                f"{B} images/GPU/step sharded over {world} GPU(s), no collectives",
                    "batch_per_gpu": B, "global_batch": B * world, "inference_steps": S, "image_size": size,
-                   "hipgraph": not args.no_graph},
+                   "hipgraph": not args.no_graph, "concurrent_trajectories": args.streams},
     }
     # whole-step roofline numbers the north_star asks for (per GPU): algorithmic activation bytes / flops per image
     per_gpu = value / world

@@ -14,6 +14,7 @@ namespace pd {
 
 constexpr int KT = 256;   // keys per LDS tile (double-buffered: one barrier per tile)
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct AttnOps;
 
 template <> struct AttnOps<bf16_t> {
@@ -41,29 +42,34 @@ template <> struct AttnOps<bf16_t> {
   // (k-slots 8..15 of the 32x32x16 MFMA are unused at head_dim 8); kstep = 0 keeps h == 1 lanes on that slot
   static __device__ __forceinline__ int kaddr(int r, int h) { return h ? KT * KROW : r * KROW; }
   static __device__ __forceinline__ int kstep(int h) { return h ? 0 : KSTEP; }
-  static __device__ __forceinline__ f32x16 qk(const unsigned char* ka, const QF& q, const f32x16& c) {
+  struct KF { s16x8 v; };
+  struct VF { u32x4 v[2]; };
+  static __device__ __forceinline__ KF load_k(const unsigned char* ka) { KF f; f.v = *(const s16x8*)ka; return f; }
+  static __device__ __forceinline__ f32x16 qk(const KF& a, const QF& q, const f32x16& c) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 a = *(const s16x8*)ka;
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, q.v), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, q.v), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ VF load_v(const unsigned char* vrow, int key0) {
+    VF f;
+    f.v[0] = *(const u32x4*)(vrow + key0 * 2);
+    f.v[1] = *(const u32x4*)(vrow + (key0 + 16) * 2);
+    return f;
   }
   // V^T row position of key t: within each 16-key block the middle two groups of 4 are swapped, so the 8 keys one lane
   // feeds to a PV k-step (16s + 4h + {0..3}, 16s + 8 + 4h + {0..3}) are 16 contiguous bytes -> one ds_read_b128
   static __device__ __forceinline__ int vpos(int t) { return t ^ ((((t >> 2) ^ (t >> 3)) & 1) * 12); }
   static __device__ __forceinline__ int vlane_off(int h) { return h * 16; }
-  // O^T += A . P^T for the 32 keys starting at key0; p = exponentiated tile (fp32 accumulator layout)
-  static __device__ __forceinline__ f32x16 pv(const unsigned char* vrow, int key0, const f32x16& p, f32x16 o) {
+  // O^T += A . P^T for one 32-key sub-tile; p = exponentiated tile (fp32 accumulator layout)
+  static __device__ __forceinline__ f32x16 pv(const VF& a, const f32x16& p, f32x16 o) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    const unsigned char* row = vrow + key0 * 2;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // B fragment: element j <-> key 16s + 8(j>>2) + 4h + (j&3) == accumulator register 8s + j
       uint32_t bw[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) bw[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       u32x4 bv = {bw[0], bw[1], bw[2], bw[3]};
-      const u32x4 av = *(const u32x4*)(row + (16 * s) * 2);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v[s]), __builtin_bit_cast(bf16x8, bv), o, 0, 0, 0);
     }
     return o;
   }
@@ -86,26 +92,33 @@ template <> struct AttnOps<float> {
   static __device__ __forceinline__ int kstep(int) { return KSTEP; }
   static __device__ __forceinline__ int vpos(int t) { return t; }
   static __device__ __forceinline__ int vlane_off(int h) { return h * 16; }
-  static __device__ __forceinline__ f32x16 qk(const unsigned char* ka, const QF& q, f32x16 c) {
-    const f32x4 a = *(const f32x4*)ka;
+  struct KF { f32x4 v; };
+  struct VF { f32x4 v[4]; };
+  static __device__ __forceinline__ KF load_k(const unsigned char* ka) { KF f; f.v = *(const f32x4*)ka; return f; }
+  static __device__ __forceinline__ f32x16 qk(const KF& a, const QF& q, f32x16 c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], q.v[i], c, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[i], q.v[i], c, 0, 0, 0);
     return c;
   }
-  static __device__ __forceinline__ f32x16 pv(const unsigned char* vrow, int key0, const f32x16& p, f32x16 o) {
-    const unsigned char* row = vrow + key0 * 4;
+  static __device__ __forceinline__ VF load_v(const unsigned char* vrow, int key0) {
+    VF f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 a = *(const f32x4*)(row + (8 * g) * 4);   // keys 8g + 4h + (0..3)  == accumulator registers 4g + (0..3)
+    for (int g = 0; g < 4; ++g) f.v[g] = *(const f32x4*)(vrow + (key0 + 8 * g) * 4);   // keys 8g + 4h + (0..3)
+    return f;
+  }
+  static __device__ __forceinline__ f32x16 pv(const VF& a, const f32x16& p, f32x16 o) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], p[4 * g + i], o, 0, 0, 0);
-    }
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[g][i], p[4 * g + i], o, 0, 0, 0);
     return o;
   }
 };
 
-template <typename T>
+template <typename T, int QB>
 __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
+  constexpr int QPW = 32 * QB;                       // queries per wave
+  constexpr int QPB = 4 * QPW;                       // queries per workgroup
   using E = Elem<T>;
   using Ops = AttnOps<T>;
   constexpr int KROW = Ops::KROW;
@@ -116,20 +129,48 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // 1-D grid with an XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so giving each XCD a
+  // contiguous range of work items keeps all query blocks of one (batch, head) -- which stream the same K / V -- on
+  // one L2 (speed only; any placement is correct)
+  const int nqb = (a.N + QPB - 1) / QPB;
+  const int total = nqb * a.heads * a.B;
+  int item = blockIdx.x;
+  if ((total & 7) == 0) item = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int qb = item % nqb;
+  const int head = (item / nqb) % a.heads, b = item / (nqb * a.heads);
   const int N = a.N;
   const size_t bh = ((size_t)b * a.heads + head) * N;
   const T* qp = (const T*)a.q + bh * 8;
   const T* kp = (const T*)a.k + bh * 8;
   const T* vp = (const T*)a.v + bh * 8;
 
-  const int query = blockIdx.x * 128 + wave * 32 + r;
-  const int qclamp = min(query, N - 1);
   // fold softmax scale 8^-1/2 and log2(e) into q: p = exp2(s' - m')
   const float qscale = 0.35355339059327373f * 1.4426950408889634f;
-  const typename Ops::QF qf = Ops::load_q(qp + (size_t)qclamp * 8, h, qscale);
+  // Deferred-rescale online softmax (per query block).  `m` is the reference maximum (log2 domain) shared by both lane
+  // halves of a query; -m rides in the C operand of the QK^T MFMA, so s' = S - m leaves the matrix pipe ready for exp2.
+  // m is only raised when some s' exceeds RESCALE_THR (p <= 2^THR otherwise).  A tile needs the exact row max only if
+  // some score COULD exceed m + THR: s = q.k <= |q| * max|k| (Cauchy-Schwarz), checked once per 256-key tile.
+#ifdef PD_ABL_THR
+  constexpr float RESCALE_THR = 1e30f;   // ablation only: never take the exact-max path after the first tile
+#else
+  constexpr float RESCALE_THR = 16.0f;
+#endif
+  int query[QB];
+  typename Ops::QF qf[QB];
+  f32x16 o[QB], negm[QB];
+  float qn[QB], m[QB];
+  bool first[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    query[j] = qb * QPB + (wave * QB + j) * 32 + r;
+    qf[j] = Ops::load_q(qp + (size_t)min(query[j], N - 1) * 8, h, qscale);
+    float t = Ops::q_norm2(qf[j]);
+    t += __shfl_xor(t, 32);
+    qn[j] = sqrtf(t) * 1.00001f + 1e-6f;
+    o[j] = (f32x16)(0.f); negm[j] = (f32x16)(0.f); m[j] = 0.f; first[j] = true;
+  }
 
-  // constant LDS content, written once: zero half of the bf16 K rows, all-ones row 8 of V^T (A rows 8..15 -> l)
+  // constant LDS content, written once: the shared zero K slot, all-ones row 8 of V^T (A rows 8..15 -> l)
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
     if (tid == 0) *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f);
@@ -138,24 +179,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
   const int ka0 = Ops::kaddr(r, h), kst = Ops::kstep(h);
 
-  f32x16 o = (f32x16)(0.f);
-  // Deferred-rescale online softmax.  `m` is the reference maximum (log2 domain) shared by both lane halves of a
-  // query; -m rides in the C operand of the QK^T MFMA, so s' = S - m leaves the matrix pipe ready for exp2.  m is
-  // only raised when some s' exceeds RESCALE_THR (p <= 2^THR otherwise): the common path has no cross-lane traffic,
-  // no subtraction and no accumulator rescale.
-  // A tile needs the exact row max only if some score COULD exceed m + THR.  s = q.k <= |q| * max|k|, so when
-  // |q| * max|k| - m <= THR the max / ballot / branch are skipped altogether (the usual case once m has settled).
-#ifdef PD_ABL_THR
-  constexpr float RESCALE_THR = 1e30f;   // ablation only: never take the exact-max path after the first tile
-#else
-  constexpr float RESCALE_THR = 16.0f;
-#endif
-  float qn = Ops::q_norm2(qf);
-  qn += __shfl_xor(qn, 32);
-  qn = sqrtf(qn) * 1.00001f + 1e-6f;
-  float m = 0.f;
-  f32x16 negm = (f32x16)(0.f);
-  bool first = true;
   // staging: thread t owns K row t and V row t of the 256-key tile
   typename E::Frag stk, stv;
   auto issue = [&](int k0) {
@@ -192,50 +215,66 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
 #pragma unroll
     for (int i = 1; i < KT / 32; ++i) kn8 = fmaxf(kn8, knmax[cur][i]);
     const bool full_tile = k0 + KT <= N;
-    if (full_tile && !__builtin_amdgcn_ballot_w64(first || qn * kn8 - m > RESCALE_THR)) {
+    bool need = false;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) need = need || first[j] || (qn[j] * kn8 - m[j] > RESCALE_THR);
+    if (full_tile && !__builtin_amdgcn_ballot_w64(need)) {
+      // check-free body: per sub-tile one K and one V^T fragment read feed all QB query blocks
 #pragma unroll
       for (int sub = 0; sub < KT / 32; ++sub) {
-        f32x16 s = Ops::qk(kl + ka0 + sub * kst, qf, negm);
+        const typename Ops::KF kf = Ops::load_k(kl + ka0 + sub * kst);
+        const typename Ops::VF vf = Ops::load_v(vrow, sub * 32);
+        f32x16 s[QB];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
-        o = Ops::pv(vrow, sub * 32, s, o);
+        for (int j = 0; j < QB; ++j) s[j] = Ops::qk(kf, qf[j], negm[j]);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[j][i] = __builtin_amdgcn_exp2f(s[j][i]);
+          o[j] = Ops::pv(vf, s[j], o[j]);
+        }
       }
     } else {
 #pragma unroll 1
       for (int sub = 0; sub < KT / 32; ++sub) {
         const int kb = sub * 32;
         if (k0 + kb >= N) break;
-        f32x16 s = Ops::qk(kl + ka0 + sub * kst, qf, negm);
-        // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
-        if (k0 + kb + 32 > N) {
+        const typename Ops::KF kf = Ops::load_k(kl + ka0 + sub * kst);
+        const typename Ops::VF vf = Ops::load_v(vrow, kb);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = k0 + kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (key >= N) s[i] = -INFINITY;
+        for (int j = 0; j < QB; ++j) {
+          f32x16 s = Ops::qk(kf, qf[j], negm[j]);
+          // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
+          if (k0 + kb + 32 > N) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int key = k0 + kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+              if (key >= N) s[i] = -INFINITY;
+            }
           }
-        }
-        const float bound = qn * knmax[cur][sub] - m;   // upper bound of every s' of this lane in this sub-tile
-        if (__builtin_amdgcn_ballot_w64(first || bound > RESCALE_THR)) {   // wave-uniform
-          float tmax = s[0];
+          const float bound = qn[j] * knmax[cur][sub] - m[j];   // upper bound of every s' of this lane in this sub-tile
+          if (__builtin_amdgcn_ballot_w64(first[j] || bound > RESCALE_THR)) {   // wave-uniform
+            float tmax = s[0];
 #pragma unroll
-          for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-          if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR)) {
-            const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));           // finite: the first tile holds key 0
-            const float delta = first ? t2 : fmaxf(t2, 0.f);
-            const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-            // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
+            for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+            if (__builtin_amdgcn_ballot_w64(first[j] || tmax > RESCALE_THR)) {
+              const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));           // finite: the first tile holds key 0
+              const float delta = first[j] ? t2 : fmaxf(t2, 0.f);
+              const float sc = first[j] ? 1.f : __builtin_amdgcn_exp2f(-delta);
+              // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] *= sc;
+              for (int i = 0; i < 8; ++i) o[j][i] *= sc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] -= delta;
-            m += delta;
-            negm = (f32x16)(-m);
-            first = false;
+              for (int i = 0; i < 16; ++i) s[i] -= delta;
+              m[j] += delta;
+              negm[j] = (f32x16)(-m[j]);
+              first[j] = false;
+            }
           }
-        }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
-        o = Ops::pv(vrow, kb, s, o);
+          for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+          o[j] = Ops::pv(vf, s, o[j]);
+        }
       }
     }
     if (k0 + KT < N) {
@@ -245,11 +284,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
     __syncthreads();
   }
 
-  if (query < N) {
-    // lane (query, h): registers 0..3 = O^T rows 4h..4h+3 (d), register 4 = row 8 + 4h = l
-    const float inv = 1.0f / o[4];
-    T* dst = (T*)a.out + ((size_t)b * N + query) * (a.heads * 8) + head * 8 + 4 * h;
-    store4(dst, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    if (query[j] < N) {
+      // lane (query, h): registers 0..3 = O^T rows 4h..4h+3 (d), register 4 = row 8 + 4h = l
+      const float inv = 1.0f / o[j][4];
+      T* dst = (T*)a.out + ((size_t)b * N + query[j]) * (a.heads * 8) + head * 8 + 4 * h;
+      store4(dst, o[j][0] * inv, o[j][1] * inv, o[j][2] * inv, o[j][3] * inv);
+    }
   }
 }
 
@@ -260,11 +302,24 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_attn_d8: null args");
   PD_CHECK(a->B > 0 && a->heads > 0 && a->N > 0, PD_ERR_SHAPE, "pd_attn_d8: bad shape");
   PD_CHECK(a->q && a->k && a->v && a->out, PD_ERR_ARG, "pd_attn_d8: null pointer");
-  PD_CHECK(a->heads <= 65535 && a->B <= 65535, PD_ERR_SHAPE, "pd_attn_d8: grid too large");
-  dim3 grid((a->N + 127) / 128, a->heads, a->B);
-  if (a->dtype == PD_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
+  // Query blocks per wave.  QB = 2 (K / V^T fragments shared by two independent chains, 2 waves/SIMD) measured 3 % slower
+  // than QB = 1 (4 waves/SIMD) at N = 4096: the tile time is pinned by the exp + MFMA issue mix (scripts/micro/), not by
+  // LDS traffic or occupancy.  Kept selectable for future shapes.
+#ifdef PD_ATTN_QB2
+  const int qbw = (a->N >= 2048) ? 2 : 1;
+#else
+  const int qbw = 1;
+#endif
+  const int qpb = 128 * qbw;
+  PD_CHECK((long long)((a->N + qpb - 1) / qpb) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8: grid too large");
+  dim3 grid(((a->N + qpb - 1) / qpb) * a->heads * a->B);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PD_F32) {
+    hipLaunchKernelGGL((attn_kernel<float, 1>), dim3(((a->N + 127) / 128) * a->heads * a->B), dim3(256), 0, st, *a);
+  } else if (a->dtype == PD_BF16) {
+    if (qbw == 2) hipLaunchKernelGGL((attn_kernel<bf16_t, 2>), grid, dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL((attn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, *a);
+  } else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

@@ -79,7 +79,7 @@ class DDIBGraph:
     and optionally the uint8 quantisation."""
 
     def __init__(self, pipe: ConditionalDDIMPipeline, batch_size: int, num_inference_steps: int, height: int = None,
-                 width: int = None, variant: str = "0.18.2", device=None, use_graph: bool = True):
+                 width: int = None, variant: str = "0.18.2", device=None, use_graph: bool = True, private_plan: bool = False):
         self.pipe = pipe
         unet = pipe.unet
         self.device = torch.device(device) if device is not None else unet.device
@@ -90,7 +90,7 @@ class DDIBGraph:
         B, S = self.B, self.S
         dev = self.device
         self.lib = L.lib()
-        self.plan = unet.plan_for(B, H, W, dev)
+        self.plan = unet.new_plan(B, H, W, dev) if private_plan else unet.plan_for(B, H, W, dev)
         cin = unet.config.in_channels
         # schedulers (host tables)
         self.inv = DDIMInverseScheduler.from_config(pipe.scheduler.config, variant=variant)

@@ -265,6 +265,12 @@ class CustomCondUNet2DModel(nn.Module):
             return (out,)
         return UNet2DOutput(sample=out)
 
+    def new_plan(self, B, H, W, device):
+        """A plan with its OWN activation buffers (for trajectories replayed concurrently on different streams)."""
+        if self._weights is None:
+            self._weights = _PackedWeights(self, device)
+        return UNetPlan(self, self._weights, B, H, W, device)
+
     def plan_for(self, B, H, W, device):
         key = (B, H, W, str(device), self.compute_dtype)
         p = self._plans.get(key)
