@@ -9,5 +9,6 @@ from ._lib import PhenDiffHipError, lib  # noqa: F401
 from .unet import CustomCondUNet2DModel, UNet2DOutput  # noqa: F401
 from .schedulers import DDIMScheduler, DDIMInverseScheduler  # noqa: F401
 from .pipeline import ConditionalDDIMPipeline, ImagePipelineOutput  # noqa: F401
-from .img2img import inversion, ddib, DDIBGraph, shard_batches, swap_binary_labels  # noqa: F401
+from .img2img import (inversion, ddib, inverted_regeneration, classifier_free_guidance_forward_start, DDIBGraph,  # noqa: F401
+                      CFGForwardStartGraph, shard_batches, swap_binary_labels)
 from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401

@@ -46,6 +46,24 @@ def ddib(pipe, clean_images, orig_class_labels, target_class_labels, num_inferen
                 output_type=output_type).images
 
 
+@torch.no_grad()
+def inverted_regeneration(pipe, clean_images, orig_class_labels, num_inference_steps: int, **kw):
+    """``"inverted_regeneration"`` (utils_Img2Img.py:374-384): DDIB with the original class as target."""
+    return ddib(pipe, clean_images, orig_class_labels, orig_class_labels, num_inference_steps, **kw)
+
+
+@torch.no_grad()
+def classifier_free_guidance_forward_start(pipe, clean_images, target_class_labels, guidance_scale: float,
+                                           frac_diffusion_skipped: float, num_inference_steps: int, generator=None,
+                                           output_type: str = "numpy"):
+    """``_classifier_free_guidance_forward_start`` (utils_Img2Img.py:615-648), ConditionalDDIMPipeline branch: noise
+    the image up to ``(1 - frac_diffusion_skipped)`` of the trajectory, then denoise under the target class with
+    classifier-free guidance."""
+    return pipe(class_labels=target_class_labels, w=guidance_scale, num_inference_steps=num_inference_steps,
+                start_image=clean_images, frac_diffusion_skipped=frac_diffusion_skipped, generator=generator,
+                output_type=output_type).images
+
+
 def swap_binary_labels(orig_class_labels: torch.Tensor) -> torch.Tensor:
     """``target = 1 - orig`` (utils_Img2Img.py:343-344): strictly binary datasets."""
     return 1 - orig_class_labels
@@ -185,6 +203,120 @@ class DDIBGraph:
                 if not hasattr(self, "_ones"):
                     self._ones = torch.ones((B,), dtype=torch.float32, device=self.device)
                     self._zeros = torch.zeros((B,), dtype=torch.float32, device=self.device)
+                self._enqueue(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return self
+
+    def __del__(self):
+        try:
+            if self.graph:
+                self.lib.pd_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+class CFGForwardStartGraph:
+    """hipGraph form of the CFG forward-start transfer (utils_Img2Img.py:615-648 +
+    pipeline_conditionial_ddim.py:248-347): ``add_noise`` to the first kept timestep, then per step a conditional
+    and an unconditional UNet evaluation (``class_emb = 0``, pipeline :310-317) feeding ONE fused
+    guidance-combine + DDIM update; post-processing; all captured once and replayed per batch.
+
+    ``run(clean_images, target_labels, noise)``: the forward noise is an input (the reference draws it from the
+    caller's generator, ``randn_tensor``), so results are reproducible against the eager pipeline / the oracle."""
+
+    def __init__(self, pipe: ConditionalDDIMPipeline, batch_size: int, num_inference_steps: int, guidance_scale: float = 2.5,
+                 frac_diffusion_skipped: float = 0.5, guidance_eqn: str = "imagen", height: int = None, width: int = None,
+                 device=None, use_graph: bool = True):
+        if guidance_eqn not in ("imagen", "CFG"):
+            raise ValueError(f"Unknown guidance equation '{guidance_eqn}'; should be 'imagen' or 'CFG'")
+        unet = pipe.unet
+        self.device = dev = torch.device(device) if device is not None else unet.device
+        ss = unet.config.sample_size
+        H = height or (ss if isinstance(ss, int) else ss[0])
+        W = width or (ss if isinstance(ss, int) else ss[1])
+        self.B, self.S = B, S = batch_size, num_inference_steps
+        self.lib = L.lib()
+        self.plan = unet.plan_for(B, H, W, dev)
+        cin = unet.config.in_channels
+        sch = pipe.scheduler
+        sch.set_timesteps(S)
+        init_t = sch.config.num_train_timesteps * (1 - frac_diffusion_skipped)   # pipeline :252-258
+        self.ts = [int(t) for t in sch.timesteps[sch.timesteps <= init_t]]
+        n = len(self.ts)
+        w = guidance_scale
+        self.do_cfg = (guidance_eqn == "imagen" and w > 1) or (guidance_eqn == "CFG" and w > 0)   # :272-284
+        self.x = torch.empty((B, cin, H, W), dtype=torch.float32, device=dev)
+        self.clean = torch.empty_like(self.x)
+        self.noise = torch.empty_like(self.x)
+        self.cond_out = torch.empty_like(self.x)
+        self.uncond_out = torch.empty_like(self.x)
+        self.images = torch.empty((B, H, W, cin), dtype=torch.float32, device=dev)
+        self.images_u8 = torch.empty((B, H, W, cin), dtype=torch.uint8, device=dev)
+        self.ts_rows = torch.tensor(self.ts, dtype=torch.float32).repeat_interleave(B).to(dev)
+        self.label_rows = torch.empty((n * B,), dtype=torch.int64, device=dev)
+        self.zero_emb = torch.zeros((n * B, unet.time_embed_dim), dtype=torch.float32, device=dev)
+        pd = self.plan.w.proj_dim
+        self.temb_c = torch.empty((n * B, pd), dtype=torch.float32, device=dev)
+        self.temb_u = torch.empty((n * B, pd), dtype=torch.float32, device=dev)
+        self.w_dev = torch.tensor([float(w)], dtype=torch.float32, device=dev)
+        sa, sb = sch._per_sample_coefs(torch.tensor([self.ts[0]] * B), dev)
+        self._sa, self._sb = sa, sb
+        self.noise_args = L.AddNoiseArgs(numel=self.x.numel(), per_sample=self.x[0].numel(), velocity=0,
+                                         x=self.clean.data_ptr(), noise=self.noise.data_ptr(), sa=sa.data_ptr(),
+                                         sb=sb.data_ptr(), out=self.x.data_ptr())
+        c = sch.config
+        self.step_args = []
+        for t in self.ts:
+            sa_, sb_, sap, dirc, _ = sch.step_coefficients(t, 0.0)
+            self.step_args.append(L.DdimStepArgs(
+                numel=self.x.numel(), per_sample=self.x[0].numel(), pred_type=L.PD_PRED[c.prediction_type],
+                clip=int(bool(c.clip_sample)), clip_range=float(c.clip_sample_range), use_clipped_model_output=0,
+                sqrt_a=sa_, sqrt_b=sb_, sqrt_ap=sap, dir_coef=dirc, sample=self.x.data_ptr(), model_out=self.cond_out.data_ptr(),
+                uncond_out=(self.uncond_out.data_ptr() if self.do_cfg else None), w=self.w_dev.data_ptr(), w_per_sample=0,
+                guidance_cfg=int(guidance_eqn == "CFG"), prev_sample=self.x.data_ptr(), pred_x0=None))
+        self.post_args = L.PostprocArgs(B=B, C=cin, H=H, W=W, x=self.x.data_ptr(), out_f32=self.images.data_ptr(),
+                                        out_u8=self.images_u8.data_ptr())
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph = C.c_void_p(None)
+        self.use_graph = use_graph
+        if use_graph:
+            torch.cuda.synchronize(dev)
+            st = self.stream.cuda_stream
+            L.check(self.lib.pd_graph_begin(st), "pd_graph_begin")
+            try:
+                self._enqueue(st)
+            finally:
+                rc = self.lib.pd_graph_end(st, C.byref(self.graph))
+            L.check(rc, "pd_graph_end")
+
+    def _enqueue(self, st):
+        lib, plan, B = self.lib, self.plan, self.B
+        rows = self.ts_rows.numel()
+        plan.temb_rows(self.ts_rows, self.label_rows, None, st, rows=rows, out=self.temb_c)
+        if self.do_cfg:
+            plan.temb_rows(self.ts_rows, None, self.zero_emb, st, rows=rows, out=self.temb_u)
+        L.check(lib.pd_add_noise(C.byref(self.noise_args), st), "pd_add_noise")
+        row_bytes = plan.w.proj_dim * 4
+        for i, a in enumerate(self.step_args):
+            plan.run(self.x.data_ptr(), self.temb_c.data_ptr() + i * B * row_bytes, self.cond_out.data_ptr(), st)
+            if self.do_cfg:
+                plan.run(self.x.data_ptr(), self.temb_u.data_ptr() + i * B * row_bytes, self.uncond_out.data_ptr(), st)
+            L.check(lib.pd_ddim_step(C.byref(a), st), "pd_ddim_step")
+        L.check(lib.pd_postproc(C.byref(self.post_args), st), "pd_postproc")
+
+    @torch.no_grad()
+    def run(self, clean_images: torch.Tensor, target_class_labels: torch.Tensor, noise: torch.Tensor):
+        n, B = len(self.ts), self.B
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.clean.copy_(clean_images, non_blocking=True)
+            self.noise.copy_(noise, non_blocking=True)
+            t = target_class_labels.to(device=self.device, dtype=torch.int64)
+            self.label_rows.view(n, B).copy_(t.view(1, B).expand(n, B))
+            if self.use_graph:
+                L.check(self.lib.pd_graph_launch(self.graph, self.stream.cuda_stream), "pd_graph_launch")
+            else:
                 self._enqueue(self.stream.cuda_stream)
         cur.wait_stream(self.stream)
         return self

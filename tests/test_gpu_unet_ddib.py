@@ -183,3 +183,43 @@ def test_roundtrip_property_full_size():
         ref = sap * x0 + dirc * (sb * ref)
     assert torch.allclose(out.inverted.cpu(), ref, atol=1e-5)
     assert torch.isfinite(out.images).all() and float(out.images.min()) >= 0 and float(out.images.max()) <= 1
+
+
+@pytest.mark.parametrize("eqn,w", [("imagen", 2.5), ("CFG", 1.5)])
+def test_cfg_forward_start_eager_and_graph_vs_oracle(eqn, w):
+    """classifier_free_guidance_forward_start (utils_Img2Img.py:615-648; guidance_scale 2.5,
+    frac_diffusion_skipped 0.5 in the shipped config): eager pipeline and hipGraph form against the oracle."""
+    import phendiff_amd as P
+    pref, pgot = _pipes("f32")
+    x, labels = synth_batch(4, 32)
+    target = 1 - labels
+    S, frac = 6, 0.5
+    ref = pref(class_labels=target, w=w, num_inference_steps=S, start_image=x, frac_diffusion_skipped=frac,
+               guidance_eqn=eqn, generator=torch.Generator().manual_seed(7)).images
+    if eqn == "imagen":
+        eager = P.classifier_free_guidance_forward_start(pgot, x.cuda(), target.cuda(), w, frac, S,
+                                                         generator=torch.Generator().manual_seed(7))
+        assert rel(eager, ref) < 2e-4
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(7))   # the draw the pipeline makes
+    g = P.CFGForwardStartGraph(pgot, batch_size=4, num_inference_steps=S, guidance_scale=w, frac_diffusion_skipped=frac,
+                               guidance_eqn=eqn)
+    assert g.ts == [t for t in pgot.scheduler.timesteps.tolist() if t <= 1500] and len(g.ts) == 3
+    out = g.run(x.cuda(), target.cuda(), noise.cuda())
+    torch.cuda.synchronize()
+    assert rel(out.images, ref) < 2e-4
+    out2 = g.run(x.cuda(), labels.cuda(), noise.cuda())      # replay with other labels
+    torch.cuda.synchronize()
+    ref2 = pref(class_labels=labels, w=w, num_inference_steps=S, start_image=x, frac_diffusion_skipped=frac,
+                guidance_eqn=eqn, generator=torch.Generator().manual_seed(7)).images
+    assert rel(out2.images, ref2) < 2e-4
+
+
+def test_inverted_regeneration_reconstructs():
+    """"inverted_regeneration" (utils_Img2Img.py:374-384) = DDIB with target = original class; more steps reconstruct
+    the input at least as well (trend of saved_figures/reco_err_*.png), checked on the engine itself."""
+    import phendiff_amd as P
+    _, pgot = _pipes("f32")
+    x, labels = synth_batch(2, 32)
+    want = (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    errs = [float(np.abs(P.inverted_regeneration(pgot, x.cuda(), labels.cuda(), S) - want).mean()) for S in (2, 10)]
+    assert errs[1] <= errs[0] * 1.05
