@@ -139,6 +139,11 @@ typedef struct {
   void* y;
   float* stats_out;         /* NULL, or [B][pd_conv_stat_tiles()][Cout][2]: per-tile per-channel (sum, sum of squares) of the
                                stored output -- the GroupNorm statistics of the CONSUMER, produced for free here */
+  /* Fused 1x1 "tail" (ResnetBlock2D.conv_shortcut folded into conv2): y += Wt . [tail_x0 | tail_x1] on the same pixels
+     (no GroupNorm / SiLU on the tail).  3x3 stride-1 convs only; the tail's weight fragments follow the main ones in
+     w_packed: per 32-co tile [main: (C0+C1)/32 * 9 * 2 fragments][tail: (tail_C0+tail_C1)/32 * 2 fragments]; `bias` is
+     the sum of both biases.  tail_x0 = NULL: no tail. */
+  const void* tail_x0; const void* tail_x1; int tail_C0, tail_C1;
   int im2col3;              /* 0, or n <= 3: x0 is an NCHW fp32 tensor with n channels (the UNet input sample) and the op is
                                the 3x3 pad-1 conv_in run as a 1x1 conv over 32 virtual channels k = ci*9 + ky*3 + kx
                                (ksize must be 1, C0 = 32, weights packed accordingly) */

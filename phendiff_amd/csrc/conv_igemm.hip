@@ -33,6 +33,11 @@ struct ConvP {
   const void* residual;
   void* y;
   float* stats;        // [B][tiles][Cout][2] per-tile channel (sum, sumsq) of the stored output, or null
+  // fused 1x1 "tail": extra K chunks over [t0 | t1] (centre tap only, no GroupNorm transform) appended after the main
+  // chunks -- ResnetBlock2D.conv_shortcut folded into conv2
+  int n_main, n_tail, Ct0, Ct1;
+  unsigned tbytes0, tbytes1;
+  const void* t0; const void* t1;
   int im2col3;         // source is NCHW fp32 with C0r <= 3..4 real channels: 3x3 taps gathered into 32 virtual channels
   int C0r;
 };
@@ -107,8 +112,9 @@ template <> struct Stage<float> {
   }
 };
 
-template <typename T, int KS, int STRIDE, int TH, int TW, bool DB>
+template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
+  static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using SR = typename Stage<T>::R;
@@ -148,6 +154,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0, 0, p.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1 ? p.x1 : p.x0), 0, p.bytes1, 0x00020000);
 
+  const __amdgpu_buffer_rsrc_t rt0 = __builtin_amdgcn_make_buffer_rsrc((void*)(TAIL ? p.t0 : p.x0), 0, TAIL ? p.tbytes0 : p.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rt1 = __builtin_amdgcn_make_buffer_rsrc((void*)((TAIL && p.t1) ? p.t1 : p.x0), 0, (TAIL && p.t1) ? p.tbytes1 : p.bytes0, 0x00020000);
+
   // ---- staging bookkeeping: this thread's pieces (pixel, 8-channel sub-block)
   const int sub = tid & 3;
   const int Hc = p.upsample ? p.Hin * 2 : p.Hin;
@@ -175,17 +184,21 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   float sc[8], sh[8];
   unsigned soff[NIT];     // byte offset of (pixel, sub-block) in the CURRENT source; OOB_OFF for padding
   int soff_src = -1;
+  bool stage_plain = false;   // the staged chunk is a tail chunk: no affine / SiLU
   auto issue_loads = [&](int chunk) {
-    const int cch = chunk * 32;
-    const bool s0 = cch < p.C0;
-    if (soff_src != (s0 ? 0 : 1)) {      // (re)computed once per source: at most twice per tile
-      soff_src = s0 ? 0 : 1;
-      const unsigned cs = s0 ? p.C0 : p.C1;
+    // source of this chunk: 0/1 = main [x0 | x1], 2/3 = tail [t0 | t1]
+    int src, cch;
+    if (!TAIL || chunk < p.n_main) { cch = chunk * 32; src = cch < p.C0 ? 0 : 1; if (src == 1) cch -= p.C0; }
+    else { cch = (chunk - p.n_main) * 32; src = cch < p.Ct0 ? 2 : 3; if (src == 3) cch -= p.Ct0; }
+    stage_plain = TAIL && src >= 2;
+    if (soff_src != src) {      // (re)computed once per source
+      soff_src = src;
+      const unsigned cs = src == 0 ? p.C0 : (src == 1 ? p.C1 : (src == 2 ? p.Ct0 : p.Ct1));
 #pragma unroll
       for (int i = 0; i < NIT; ++i)
         soff[i] = spix[i] >= 0 ? ((unsigned)spix[i] * cs + sub * 8) * E::BYTES : OOB_OFF;
     }
-    const unsigned cbytes = (unsigned)(s0 ? cch : cch - p.C0) * E::BYTES;
+    const unsigned cbytes = (unsigned)cch * E::BYTES;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
 #ifdef PD_ABL_X0
@@ -193,11 +206,13 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
 #else
       const unsigned off = soff[i] + (spix[i] >= 0 ? cbytes : 0u);
 #endif
-      stage[i] = s0 ? Stage<T>::load(rs0, off) : Stage<T>::load(rs1, off);
+      stage[i] = src == 0 ? Stage<T>::load(rs0, off) : (src == 1 ? Stage<T>::load(rs1, off)
+                 : (src == 2 ? Stage<T>::load(rt0, off) : Stage<T>::load(rt1, off)));
     }
-    if (affine) {
-      const float* ps = p.scale + (size_t)n * cin + cch + sub * 8;
-      const float* pb = p.shift + (size_t)n * cin + cch + sub * 8;
+    if (affine && !stage_plain) {
+      const int cg = chunk * 32 + sub * 8;          // channel index in the concatenated main input
+      const float* ps = p.scale + (size_t)n * cin + cg;
+      const float* pb = p.shift + (size_t)n * cin + cg;
       const f32x4 a0 = *(const f32x4*)ps, a1 = *((const f32x4*)ps + 1);
       const f32x4 b0 = *(const f32x4*)pb, b1 = *((const f32x4*)pb + 1);
 #pragma unroll
@@ -206,7 +221,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   };
   auto write_piece = [&](int i, unsigned char* buf) {
     const int pix = (tid + 256 * i) >> 2;
-    if (pix < NPIX) Stage<T>::xform_store(buf + pix * PITCH + sub * 8 * E::BYTES, stage[i], sc, sh, affine, do_silu, spix[i] >= 0);
+    if (pix < NPIX)
+      Stage<T>::xform_store(buf + pix * PITCH + sub * 8 * E::BYTES, stage[i], sc, sh, affine && !stage_plain,
+                            do_silu && !stage_plain, spix[i] >= 0);
   };
 
   // conv_in (cond_unet_2d.py:127-129): the 3x3 conv over <= 3 fp32 NCHW channels is run as a 1x1 conv over 32 virtual
@@ -251,7 +268,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   }
 
   f32x16 acc[NF];
-  const T* wbase = (const T*)p.w + (size_t)ct32 * p.nchunks * (KSTEPS * 512) + lane * 8;
+  const int main_ksteps = (TAIL ? p.n_main : p.nchunks) * KSTEPS;
+  const int all_ksteps = main_ksteps + (TAIL ? p.n_tail * 2 : 0);
+  const T* wbase = (const T*)p.w + (size_t)ct32 * all_ksteps * 512 + lane * 8;
 
   // Weight (A) fragments live in a register ring of AR entries, prefetched AD k-steps ahead and CONTINUOUSLY across
   // chunk boundaries (a chunk's fragments are contiguous with the next chunk's), so L2 latency (~600-800 cycles under
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   constexpr int AR = (KSTEPS % 3 == 0) ? 3 : 2;
   constexpr int AD = AR - 1;
   Frag aring[AR];
-  const int last_kstep = p.nchunks * KSTEPS - 1;
+  const int last_kstep = all_ksteps - 1;
 
   // one chunk of MFMAs out of `buf`; when DB, pieces of the NEXT chunk are transformed + written to `nbuf` in between
   auto mma_chunk = [&](int chunk, const unsigned char* buf, unsigned char* nbuf, auto have_next_c, auto active_c) {
@@ -299,6 +318,29 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
           if (i >= piece && i < due) write_piece(i, nbuf);
         piece = due;
       }
+    }
+  };
+  // tail chunk (fused 1x1 shortcut): 2 k-steps at the centre tap; its two weight fragments are loaded up front
+  auto mma_tail = [&](int chunk, const unsigned char* buf, unsigned char* nbuf, auto have_next_c, auto active_c) {
+    constexpr bool HAVE_NEXT = decltype(have_next_c)::value;
+    constexpr bool ACTIVE = decltype(active_c)::value;
+    constexpr int CENTER = ((KS / 2) * IN_TW + (KS / 2)) * PITCH;
+    if constexpr (ACTIVE) {
+      const T* wt = wbase + (size_t)(main_ksteps + (chunk - p.n_main) * 2) * 512;
+      const Frag a0 = E::load(wt), a1 = E::load(wt + 512);
+      Frag b0[NF], b1[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) { b0[f] = E::load(buf + rbase[f] + CENTER); b1[f] = E::load(buf + rbase[f] + CENTER + 16 * E::BYTES); }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = E::mma(a0, b0[f], acc[f]);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = E::mma(a1, b1[f], acc[f]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (HAVE_NEXT) {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) write_piece(i, nbuf);
     }
   };
   // chunk driver: the last chunk is peeled (HAVE_NEXT = false) so the accumulators flow through two call sites
@@ -359,7 +401,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
     __syncthreads();
     PD_STAMP(2);
     int chunk = 0;
-    for (; chunk + 1 < p.nchunks; ++chunk) {
+    const int main_loop_end = TAIL ? p.n_main : p.nchunks - 1;   // with a tail every main chunk has a successor
+    for (; chunk < main_loop_end; ++chunk) {
       unsigned char* buf = lds + (chunk & 1) * LDS_TILE;
       unsigned char* nbuf = lds + ((chunk + 1) & 1) * LDS_TILE;
       if (wave_active) mma_chunk(chunk, buf, nbuf, true_type{}, true_type{});
@@ -369,7 +412,19 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
       __syncthreads();
       if (chunk == 0) PD_STAMP(4);
     }
-    if (wave_active) mma_chunk(chunk, lds + (chunk & 1) * LDS_TILE, lds, false_type{}, true_type{});
+    if constexpr (TAIL) {
+      for (; chunk + 1 < p.nchunks; ++chunk) {
+        unsigned char* buf = lds + (chunk & 1) * LDS_TILE;
+        unsigned char* nbuf = lds + ((chunk + 1) & 1) * LDS_TILE;
+        if (wave_active) mma_tail(chunk, buf, nbuf, true_type{}, true_type{});
+        else mma_tail(chunk, buf, nbuf, true_type{}, false_type{});
+        if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+        __syncthreads();
+      }
+      if (wave_active) mma_tail(chunk, lds + (chunk & 1) * LDS_TILE, lds, false_type{}, true_type{});
+    } else {
+      if (wave_active) mma_chunk(chunk, lds + (chunk & 1) * LDS_TILE, lds, false_type{}, true_type{});
+    }
     __syncthreads();
     PD_STAMP(5);
   } else {
@@ -498,7 +553,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   PD_STAMP(6);
 }
 
-template <typename T, int KS, int STRIDE, int TH, int TW>
+template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int IN_TH = (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
@@ -508,7 +563,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int LDS_MAIN = DB ? 2 * LDS_TILE : LDS_TILE;
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
-  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB>;
+  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL>;
   if (LDS_BYTES > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -549,6 +604,11 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
     if (w >= 16) return launch_conv<T, 3, 1, 8, 16>(p, st);
     return launch_conv<T, 3, 1, 16, 8>(p, st);
 #else
+    if (p.n_tail > 0) {
+      if (w >= 32) return launch_conv<T, 3, 1, 8, 32, true>(p, st);
+      if (w >= 16) return launch_conv<T, 3, 1, 16, 16, true>(p, st);
+      return launch_conv<T, 3, 1, 32, 8, true>(p, st);
+    }
     if (w >= 32) return launch_conv<T, 3, 1, 8, 32>(p, st);
     if (w >= 16) return launch_conv<T, 3, 1, 16, 16>(p, st);
     return launch_conv<T, 3, 1, 32, 8>(p, st);
@@ -600,6 +660,16 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
              PD_ERR_UNSUPPORTED, "pd_conv: im2col3 mode needs ksize=1, C0=32 (27 real), <= 3 source channels, no GroupNorm");
   }
   PD_CHECK(!a->stats_out || a->out_mode == PD_OUT_NHWC, PD_ERR_UNSUPPORTED, "pd_conv: stats_out needs NHWC output");
+  if (a->tail_x0) {
+    PD_CHECK(a->ksize == 3 && a->stride == 1 && !a->upsample && !a->im2col3, PD_ERR_UNSUPPORTED,
+             "pd_conv: fused 1x1 tail needs a 3x3 stride-1 conv");
+    PD_CHECK(a->tail_C0 > 0 && a->tail_C0 % 32 == 0 && a->tail_C1 >= 0 && a->tail_C1 % 32 == 0 && ((a->tail_C1 == 0) == (a->tail_x1 == nullptr)),
+             PD_ERR_SHAPE, "pd_conv: tail channels must be multiples of 32");
+    PD_CHECK((size_t)a->B * a->Hin * a->Win * (a->tail_C0 > a->tail_C1 ? a->tail_C0 : a->tail_C1) * (a->dtype == PD_F32 ? 4 : 2) < 0x80000000ull,
+             PD_ERR_SHAPE, "pd_conv: tail tensor exceeds 2 GiB");
+  } else {
+    PD_CHECK(a->tail_C0 == 0 && a->tail_C1 == 0 && a->tail_x1 == nullptr, PD_ERR_ARG, "pd_conv: tail_C without tail_x0");
+  }
   const size_t esz = a->dtype == PD_F32 ? 4 : 2;
   const size_t bytes0 = (size_t)a->B * a->Hin * a->Win * a->C0 * esz, bytes1 = (size_t)a->B * a->Hin * a->Win * a->C1 * esz;
   PD_CHECK(bytes0 < 0x80000000ull && bytes1 < 0x80000000ull, PD_ERR_SHAPE,
@@ -608,7 +678,12 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   p.B = a->B; p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout;
   p.C0 = a->C0; p.C1 = a->C1; p.Cout = a->Cout; p.Cout_pad = a->Cout_pad;
   p.pad = a->pad; p.upsample = a->upsample; p.silu = a->silu; p.out_mode = a->out_mode; p.heads = a->heads;
-  p.nchunks = (a->C0 + a->C1) / 32;
+  p.n_main = (a->C0 + a->C1) / 32;
+  p.n_tail = (a->tail_C0 + a->tail_C1) / 32;
+  p.nchunks = p.n_main + p.n_tail;
+  p.Ct0 = a->tail_C0; p.Ct1 = a->tail_C1; p.t0 = a->tail_x0; p.t1 = a->tail_x1;
+  p.tbytes0 = (unsigned)((size_t)a->B * a->Hin * a->Win * a->tail_C0 * esz);
+  p.tbytes1 = (unsigned)((size_t)a->B * a->Hin * a->Win * a->tail_C1 * esz);
   p.bytes0 = (unsigned)bytes0; p.bytes1 = (unsigned)(a->x1 ? bytes1 : bytes0);
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.w = a->w_packed; p.bias = a->bias;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.residual = a->residual; p.y = a->y;
@@ -621,7 +696,7 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
 #ifdef PD_STAMPS
 extern "C" int pd_debug_conv_occupancy(int lds_bytes) {
   int nb = -1;
-  auto kern = pd::conv_kernel<pd::bf16_t, 3, 1, 8, 32, true>;
+  auto kern = pd::conv_kernel<pd::bf16_t, 3, 1, 8, 32, true, false>;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, (size_t)lds_bytes);
   hipFuncAttributes fa;
   hipFuncGetAttributes(&fa, (const void*)kern);

@@ -314,9 +314,14 @@ class _PackedWeights:
             e.w1, e.b1 = self._pack(r.conv1.weight), f32(r.conv1.bias)
             e.w2, e.b2 = self._pack(r.conv2.weight), f32(r.conv2.bias)
             if r.conv_shortcut is not None:
-                e.ws, e.bs = self._pack(r.conv_shortcut.weight), f32(r.conv_shortcut.bias)
+                # conv_shortcut is folded into conv2 (pd_conv tail): per 32-co tile the tail's fragments follow conv2's
+                ws = self._pack(r.conv_shortcut.weight)
+                ct = e.w2.shape[0]
+                e.w2 = torch.cat([e.w2.reshape(ct, -1, 64, 8), ws.reshape(ct, -1, 64, 8)], 1).contiguous()
+                e.b2 = e.b2 + f32(r.conv_shortcut.bias)
+                e.fused_shortcut = True
             else:
-                e.ws = e.bs = None
+                e.fused_shortcut = False
             e.eps = r.norm1.eps
             e.temb_off = off
             off += e.cout
@@ -417,7 +422,7 @@ class UNetPlan:
 
     def _conv(self, x0, x1, wpk, bias, cout, *, ksize=3, stride=1, pad=1, upsample=0, silu=0, gn=None, temb_off=None,
               residual=None, out_mode=L.PD_OUT_NHWC, heads=0, cout_pad=None, y=None, stats=True, im2col3=0, src_ptr=None,
-              src_shape=None):
+              src_shape=None, tail=None):
         B, hin, win, c0 = src_shape if src_shape is not None else x0.shape
         c1 = x1.shape[3] if x1 is not None else 0
         hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
@@ -441,14 +446,19 @@ class UNetPlan:
                        out_mode=out_mode, heads=heads, x0=(x0.data_ptr() if x0 is not None else src_ptr), x1=L.ptr(x1),
                        scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None,
                        w_packed=wpk.data_ptr(), bias=bias.data_ptr(), temb=None, temb_stride=self.w.proj_dim,
-                       residual=L.ptr(residual), y=L.ptr(y), stats_out=L.ptr(st), im2col3=im2col3)
+                       residual=L.ptr(residual), y=L.ptr(y), stats_out=L.ptr(st), im2col3=im2col3,
+                       tail_x0=L.ptr(tail[0]) if tail else None, tail_x1=L.ptr(tail[1]) if tail else None,
+                       tail_C0=tail[0].shape[3] if tail else 0,
+                       tail_C1=(tail[1].shape[3] if (tail and tail[1] is not None) else 0))
         if temb_off is not None:
             self._temb_ptr_fields.append((a, temb_off))
         esz = 2 if self.code == L.PD_BF16 else 4
         cin = c0 + c1
         flops = 2.0 * B * hout * wout * cout * cin * ksize * ksize
+        tail_c = (tail[0].shape[3] + (tail[1].shape[3] if tail[1] is not None else 0)) if tail else 0
+        flops += 2.0 * B * hout * wout * cout * tail_c
         nbytes = (B * hin * win * cin + B * hout * wout * cout * (2 if residual is not None else 1)) * esz \
-            + cout * cin * ksize * ksize * esz
+            + cout * cin * ksize * ksize * esz + (B * hout * wout * tail_c + cout * tail_c) * esz
         if out_mode == L.PD_OUT_NCHW_F32:
             nbytes += B * hout * wout * cout * (4 - esz)
         self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}", flops, nbytes))
@@ -459,12 +469,11 @@ class UNetPlan:
         gn1 = self._gn(x0, x1, e.g1, e.be1, e.eps)
         h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=e.temb_off)
         gn2 = self._gn(h1, None, e.g2, e.be2, e.eps)
-        if e.ws is not None:
-            sc, _ = self._conv(x0, x1, e.ws, e.bs, e.cout, ksize=1, pad=0, stats=False)
+        if e.fused_shortcut:
+            out, _ = self._conv(h1, None, e.w2, e.b2, e.cout, silu=1, gn=gn2, tail=(x0, x1))
         else:
             assert x1 is None
-            sc = x0
-        out, _ = self._conv(h1, None, e.w2, e.b2, e.cout, silu=1, gn=gn2, residual=sc)
+            out, _ = self._conv(h1, None, e.w2, e.b2, e.cout, silu=1, gn=gn2, residual=x0)
         return out
 
     def _attn(self, name, x):

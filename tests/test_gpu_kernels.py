@@ -357,3 +357,38 @@ def test_conv_in_im2col_mode(env, mode, hw):
     torch.cuda.synchronize()
     ref = F.conv2d(bf16_round(x, mode), bf16_round(w, mode), b, padding=1)
     assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 96, 32, 64, 32, 32), (1, 128, 64, 0, 64, 16, 16), (2, 32, 32, 32, 96, 8, 8)])
+def test_conv3x3_with_fused_1x1_tail(env, mode, shape):
+    """ResnetBlock2D tail: conv2(silu(gn(h))) + conv_shortcut(cat[x0, x1]) in ONE pd_conv (tail chunks)."""
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    B, cm, t0, t1, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(13)
+    hmid = torch.randn(B, cm, h, w_, generator=g)
+    xa = torch.randn(B, t0, h, w_, generator=g)
+    xb = torch.randn(B, t1, h, w_, generator=g) if t1 else None
+    w2 = torch.randn(cout, cm, 3, 3, generator=g) / (cm * 9) ** 0.5
+    ws = torch.randn(cout, t0 + t1, 1, 1, generator=g) / (t0 + t1) ** 0.5
+    b2, bs = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    scale, shift = torch.rand(B, cm, generator=g) + 0.5, torch.randn(B, cm, generator=g)
+    p2, ps = pack(w2, tdt), pack(ws, tdt)
+    ct = p2.shape[0]
+    wp = torch.cat([p2.reshape(ct, -1, 64, 8), ps.reshape(ct, -1, 64, 8)], 1).contiguous().to(dev)
+    H_, XA = nhwc(hmid.to(dev), tdt), nhwc(xa.to(dev), tdt)
+    XB = nhwc(xb.to(dev), tdt) if xb is not None else None
+    bias = (b2 + bs).to(dev)
+    sc, sh = scale.to(dev), shift.to(dev)
+    y = torch.full((B, h, w_, cout), float("nan"), dtype=tdt, device=dev)
+    a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=h, Wout=w_, C0=cm, C1=0, Cout=cout, Cout_pad=cout, ksize=3, stride=1, pad=1,
+                   upsample=0, silu=1, out_mode=0, heads=0, x0=H_.data_ptr(), x1=None, scale=sc.data_ptr(), shift=sh.data_ptr(),
+                   w_packed=wp.data_ptr(), bias=bias.data_ptr(), temb=None, temb_stride=0, residual=None, y=y.data_ptr(),
+                   stats_out=None, tail_x0=XA.data_ptr(), tail_x1=L.ptr(XB), tail_C0=t0, tail_C1=t1, im2col3=0)
+    L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+    torch.cuda.synchronize()
+    hin = bf16_round(F.silu(bf16_round(hmid, mode) * scale[:, :, None, None] + shift[:, :, None, None]), mode)
+    xcat = torch.cat([bf16_round(xa, mode)] + ([bf16_round(xb, mode)] if xb is not None else []), 1)
+    ref = F.conv2d(hin, bf16_round(w2, mode), b2, padding=1) + F.conv2d(xcat, bf16_round(ws, mode), bs)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
