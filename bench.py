@@ -221,8 +221,21 @@ def main():
             ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS[args.dtype], "TFLOP/s"
         else:
             ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r1_hbm_traffic.json: rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections); counters cannot be read from inside the process
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
+            key = {"attn_d8": "attn_kernel<unsigned short", "conv3x3": "conv_kernel<unsigned short, 3, 1, 8, 32, true, false",
+                   "conv1x1": "conv_kernel<unsigned short, 1, 1, 8, 32, true, false"}.get(kind)
+            for name, v in tj["kernels"].items():
+                if key and key in name and B == 32 and args.dtype == "bf16" and size == 256:
+                    traffic, traffic_src = round(v["hbm_bytes_per_launch"]), "profiles/r1_hbm_traffic.json"
+        except (OSError, ValueError, KeyError):
+            pass
         res["roofline"] = {"kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                           "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
                            "launches_per_forward": round(d["launches"]), "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                            "share_of_forward": round(d["ms"] / total_ms, 3),
                            "method": "HIP events on the launch stream between consecutive launches of one UNet forward "
