@@ -223,3 +223,77 @@ def test_inverted_regeneration_reconstructs():
     want = (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
     errs = [float(np.abs(P.inverted_regeneration(pgot, x.cuda(), labels.cuda(), S) - want).mean()) for S in (2, 10)]
     assert errs[1] <= errs[0] * 1.05
+
+
+def test_nonsquare_and_batch1_f32():
+    """Edge shapes: batch 1, non-square sample_size (tuple, pipeline_conditionial_ddim.py:222-234), sizes that are not
+    multiples of the conv tile (masked tiles)."""
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef
+    torch.manual_seed(0)
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    cfg = dict(P.UNET_CONFIGS["super_small"], sample_size=(24, 40))
+    r = CondUNet2DRef(**{k: v for k, v in cfg.items() if k in keys}).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype="f32", **cfg)
+    m.load_state_dict(r.state_dict())
+    m.to("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(1, 3, 24, 40, generator=g) * 2 - 1
+    lab = torch.tensor([1])
+    with torch.no_grad():
+        ref = r(x, 77, class_labels=lab).sample
+    got = m(x.cuda(), 77, class_labels=lab.cuda()).sample
+    assert rel(got, ref) < 5e-5
+    # per-sample timesteps (training-style call, utils_training.py:522-527)
+    x3 = torch.rand(3, 3, 24, 40, generator=g) * 2 - 1
+    ts = torch.tensor([5, 1500, 2999])
+    l3 = torch.tensor([0, 1, 0])
+    with torch.no_grad():
+        ref = r(x3, ts, class_labels=l3).sample
+    got = m(x3.cuda(), ts.cuda(), class_labels=l3.cuda()).sample
+    assert rel(got, ref) < 5e-5
+    # from-noise generation on a tuple sample_size
+    from oracle import ConditionalDDIMPipelineRef, DDIMSchedulerRef
+    sc = P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]
+    pref, pgot = ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**sc)), P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**sc))
+    a = pref(class_labels=l3, num_inference_steps=3, generator=torch.Generator().manual_seed(2)).images
+    b = pgot(class_labels=l3.cuda(), num_inference_steps=3, generator=torch.Generator().manual_seed(2), output_type="numpy").images
+    assert b.shape == (3, 24, 40, 3) and rel(b, a) < 2e-4
+
+
+@pytest.mark.parametrize("sched", ["1k_epsilon_pred", "SD_orig_config", "better_SD_config"])
+def test_ddib_graph_other_scheduler_configs_f32(sched):
+    """The other shipped scheduler configs (epsilon prediction with zero-SNR table: x0 = (x - sqrt(b) out)/sqrt(a) with
+    a -> 0; leading spacing + steps_offset + set_alpha_to_one=False; no clipping) through eager + graph DDIB."""
+    import phendiff_amd as P
+    from oracle import ConditionalDDIMPipelineRef, DDIMSchedulerRef, ddib_ref
+    r, m = make_pair("super_small", 32, "f32")
+    cfg = P.SCHEDULER_CONFIGS[sched]
+    pref, pgot = ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**cfg)), P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**cfg))
+    x, labels = synth_batch(2, 32)
+    ref_img, ref_inv = ddib_ref(pref, x, labels, 1 - labels, 5)
+    out = P.DDIBGraph(pgot, batch_size=2, num_inference_steps=5).run(x.cuda(), labels.cuda(), (1 - labels).cuda())
+    torch.cuda.synchronize()
+    fin = torch.isfinite(torch.from_numpy(ref_img))
+    assert torch.equal(torch.isfinite(out.images.cpu()), fin)            # the epsilon/zero-SNR hazard (SURVEY A.7) reproduces
+    assert rel(out.inverted, ref_inv) < 5e-4
+    assert rel(out.images.cpu()[fin], torch.from_numpy(ref_img)[fin]) < 5e-4
+
+
+def test_scheduler_step_options_f32():
+    """eta > 0 with explicit variance noise, use_clipped_model_output, sample prediction, linspace spacing."""
+    import phendiff_amd as P
+    from oracle import DDIMSchedulerRef
+    g = torch.Generator().manual_seed(21)
+    x, out, vn = (torch.randn(2, 3, 8, 8, generator=g) for _ in range(3))
+    for pt in ("epsilon", "sample", "v_prediction"):
+        cfg = dict(num_train_timesteps=1000, beta_schedule="linear", prediction_type=pt, timestep_spacing="linspace",
+                   clip_sample=True, clip_sample_range=0.8)
+        a, b = DDIMSchedulerRef(**cfg), P.DDIMScheduler(**cfg)
+        a.set_timesteps(7); b.set_timesteps(7)
+        assert torch.equal(a.timesteps, b.timesteps)
+        for t in a.timesteps[1:4]:
+            ra = a.step(out, t, x, eta=0.7, use_clipped_model_output=True, variance_noise=vn)
+            rb = b.step(out.cuda(), t, x.cuda(), eta=0.7, use_clipped_model_output=True, variance_noise=vn.cuda())
+            assert torch.allclose(rb.prev_sample.cpu(), ra.prev_sample, rtol=1e-5, atol=1e-5), (pt, int(t))
+            assert torch.allclose(rb.pred_original_sample.cpu(), ra.pred_original_sample, rtol=1e-5, atol=1e-6)
