@@ -177,17 +177,20 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const pd_gn_stats_args
 
 // pd_gn_finalize: per-tile channel sums written by pd_conv epilogues -> scale / shift.  One block per sample;
 // thread (channel-in-block-of-64, tile slice) streams the tile axis with coalesced 512-B rows; fp64 combine.
-__global__ __launch_bounds__(1024) void gn_finalize2_kernel(const pd_gn_finalize_args a) {
+// grid = (B, channel blocks): each block owns CB consecutive channels that contain only whole groups (CB = 96 is a
+// multiple of every group size in the shipped models; otherwise one block takes all channels).
+__global__ __launch_bounds__(1024) void gn_finalize2_kernel(const pd_gn_finalize_args a, int CB) {
   __shared__ double chs[1024], chq[1024];
   __shared__ double part[16][64][2];
   __shared__ float mean_s[64], rstd_s[64];
   const int C = a.C0 + a.C1;
   const int n = blockIdx.x, tid = threadIdx.x;
+  const int c_lo = blockIdx.y * CB, c_hi = min(C, c_lo + CB);
   const int cl = tid & 63, sl = tid >> 6;        // 64 channels x 16 tile slices
-  for (int cb = 0; cb < C; cb += 64) {
+  for (int cb = c_lo; cb < c_hi; cb += 64) {
     const int c = cb + cl;
     double s = 0.0, q = 0.0;
-    if (c < C) {
+    if (c < c_hi) {
       const bool first = c < a.C0;
       const float* st = first ? a.stats0 : a.stats1;
       const int Cs = first ? a.C0 : a.C1, T = first ? a.T0 : a.T1, cc = first ? c : c - a.C0;
@@ -199,16 +202,17 @@ __global__ __launch_bounds__(1024) void gn_finalize2_kernel(const pd_gn_finalize
     }
     part[sl][cl][0] = s; part[sl][cl][1] = q;
     __syncthreads();
-    if (sl == 0 && c < C) {
+    if (sl == 0 && c < c_hi) {
       double ts = 0.0, tq = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) { ts += part[k][cl][0]; tq += part[k][cl][1]; }
-      chs[c] = ts; chq[c] = tq;
+      chs[c - c_lo] = ts; chq[c - c_lo] = tq;
     }
     __syncthreads();
   }
   const int gs = C / a.groups;
-  if (tid < a.groups) {
+  const int g_lo = c_lo / gs, ng = (c_hi - c_lo) / gs;
+  if (tid < ng) {
     double ds = 0.0, dq = 0.0;
     for (int c = tid * gs; c < (tid + 1) * gs; ++c) { ds += chs[c]; dq += chq[c]; }
     const double cnt = (double)gs * (double)a.HW;
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(1024) void gn_finalize2_kernel(const pd_gn_finalize
     rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    const int g = c / gs;
+  for (int c = c_lo + tid; c < c_hi; c += 1024) {
+    const int g = c / gs - g_lo;
     const float sc = rstd_s[g] * a.gamma[c];
     a.scale[(size_t)n * C + c] = sc;
     a.shift[(size_t)n * C + c] = a.beta[c] - mean_s[g] * sc;
@@ -355,7 +359,9 @@ extern "C" int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream) {
   PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0, PD_ERR_SHAPE, "pd_gn_finalize: groups=%d C=%d", a->groups, C);
   PD_CHECK(a->stats0 && a->gamma && a->beta && a->scale && a->shift, PD_ERR_ARG, "pd_gn_finalize: null pointer");
   PD_CHECK((a->C1 == 0) == (a->stats1 == nullptr) && (a->C1 == 0 || a->T1 > 0), PD_ERR_ARG, "pd_gn_finalize: stats1/C1 mismatch");
-  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->B), dim3(1024), 0, (hipStream_t)stream, *a);
+  const int gs = C / a->groups;
+  const int CB = (96 % gs == 0) ? 96 : C;          // channel block of whole groups
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->B, (C + CB - 1) / CB), dim3(1024), 0, (hipStream_t)stream, *a, CB);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
