@@ -297,3 +297,41 @@ def test_scheduler_step_options_f32():
             rb = b.step(out.cuda(), t, x.cuda(), eta=0.7, use_clipped_model_output=True, variance_noise=vn.cuda())
             assert torch.allclose(rb.prev_sample.cpu(), ra.prev_sample, rtol=1e-5, atol=1e-5), (pt, int(t))
             assert torch.allclose(rb.pred_original_sample.cpu(), ra.pred_original_sample, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_forward_vs_oracle():
+    """BASELINE size (256x256, super_small): one UNet evaluation against the CPU oracle, both engine modes."""
+    import os as _os
+    torch.set_num_threads(min(16, len(_os.sched_getaffinity(0))))
+    r, m32 = make_pair("super_small", 256, "f32")
+    x, labels = synth_batch(1, 256)
+    with torch.no_grad():
+        ref = r(x, 1500, class_labels=labels).sample
+    got = m32(x.cuda(), 1500, class_labels=labels.cuda()).sample
+    assert rel(got, ref) < 5e-5
+    _, m16 = make_pair("super_small", 256, "bf16")
+    got16 = m16(x.cuda(), 1500, class_labels=labels.cuda()).sample
+    assert rel(got16, ref) < 3e-2
+
+
+def test_full_size_trajectory_bf16_vs_f32_engine():
+    """The metric's own workload (256x256, 50 + 50 DDIM steps): the bf16 (bench) engine against the exact-fp32 engine on the
+    same weights and images -- the oracle takes minutes per image here, the fp32 engine is its stand-in (it agrees with the
+    oracle to 5e-5 per forward, test above)."""
+    import phendiff_amd as P
+    outs = {}
+    x, labels = synth_batch(2, 256)
+    for mode in ("f32", "bf16"):
+        torch.manual_seed(0)
+        unet = P.CustomCondUNet2DModel(compute_dtype=mode, **dict(P.UNET_CONFIGS["super_small"], sample_size=256)).to("cuda:0")
+        pipe = P.ConditionalDDIMPipeline(unet, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
+        g = P.DDIBGraph(pipe, batch_size=2, num_inference_steps=50)
+        o = g.run(x.cuda(), labels.cuda(), (1 - labels).cuda())
+        torch.cuda.synchronize()
+        outs[mode] = (o.images.cpu().clone(), o.inverted.cpu().clone())
+        del g, pipe, unet
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs["f32"][0]).all() and torch.isfinite(outs["bf16"][0]).all()
+    assert rel(outs["bf16"][1], outs["f32"][1]) < 6e-2          # inverted latents after 50 steps
+    assert rel(outs["bf16"][0], outs["f32"][0]) < 6e-2          # images after 100 steps
+    assert float(outs["bf16"][0].min()) >= 0.0 and float(outs["bf16"][0].max()) <= 1.0
