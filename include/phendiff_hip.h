@@ -230,6 +230,45 @@ typedef struct {
 int pd_postproc(const pd_postproc_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training-step building blocks.  The UNet backward is not built yet; these are the fused
+ * bandwidth-bound passes around it, on flat fp32 buffers.
+ *
+ * pd_diffusion_loss (utils_training.py:415-433): loss = mean(w_n (out - target)^2) and d loss / d out, with
+ *   epsilon: target = noise, w = 1      sample: target = clean, w_n = alpha_t/(1-alpha_t) (SNR weights, `weight`)
+ *   v_prediction: target = sa_n*noise - sb_n*clean  (DDIMScheduler.get_velocity)
+ * Deterministic two-stage reduction (fp64 partials).
+ */
+typedef struct {
+  int64_t numel, per_sample;
+  int pred_type;
+  const float* model_out; const float* noise; const float* clean;
+  const float* weight;            /* [B] SNR weights (sample prediction) or NULL */
+  const float* sa; const float* sb;   /* [B] sqrt(alpha_bar_t), sqrt(1-alpha_bar_t) (v_prediction) or NULL */
+  float grad_scale;               /* multiplies d loss / d out (1.0; loss scaling for fp16) */
+  float* grad_out;                /* [numel] or NULL */
+  double* partial;                /* workspace [1024] */
+  float* loss_out;                /* [1] */
+} pd_loss_args;
+int pd_diffusion_loss(const pd_loss_args* a, void* stream);
+
+/* pd_grad_norm (utils_training.py:438-440, torch.nn.utils.clip_grad_norm_): global L2 norm of a flat gradient buffer and the
+ * clip coefficient min(1, max_norm / (norm + 1e-6)), both left on the device (no host sync). partial: workspace [1024]. */
+int pd_grad_norm(const float* grad, int64_t numel, double* partial, float max_norm, float* norm_out, float* clip_coef_out, void* stream);
+
+/* pd_adamw_ema (utils_training.py:452-454 optimizer.step/zero_grad, :553-556 EMAModel.step): one pass over flat fp32 buffers:
+ *   g *= clip_coef;  torch.optim.AdamW single-tensor update;  ema -= one_minus_decay * (ema - param);  optional grad zeroing.
+ * Host passes step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t), one_minus_decay = 1 - EMA decay_t. */
+typedef struct {
+  int64_t numel;
+  float lr, beta1, beta2, eps, weight_decay, step_size, bias_correction2_sqrt, one_minus_decay;
+  int zero_grad;
+  const float* clip_coef;         /* device scalar from pd_grad_norm, or NULL */
+  float* param; float* grad; float* exp_avg; float* exp_avg_sq;
+  float* ema;                     /* EMA shadow parameters or NULL */
+} pd_adamw_ema_args;
+int pd_adamw_ema(const pd_adamw_ema_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stream capture helpers (hipGraph): the S-step sampling loop is captured once and replayed.
  */
 int pd_graph_begin(void* stream);

@@ -12,3 +12,4 @@ from .pipeline import ConditionalDDIMPipeline, ImagePipelineOutput  # noqa: F401
 from .img2img import (inversion, ddib, inverted_regeneration, classifier_free_guidance_forward_start, DDIBGraph,  # noqa: F401
                       CFGForwardStartGraph, shard_batches, swap_binary_labels)
 from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401
+from . import training  # noqa: F401

@@ -71,6 +71,19 @@ class AddNoiseArgs(C.Structure):
                 ("x", vp), ("noise", vp), ("sa", vp), ("sb", vp), ("out", vp)]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [("numel", C.c_int64), ("per_sample", C.c_int64), ("pred_type", C.c_int), ("model_out", vp), ("noise", vp),
+                ("clean", vp), ("weight", vp), ("sa", vp), ("sb", vp), ("grad_scale", C.c_float), ("grad_out", vp),
+                ("partial", vp), ("loss_out", vp)]
+
+
+class AdamWEmaArgs(C.Structure):
+    _fields_ = [("numel", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step_size", C.c_float), ("bias_correction2_sqrt", C.c_float),
+                ("one_minus_decay", C.c_float), ("zero_grad", C.c_int), ("clip_coef", vp), ("param", vp), ("grad", vp),
+                ("exp_avg", vp), ("exp_avg_sq", vp), ("ema", vp)]
+
+
 class PostprocArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("x", vp), ("out_f32", vp), ("out_u8", vp)]
 
@@ -89,6 +102,9 @@ SYMBOLS = {
     "pd_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), vp]),
     "pd_add_noise": (C.c_int, [C.POINTER(AddNoiseArgs), vp]),
     "pd_postproc": (C.c_int, [C.POINTER(PostprocArgs), vp]),
+    "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),
+    "pd_grad_norm": (C.c_int, [vp, C.c_int64, vp, C.c_float, vp, vp, vp]),
+    "pd_adamw_ema": (C.c_int, [C.POINTER(AdamWEmaArgs), vp]),
     "pd_graph_begin": (C.c_int, [vp]),
     "pd_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "pd_graph_launch": (C.c_int, [vp, vp]),

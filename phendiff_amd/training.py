@@ -1,0 +1,169 @@
+"""Training-step building blocks around the (not yet built) UNet backward -- SURVEY.md 8a rows A13-A16.
+
+Device side (``csrc/train_kernels.hip``): ``pd_diffusion_loss`` (loss + d loss/d out, ``utils_training.py:415-433``),
+``pd_grad_norm`` (``clip_grad_norm_(params, 1.0)``, ``:438-440``) and ``pd_adamw_ema`` (clip scaling + AdamW +
+``EMAModel.step`` in one pass over flat fp32 buffers, ``:452-454,553-556``).  Host side (this file): the schedules the
+reference takes from diffusers (EMA warm-up decay, cosine LR with warm-up), ``lr * sqrt(world)`` (``train.py:277``), the
+per-step sampling of ``perform_training_epoch`` (``:244-256``), the unconditional-step coin flip WITHOUT the per-step
+barrier + broadcast (``:262-275``: every rank seeds the same host RNG, only rank 0's draw was ever used), and
+data-parallel gradient averaging (what DDP's all-reduce computes, ``train.py:311-326``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import _lib as L
+
+
+# ---- host-side schedules -------------------------------------------------------------------------------------------
+def ema_decay(optimization_step: int, decay: float = 0.9999, use_ema_warmup: bool = True, inv_gamma: float = 1.0,
+              power: float = 0.75, update_after_step: int = 0, min_decay: float = 0.0) -> float:
+    """diffusers ``EMAModel.get_decay`` (0.18.2), called with the 1-based step count (``EMAModel.step`` increments first).
+    Reference settings: train.py:229-237 (decay .9999, warm-up on, inv_gamma 1, power .75)."""
+    step = max(0, optimization_step - update_after_step - 1)
+    if step <= 0:
+        return 0.0
+    cur = 1 - (1 + step / inv_gamma) ** -power if use_ema_warmup else (1 + step) / (10 + step)
+    return max(min(cur, decay), min_decay)
+
+
+def cosine_lr_factor(step: int, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5) -> float:
+    """diffusers ``get_scheduler("cosine")`` LambdaLR factor (train.py:298-303)."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+def scaled_lr(lr: float, world_size: int) -> float:
+    """``lr *= sqrt(num_processes)`` (train.py:277)."""
+    return lr * math.sqrt(world_size)
+
+
+class UnconditionalStepFlags:
+    """Replaces the per-step barrier + 8-byte broadcast of ``rand(1) < proba_uncond`` (utils_training.py:262-275): every
+    rank draws from an identically seeded host generator, so all ranks agree with zero traffic."""
+
+    def __init__(self, seed: int, proba_uncond: float):
+        self.g = torch.Generator().manual_seed(int(seed))
+        self.p = float(proba_uncond)
+
+    def next(self) -> bool:
+        return bool(torch.rand(1, generator=self.g).item() < self.p)
+
+
+@torch.no_grad()
+def sample_training_inputs(clean_images: torch.Tensor, scheduler, cpu_generator: Optional[torch.Generator] = None,
+                           device_generator: Optional[torch.Generator] = None):
+    """perform_training_epoch's per-step sampling: noise on the CPU RNG then H2D (utils_training.py:244), timesteps
+    ``randint(0, N, (B,))`` on the device (:247-252), ``noisy = add_noise(clean, noise, t)`` (:256, ``pd_add_noise``)."""
+    B = clean_images.shape[0]
+    noise = torch.randn(clean_images.shape, generator=cpu_generator).to(clean_images.device)
+    timesteps = torch.randint(0, scheduler.config.num_train_timesteps, (B,), device=clean_images.device,
+                              generator=device_generator).long()
+    return noise, timesteps, scheduler.add_noise(clean_images, noise, timesteps)
+
+
+# ---- device-side wrappers ------------------------------------------------------------------------------------------
+class DiffusionLoss:
+    """``loss, dloss/dout = DiffusionLoss(scheduler)(model_out, clean, noise, timesteps)`` (utils_training.py:415-433)."""
+
+    def __init__(self, scheduler, device):
+        self.scheduler = scheduler
+        self.partial = torch.empty(1024, dtype=torch.float64, device=device)
+
+    def __call__(self, model_out, clean, noise, timesteps, want_grad=True, grad_scale=1.0):
+        if not model_out.is_cuda:
+            raise L.PhenDiffHipError("phendiff_amd runs on MI355X only (no CPU fallback)")
+        pt = self.scheduler.config.prediction_type
+        dev = model_out.device
+        mo, cl, nz = model_out.contiguous().float(), clean.contiguous().float(), noise.contiguous().float()
+        acp = self.scheduler.alphas_cumprod[timesteps.detach().cpu().long()]
+        w = sa = sb = None
+        if pt == "sample":
+            w = (acp / (1 - acp)).to(dev).contiguous()          # SNR weights (extract_into_tensor, utils_misc.py:33-48)
+        elif pt == "v_prediction":
+            sa, sb = (acp ** 0.5).to(dev).contiguous(), ((1 - acp) ** 0.5).to(dev).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(mo) if want_grad else None
+        a = L.LossArgs(numel=mo.numel(), per_sample=mo[0].numel(), pred_type=L.PD_PRED[pt], model_out=mo.data_ptr(),
+                       noise=nz.data_ptr(), clean=cl.data_ptr(), weight=L.ptr(w), sa=L.ptr(sa), sb=L.ptr(sb),
+                       grad_scale=float(grad_scale), grad_out=L.ptr(grad), partial=self.partial.data_ptr(),
+                       loss_out=loss.data_ptr())
+        L.check(L.lib().pd_diffusion_loss(C.byref(a), torch.cuda.current_stream(dev).cuda_stream), "pd_diffusion_loss")
+        return loss, grad
+
+
+class FlatAdamWEMA:
+    """AdamW (torch defaults of the reference: betas (.95, .999), wd 1e-6, eps 1e-8; args_parser.py:299-321) + global
+    grad-norm clipping to ``max_grad_norm`` + diffusers EMA, fused over ONE flat fp32 buffer.  ``params`` are re-pointed
+    to views of the flat buffer (their ``.grad`` to views of the flat gradient), so modules see the updates in place."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float, betas=(0.95, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-6, max_grad_norm: Optional[float] = 1.0, use_ema: bool = True,
+                 ema_kwargs: Optional[dict] = None):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params or not self.params[0].is_cuda:
+            raise L.PhenDiffHipError("FlatAdamWEMA needs parameters on an MI355X device (no CPU fallback)")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.ema = self.flat.clone() if use_ema else None
+        self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.ema_kwargs = ema_kwargs or {}
+        self.t = 0
+        self.partial = torch.empty(1024, dtype=torch.float64, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.clip_coef = torch.ones(1, dtype=torch.float32, device=dev)
+
+    def step(self, lr: Optional[float] = None, zero_grad: bool = True):
+        """clip_grad_norm_ -> optimizer.step -> zero_grad -> EMA.step (utils_training.py:438-454, 553-556). No host sync:
+        the gradient norm stays on the device (``self.grad_norm``)."""
+        lib = L.lib()
+        st = torch.cuda.current_stream(self.flat.device).cuda_stream
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        b1, b2 = self.betas
+        if self.max_grad_norm is not None:
+            L.check(lib.pd_grad_norm(self.grad.data_ptr(), self.grad.numel(), self.partial.data_ptr(), float(self.max_grad_norm),
+                                     self.grad_norm.data_ptr(), self.clip_coef.data_ptr(), st), "pd_grad_norm")
+        d = ema_decay(self.t, **self.ema_kwargs) if self.ema is not None else 0.0
+        a = L.AdamWEmaArgs(numel=self.flat.numel(), lr=lr, beta1=b1, beta2=b2, eps=self.eps, weight_decay=self.wd,
+                           step_size=lr / (1 - b1 ** self.t), bias_correction2_sqrt=math.sqrt(1 - b2 ** self.t),
+                           one_minus_decay=1.0 - d, zero_grad=int(zero_grad),
+                           clip_coef=self.clip_coef.data_ptr() if self.max_grad_norm is not None else None,
+                           param=self.flat.data_ptr(), grad=self.grad.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
+                           exp_avg_sq=self.exp_avg_sq.data_ptr(), ema=L.ptr(self.ema))
+        L.check(lib.pd_adamw_ema(C.byref(a), st), "pd_adamw_ema")
+
+
+def allreduce_mean_(flat_grad: torch.Tensor, group=None, bucket_bytes: int = 256 << 20):
+    """Data-parallel gradient averaging over one flat buffer: what DDP's bucketed all-reduce computes for
+    ``accelerator.backward`` (utils_training.py:436, train.py:311-326), as a few LARGE asynchronous all-reduces (RCCL over
+    xGMI is per-link bound: big buckets, 288 GB HBM) followed by the 1/world scale.  No-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grad
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat_grad
+    per = max(1, bucket_bytes // flat_grad.element_size())
+    works = [dist.all_reduce(flat_grad[i:i + per], op=dist.ReduceOp.SUM, group=group, async_op=True)
+             for i in range(0, flat_grad.numel(), per)]
+    for wk in works:
+        wk.wait()
+    flat_grad.div_(world)
+    return flat_grad
