@@ -233,7 +233,15 @@ def main():
                     traffic, traffic_src = round(v["hbm_bytes_per_launch"]), "profiles/r1_hbm_traffic.json"
         except (OSError, ValueError, KeyError):
             pass
-        res["roofline"] = {"kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+        extra = {}
+        if kind == "attn_d8":
+            # the d=8 attention is bound by the VALU/transcendental issue pipe, not by MFMA or HBM: report
+            # exponentials/s against v_exp_f32's 8-cycle issue on 1024 SIMDs at the 2.4 GHz peak clock as well
+            nexp = d["flops"] / 32.0                      # flops = 4*B*heads*N^2*8  ->  B*heads*N^2 exps
+            extra = {"issue_bound": {"what": "v_exp_f32 issue (64 lanes / 8 cycles / SIMD, 1024 SIMDs, 2.4 GHz)",
+                                     "achieved_Texp_per_s": round(nexp / (d["ms"] * 1e-3) / 1e12, 2), "peak_Texp_per_s": 19.66,
+                                     "frac": round(nexp / (d["ms"] * 1e-3) / 19.66e12, 4)}}
+        res["roofline"] = {**extra, "kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
                            "launches_per_forward": round(d["launches"]), "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
