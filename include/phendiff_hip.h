@@ -126,7 +126,7 @@ typedef struct {
   int ksize;                /* 1 or 3 */
   int stride;               /* 1 or 2 (3x3 only) */
   int pad;                  /* 1 for 3x3 pad 1; 0 for 1x1 or the asymmetric (0,1,0,1) downsample */
-  int upsample;             /* 1: nearest x2 before the conv */
+  int upsample;             /* 1: nearest x2 before the conv (Upsample2D); 2: zero-stuffed x2 (input gradient of a stride-2 conv) */
   int silu;                 /* 1: SiLU after the affine */
   int out_mode;             /* pd_out_mode */
   int heads;                /* PD_OUT_QKV_HEADS: number of heads (Cout = 3*heads*8) */
@@ -160,6 +160,7 @@ typedef struct {
   int C1, T1; const float* stats1;     /* [B][T1][C1][2] or NULL (C1 = 0) */
   const float* gamma; const float* beta;
   float* scale; float* shift;          /* out [B][C0+C1] */
+  float* mean; float* rstd;            /* optional out [B][groups] (kept for the backward, pd_gn_silu_bwd), or NULL */
 } pd_gn_finalize_args;
 int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream);
 
@@ -228,6 +229,37 @@ typedef struct {
   uint8_t* out_u8;          /* NHWC or NULL */
 } pd_postproc_args;
 int pd_postproc(const pd_postproc_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * UNet backward building blocks (autograd of the forward above, utils_training.py:436).
+ * Input gradients of convolutions reuse pd_conv with W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx] (stride-2 convs: upsample = 2,
+ * zero-stuffed dY; the conv fused with Upsample2D: pd_conv at 2x resolution followed by pd_pool2x2_sum).
+ *
+ * pd_gn_silu_bwd: gradient through z = silu?(GroupNorm(x)) of [x0 | x1]:  dz -> dx (per source, = or +=), dgamma += , dbeta += .
+ *   dy = dz * silu'(gamma*xhat + beta);  dx = rstd * (gamma*dy - mean_g(gamma*dy) - xhat * mean_g(gamma*dy*xhat))
+ */
+typedef struct {
+  int dtype;
+  int B, HW, C0, C1, groups, silu;
+  const void* x0; const void* x1;        /* forward inputs of the norm (NHWC) */
+  const void* dz0; const void* dz1;      /* gradient w.r.t. the normalised (+SiLU) tensor, same split */
+  const float* mean; const float* rstd;  /* [B][groups] from pd_gn_finalize */
+  const float* gamma; const float* beta; /* [C0+C1] */
+  double* partial; int splits;           /* workspace [B][splits][C0+C1][2] */
+  float* coef;                           /* workspace [B][groups][2] */
+  void* dx0; void* dx1;                  /* outputs (either may be NULL) */
+  int accumulate0, accumulate1;          /* 1: dx += */
+  float* dgamma; float* dbeta;           /* [C0+C1], accumulated (+=), or NULL */
+} pd_gn_bwd_args;
+int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream);
+
+/* pd_pool2x2_sum: dx[n][y][x][c] (+)= sum of du[n][2y..2y+1][2x..2x+1][c]  (gradient of F.interpolate(scale_factor=2, "nearest")) */
+typedef struct { int dtype; int B, H, W, C; const void* du; void* dx; int accumulate; } pd_pool2x2_args;
+int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream);
+
+/* pd_channel_sum: out[n*out_stride + c] (+)= sum over pixels of x[n][p][c]  (bias gradients after a sum over n; d temb_proj) */
+typedef struct { int dtype; int B, HW, C; const void* x; float* out; int out_stride; int accumulate; } pd_channel_sum_args;
+int pd_channel_sum(const pd_channel_sum_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-step building blocks.  The UNet backward is not built yet; these are the fused

@@ -50,7 +50,24 @@ class ConvArgs(C.Structure):
 class GnFinalizeArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("HW", C.c_int), ("groups", C.c_int), ("eps", C.c_float),
                 ("C0", C.c_int), ("T0", C.c_int), ("stats0", vp), ("C1", C.c_int), ("T1", C.c_int), ("stats1", vp),
-                ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp)]
+                ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("rstd", vp)]
+
+
+class GnBwdArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C0", C.c_int), ("C1", C.c_int), ("groups", C.c_int),
+                ("silu", C.c_int), ("x0", vp), ("x1", vp), ("dz0", vp), ("dz1", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
+                ("beta", vp), ("partial", vp), ("splits", C.c_int), ("coef", vp), ("dx0", vp), ("dx1", vp),
+                ("accumulate0", C.c_int), ("accumulate1", C.c_int), ("dgamma", vp), ("dbeta", vp)]
+
+
+class Pool2x2Args(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("du", vp), ("dx", vp),
+                ("accumulate", C.c_int)]
+
+
+class ChannelSumArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("x", vp), ("out", vp),
+                ("out_stride", C.c_int), ("accumulate", C.c_int)]
 
 
 class AttnArgs(C.Structure):
@@ -102,6 +119,9 @@ SYMBOLS = {
     "pd_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), vp]),
     "pd_add_noise": (C.c_int, [C.POINTER(AddNoiseArgs), vp]),
     "pd_postproc": (C.c_int, [C.POINTER(PostprocArgs), vp]),
+    "pd_gn_silu_bwd": (C.c_int, [C.POINTER(GnBwdArgs), vp]),
+    "pd_pool2x2_sum": (C.c_int, [C.POINTER(Pool2x2Args), vp]),
+    "pd_channel_sum": (C.c_int, [C.POINTER(ChannelSumArgs), vp]),
     "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),
     "pd_grad_norm": (C.c_int, [vp, C.c_int64, vp, C.c_float, vp, vp, vp]),
     "pd_adamw_ema": (C.c_int, [C.POINTER(AdamWEmaArgs), vp]),

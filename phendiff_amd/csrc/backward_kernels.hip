@@ -1,0 +1,243 @@
+// Backward building blocks of the UNet, bandwidth-bound ones:
+//   pd_gn_silu_bwd : gradient through  z = silu?(GroupNorm(x))  (ResnetBlock2D.norm1/norm2 + nonlinearity, Attention.group_norm,
+//                    conv_norm_out): dz -> dx (per source of a channel concat), dgamma, dbeta
+//   pd_pool2x2_sum : gradient of the nearest x2 upsample fused into Upsample2D's conv (sum over each 2x2 block)
+//   pd_channel_sum : per-(sample, channel) sums of an NHWC tensor (bias gradients, time-embedding projection gradients)
+// The MFMA pieces live elsewhere: input gradients reuse pd_conv with flipped/transposed weights (packing.dgrad_weight),
+// weight gradients are pd_conv_wgrad (wgrad.hip).
+#include "pd_common.h"
+
+namespace pd {
+
+__device__ __forceinline__ float dsilu(float y) {          // d/dy [y * sigmoid(y)]
+  const float s = 1.0f / (1.0f + __expf(-y));
+  return s * (1.0f + y * (1.0f - s));
+}
+
+// (1) per-(sample, split, channel) partial sums of dy and dy * xhat, coalesced 8-channel pieces
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args a) {
+  using E = Elem<T>;
+  __shared__ float red[256 * 16];
+  const int C = a.C0 + a.C1, gs = C / a.groups;
+  const int PP = C / 8, ppi = 256 / PP, nthr = ppi * PP;
+  const int n = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int per = (a.HW + a.splits - 1) / a.splits;
+  const int p0 = split * per, p1 = min(a.HW, p0 + per);
+  const int tid = threadIdx.x;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (tid < nthr) {
+    const int piece = tid % PP, prow = tid / PP, c8 = piece * 8;
+    const bool first = c8 < a.C0;
+    const T* xs = (const T*)(first ? a.x0 : a.x1);
+    const T* ds = (const T*)(first ? a.dz0 : a.dz1);
+    const int cs = first ? a.C0 : a.C1, coff = first ? c8 : c8 - a.C0;
+    float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (c8 + j) / gs;
+      mu[j] = a.mean[n * a.groups + g]; rs[j] = a.rstd[n * a.groups + g]; ga[j] = a.gamma[c8 + j]; be[j] = a.beta[c8 + j];
+    }
+    for (int p = p0 + prow; p < p1; p += ppi) {
+      float xv[8], dv[8];
+      E::unpack(E::load(xs + ((size_t)n * a.HW + p) * cs + coff), xv);
+      E::unpack(E::load(ds + ((size_t)n * a.HW + p) * cs + coff), dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (xv[j] - mu[j]) * rs[j];
+        const float dy = a.silu ? dv[j] * dsilu(ga[j] * xh + be[j]) : dv[j];
+        s1[j] += dy; s2[j] += dy * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int piece = c >> 3, j = c & 7;
+    double d1 = 0.0, d2 = 0.0;
+    for (int k = 0; k < ppi; ++k) { d1 += (double)red[(k * PP + piece) * 16 + j]; d2 += (double)red[(k * PP + piece) * 16 + 8 + j]; }
+    double* out = a.partial + (((size_t)n * a.splits + split) * C + c) * 2;
+    out[0] = d1; out[1] = d2;
+  }
+}
+
+// (2) per-(sample, group) coefficients A/M, B/M and the parameter gradients dgamma, dbeta (+=)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_args a) {
+  __shared__ double s1[1024], s2[1024];
+  const int C = a.C0 + a.C1, gs = C / a.groups, tid = threadIdx.x;
+  if (blockIdx.x < (unsigned)a.B) {
+    const int n = blockIdx.x;
+    for (int c = tid; c < C; c += 256) {
+      double d1 = 0.0, d2 = 0.0;
+      for (int sp = 0; sp < a.splits; ++sp) {
+        const double* in = a.partial + (((size_t)n * a.splits + sp) * C + c) * 2;
+        d1 += in[0]; d2 += in[1];
+      }
+      s1[c] = d1 * (double)a.gamma[c]; s2[c] = d2 * (double)a.gamma[c];
+    }
+    __syncthreads();
+    if (tid < a.groups) {
+      double A = 0.0, Bq = 0.0;
+      for (int c = tid * gs; c < (tid + 1) * gs; ++c) { A += s1[c]; Bq += s2[c]; }
+      const double M = (double)gs * (double)a.HW;
+      a.coef[(n * a.groups + tid) * 2] = (float)(A / M);
+      a.coef[(n * a.groups + tid) * 2 + 1] = (float)(Bq / M);
+    }
+  } else {   // last block: parameter gradients, summed over samples in a fixed order
+    for (int c = tid; c < C; c += 256) {
+      double d1 = 0.0, d2 = 0.0;
+      for (int n = 0; n < a.B; ++n)
+        for (int sp = 0; sp < a.splits; ++sp) {
+          const double* in = a.partial + (((size_t)n * a.splits + sp) * C + c) * 2;
+          d1 += in[0]; d2 += in[1];
+        }
+      if (a.dbeta) a.dbeta[c] += (float)d1;
+      if (a.dgamma) a.dgamma[c] += (float)d2;
+    }
+  }
+}
+
+// (3) dx = rstd * (gamma*dy - A/M - xhat*B/M)   (+= into dx when accumulate)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args a) {
+  using E = Elem<T>;
+  const int C = a.C0 + a.C1, gs = C / a.groups, PP = C / 8;
+  const size_t total = (size_t)a.B * a.HW * PP;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int piece = (int)(idx % PP);
+    const size_t pixl = idx / PP;
+    const int n = (int)(pixl / a.HW);
+    const int c8 = piece * 8;
+    const bool first = c8 < a.C0;
+    const int cs = first ? a.C0 : a.C1, coff = first ? c8 : c8 - a.C0;
+    const size_t off = pixl * cs + coff;
+    T* dxp = (T*)(first ? a.dx0 : a.dx1);
+    if (!dxp) continue;
+    float xv[8], dv[8], acc[8];
+    E::unpack(E::load((const T*)(first ? a.x0 : a.x1) + off), xv);
+    E::unpack(E::load((const T*)(first ? a.dz0 : a.dz1) + off), dv);
+    const bool accum = first ? a.accumulate0 : a.accumulate1;
+    if (accum) E::unpack(E::load(dxp + off), acc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 + j, g = c / gs;
+      const float mu = a.mean[n * a.groups + g], rs = a.rstd[n * a.groups + g];
+      const float xh = (xv[j] - mu) * rs;
+      const float dy = a.silu ? dv[j] * dsilu(a.gamma[c] * xh + a.beta[c]) : dv[j];
+      const float dx = rs * (a.gamma[c] * dy - a.coef[(n * a.groups + g) * 2] - xh * a.coef[(n * a.groups + g) * 2 + 1]);
+      acc[j] = accum ? acc[j] + dx : dx;
+    }
+    E::store(dxp + off, E::pack(acc));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool2x2_kernel(const pd_pool2x2_args a) {
+  using E = Elem<T>;
+  const int PP = a.C / 8;
+  const size_t total = (size_t)a.B * a.H * a.W * PP;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int piece = (int)(idx % PP);
+    size_t pix = idx / PP;
+    const int sx = (int)(pix % a.W); pix /= a.W;
+    const int sy = (int)(pix % a.H); const int n = (int)(pix / a.H);
+    float acc[8];
+    const size_t o = (((size_t)n * a.H + sy) * a.W + sx) * a.C + piece * 8;
+    if (a.accumulate) E::unpack(E::load((const T*)a.dx + o), acc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        float v[8];
+        E::unpack(E::load((const T*)a.du + ((((size_t)n * 2 * a.H + 2 * sy + dy) * 2 * a.W) + 2 * sx + dxx) * a.C + piece * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    E::store((T*)a.dx + o, E::pack(acc));
+  }
+}
+
+// per-(sample, channel) sum over pixels of an NHWC tensor; out[n][c] (+=)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_args a) {
+  using E = Elem<T>;
+  __shared__ float red[256 * 8];
+  const int PP = a.C / 8, ppi = 256 / PP, nthr = ppi * PP;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  if (tid < nthr) {
+    const int piece = tid % PP, prow = tid / PP;
+    for (int p = prow; p < a.HW; p += ppi) {
+      float v[8];
+      E::unpack(E::load((const T*)a.x + ((size_t)n * a.HW + p) * a.C + piece * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = s[j];
+  __syncthreads();
+  for (int c = tid; c < a.C; c += 256) {
+    double d = 0.0;
+    for (int k = 0; k < ppi; ++k) d += (double)red[(k * PP + (c >> 3)) * 8 + (c & 7)];
+    float* o = a.out + (size_t)n * a.out_stride + c;
+    *o = a.accumulate ? *o + (float)d : (float)d;
+  }
+}
+
+}  // namespace pd
+
+using namespace pd;
+
+extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_gn_silu_bwd: null args");
+  const int C = a->C0 + a->C1;
+  PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0 && C <= 1024, PD_ERR_SHAPE, "pd_gn_silu_bwd: bad shape");
+  PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0 && C / 8 <= 256, PD_ERR_SHAPE, "pd_gn_silu_bwd: groups=%d C=%d", a->groups, C);
+  PD_CHECK(a->x0 && a->dz0 && a->mean && a->rstd && a->gamma && a->beta && a->partial && a->coef && a->splits >= 1, PD_ERR_ARG, "pd_gn_silu_bwd: null pointer");
+  PD_CHECK((a->C1 == 0) == (a->x1 == nullptr) && (a->C1 == 0) == (a->dz1 == nullptr), PD_ERR_ARG, "pd_gn_silu_bwd: source 1 mismatch");
+  PD_CHECK(a->dx0 || a->dx1, PD_ERR_ARG, "pd_gn_silu_bwd: no output");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)a->B * a->HW * (C / 8);
+  const unsigned agrid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (a->dtype == PD_F32) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + 1), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(agrid), dim3(256), 0, st, *a);
+  } else if (a->dtype == PD_BF16) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + 1), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(agrid), dim3(256), 0, st, *a);
+  } else { set_error("pd_gn_silu_bwd: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->C % 8 == 0 && a->du && a->dx, PD_ERR_ARG, "pd_pool2x2_sum: bad args");
+  const size_t total = (size_t)a->B * a->H * a->W * (a->C / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(pool2x2_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(pool2x2_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_pool2x2_sum: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_channel_sum(const pd_channel_sum_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->B > 0 && a->HW > 0 && a->C > 0 && a->C % 8 == 0 && a->C / 8 <= 256 && a->x && a->out, PD_ERR_ARG, "pd_channel_sum: bad args");
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_channel_sum: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}

@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
     if (pix < NPIX) {
       const int u = pix / IN_TW, vv = pix - u * IN_TW;
       const int iy = y0 * STRIDE - p.pad + u, ix = x0 * STRIDE - p.pad + vv;
-      if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) {
+      // upsample 1: nearest x2 (Upsample2D);  upsample 2: zero-stuffed x2 (the stride-2 conv's input gradient is a
+      // stride-1 conv over dY with zeros between its samples)
+      if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && (p.upsample != 2 || (((iy | ix) & 1) == 0))) {
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
         v = (n * p.Hin + sy) * p.Win + sx;
       }

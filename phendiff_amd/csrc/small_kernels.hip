@@ -221,6 +221,7 @@ __global__ __launch_bounds__(1024) void gn_finalize2_kernel(const pd_gn_finalize
     if (var < 0.0) var = 0.0;
     mean_s[tid] = (float)mean;
     rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    if (a.mean) { a.mean[n * a.groups + g_lo + tid] = mean_s[tid]; a.rstd[n * a.groups + g_lo + tid] = rstd_s[tid]; }
   }
   __syncthreads();
   for (int c = c_lo + tid; c < c_hi; c += 1024) {
@@ -359,6 +360,7 @@ extern "C" int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream) {
   PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0, PD_ERR_SHAPE, "pd_gn_finalize: groups=%d C=%d", a->groups, C);
   PD_CHECK(a->stats0 && a->gamma && a->beta && a->scale && a->shift, PD_ERR_ARG, "pd_gn_finalize: null pointer");
   PD_CHECK((a->C1 == 0) == (a->stats1 == nullptr) && (a->C1 == 0 || a->T1 > 0), PD_ERR_ARG, "pd_gn_finalize: stats1/C1 mismatch");
+  PD_CHECK((a->mean == nullptr) == (a->rstd == nullptr), PD_ERR_ARG, "pd_gn_finalize: mean/rstd must be given together");
   const int gs = C / a->groups;
   const int CB = (96 % gs == 0) ? 96 : C;          // channel block of whole groups
   hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->B, (C + CB - 1) / CB), dim3(1024), 0, (hipStream_t)stream, *a, CB);

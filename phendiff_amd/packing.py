@@ -24,3 +24,9 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cout_pad: int | None =
     # [ct, r, chunk, s, h, j, tap] -> [ct, chunk, tap, s, h, r, j]
     wf = wf.reshape(cp // 32, 32, cin // 32, 2, 2, 8, taps).permute(0, 2, 6, 3, 4, 1, 5).contiguous()
     return wf.reshape(cp // 32, cin // 32, taps, 2, 64, 8).to(dtype)
+
+
+def dgrad_weight(w: torch.Tensor) -> torch.Tensor:
+    """Weight of the input-gradient convolution: for y = conv(x, W) (stride 1, "same" padding),
+    dx = conv(dy, W') with W'[ci, co, ky, kx] = W[co, ci, K-1-ky, K-1-kx]  (transpose + spatial flip)."""
+    return w.permute(1, 0, 2, 3).flip(2, 3).contiguous()
