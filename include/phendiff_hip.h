@@ -261,6 +261,32 @@ int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream);
 typedef struct { int dtype; int B, HW, C; const void* x; float* out; int out_stride; int accumulate; } pd_channel_sum_args;
 int pd_channel_sum(const pd_channel_sum_args* a, void* stream);
 
+/* pd_conv_wgrad: weight gradient of a convolution pd_conv ran in the forward:
+ *   dw[co][ci][ky][kx] (+)= sum_{n,oy,ox} dy[n][oy][ox][co] * Z[n][oy*stride+ky-pad][ox*stride+kx-pad][ci],
+ * Z = silu?(scale*[x0|x1] + shift) (optionally nearest-x2 upsampled) rebuilt on the fly exactly as pd_conv's staging does.
+ * B/Hin/.../pad/upsample/silu/x0/x1/scale/shift have pd_conv's meaning (upsample: 0 or 1).  dy is NHWC with channel stride
+ * Cout (multiple of 8); dw is the fp32 OIHW gradient [Cout_valid][Cin_valid][k][k] (Cout_valid/Cin_valid = 0: all channels).
+ * slab: workspace of slab_bytes >= pd_conv_wgrad_workspace(a) (smaller is accepted down to one split, at lower occupancy);
+ * the partial sums are reduced in a fixed order: results are bitwise reproducible. */
+typedef struct {
+  int dtype;
+  int B, Hin, Win, Hout, Wout;
+  int C0, C1, Cout;
+  int ksize, stride, pad, upsample, silu;
+  const void* x0; const void* x1;
+  const float* scale; const float* shift;
+  const void* dy;
+  float* slab; size_t slab_bytes;
+  float* dw; int Cout_valid, Cin_valid; int accumulate;
+} pd_wgrad_args;
+size_t pd_conv_wgrad_workspace(const pd_wgrad_args* a);
+int pd_conv_wgrad(const pd_wgrad_args* a, void* stream);
+
+/* pd_im2col3: out[n][y][x][ci*9+ky*3+kx] = x[n][ci][y+ky-1][x+kx-1] (zero padded; 27 of 32 channels used): the input of
+ * conv_in seen as a 1x1 convolution, for its weight gradient (cond_unet_2d.py:127-129). x: NCHW fp32, C <= 3; out: NHWC dtype. */
+typedef struct { int dtype; int B, H, W, C; const float* x; void* out; } pd_im2col3_args;
+int pd_im2col3(const pd_im2col3_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-step building blocks.  The UNet backward is not built yet; these are the fused
  * bandwidth-bound passes around it, on flat fp32 buffers.

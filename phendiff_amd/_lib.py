@@ -70,6 +70,18 @@ class ChannelSumArgs(C.Structure):
                 ("out_stride", C.c_int), ("accumulate", C.c_int)]
 
 
+class WgradArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+                ("C0", C.c_int), ("C1", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+                ("upsample", C.c_int), ("silu", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("dy", vp),
+                ("slab", vp), ("slab_bytes", C.c_size_t), ("dw", vp), ("Cout_valid", C.c_int), ("Cin_valid", C.c_int),
+                ("accumulate", C.c_int)]
+
+
+class Im2col3Args(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("x", vp), ("out", vp)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("N", C.c_int),
                 ("q", vp), ("k", vp), ("v", vp), ("out", vp)]
@@ -122,6 +134,9 @@ SYMBOLS = {
     "pd_gn_silu_bwd": (C.c_int, [C.POINTER(GnBwdArgs), vp]),
     "pd_pool2x2_sum": (C.c_int, [C.POINTER(Pool2x2Args), vp]),
     "pd_channel_sum": (C.c_int, [C.POINTER(ChannelSumArgs), vp]),
+    "pd_conv_wgrad_workspace": (C.c_size_t, [C.POINTER(WgradArgs)]),
+    "pd_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
+    "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),
     "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),
     "pd_grad_norm": (C.c_int, [vp, C.c_int64, vp, C.c_float, vp, vp, vp]),
     "pd_adamw_ema": (C.c_int, [C.POINTER(AdamWEmaArgs), vp]),

@@ -16,6 +16,7 @@
 #include <type_traits>
 #include <stdio.h>
 #include "pd_common.h"
+#include "pd_stage.h"
 
 namespace pd {
 
@@ -42,7 +43,6 @@ struct ConvP {
   int C0r;
 };
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Ablation switches for diagnostic builds (scripts/ablate_conv.sh); never defined in the shipped library.
 #ifdef PD_ABL_W0
@@ -64,54 +64,6 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 #else
 #define PD_STAMP(k) do {} while (0)
 #endif
-constexpr unsigned OOB_OFF = 0xC0000000u;   // > any tensor we accept (< 2 GiB): buffer loads return 0
-
-template <typename T> struct Stage;
-template <> struct Stage<bf16_t> {
-  struct R { u32x4 v; };
-  static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
-    R r; r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); return r;
-  }
-  // y = silu?(x*sc + sh) on 8 packed bf16, zeroed when !valid
-  static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
-                                                     bool affine, bool silu, bool valid) {
-    u32x4 o = in.v;
-    if (affine || silu) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float lo = __uint_as_float(in.v[j] << 16), hi = __uint_as_float(in.v[j] & 0xffff0000u);
-        if (affine) { lo = lo * sc[2 * j] + sh[2 * j]; hi = hi * sc[2 * j + 1] + sh[2 * j + 1]; }
-        if (silu) { lo = silu_fast(lo); hi = silu_fast(hi); }
-        o[j] = pack2bf(lo, hi);
-      }
-      if (!valid) o = (u32x4)(0u);
-    }
-    *(u32x4*)dst = o;
-  }
-};
-template <> struct Stage<float> {
-  struct R { u32x4 a, b; };
-  static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
-    R r; r.a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); r.b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
-    return r;
-  }
-  static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
-                                                     bool affine, bool silu, bool valid) {
-    u32x4 oa = in.a, ob = in.b;
-    if (affine || silu) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = __uint_as_float(in.a[j]), y = __uint_as_float(in.b[j]);
-        if (affine) { x = x * sc[j] + sh[j]; y = y * sc[4 + j] + sh[4 + j]; }
-        if (silu) { x = silu_f(x); y = silu_f(y); }   // parity mode: accurate division
-        oa[j] = __float_as_uint(x); ob[j] = __float_as_uint(y);
-      }
-      if (!valid) { oa = (u32x4)(0u); ob = (u32x4)(0u); }
-    }
-    *(u32x4*)dst = oa; *((u32x4*)dst + 1) = ob;
-  }
-};
-
 template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");

@@ -1,0 +1,60 @@
+// Global -> register -> LDS staging pieces shared by the forward implicit-GEMM conv (conv_igemm.hip) and the
+// weight-gradient kernel (wgrad.hip): 8-channel pieces loaded with buffer loads (out-of-range offset -> zeros) and written
+// to LDS through the GroupNorm affine (+ SiLU) the consuming convolution sees.
+#pragma once
+#include "pd_common.h"
+
+namespace pd {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB_OFF = 0xC0000000u;   // > any tensor we accept (< 2 GiB): buffer loads return 0
+
+template <typename T> struct Stage;
+template <> struct Stage<bf16_t> {
+  struct R { u32x4 v; };
+  static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    R r; r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); return r;
+  }
+  // y = silu?(x*sc + sh) on 8 packed bf16, zeroed when !valid
+  static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
+                                                     bool affine, bool silu, bool valid) {
+    u32x4 o = in.v;
+    if (affine || silu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = __uint_as_float(in.v[j] << 16), hi = __uint_as_float(in.v[j] & 0xffff0000u);
+        if (affine) { lo = lo * sc[2 * j] + sh[2 * j]; hi = hi * sc[2 * j + 1] + sh[2 * j + 1]; }
+        if (silu) { lo = silu_fast(lo); hi = silu_fast(hi); }
+        o[j] = pack2bf(lo, hi);
+      }
+      if (!valid) o = (u32x4)(0u);
+    }
+    *(u32x4*)dst = o;
+  }
+};
+template <> struct Stage<float> {
+  struct R { u32x4 a, b; };
+  static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    R r; r.a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); r.b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+    return r;
+  }
+  static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
+                                                     bool affine, bool silu, bool valid) {
+    u32x4 oa = in.a, ob = in.b;
+    if (affine || silu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = __uint_as_float(in.a[j]), y = __uint_as_float(in.b[j]);
+        if (affine) { x = x * sc[j] + sh[j]; y = y * sc[4 + j] + sh[4 + j]; }
+        if (silu) { x = silu_f(x); y = silu_f(y); }   // parity mode: accurate division
+        oa[j] = __float_as_uint(x); ob[j] = __float_as_uint(y);
+      }
+      if (!valid) { oa = (u32x4)(0u); ob = (u32x4)(0u); }
+    }
+    *(u32x4*)dst = oa; *((u32x4*)dst + 1) = ob;
+  }
+};
+
+
+}  // namespace pd

@@ -1,0 +1,399 @@
+// pd_conv_wgrad: weight gradient of the convolutions pd_conv runs in the forward (autograd of nn.Conv2d / nn.Linear at the
+// call sites listed in include/phendiff_hip.h), as an MFMA GEMM whose K dimension is the pixel index:
+//     dW[co][ci][ky][kx] = sum over (n, oy, ox) of dY[n][oy][ox][co] * Z[n][oy*s + ky - pad][ox*s + kx - pad][ci]
+// Z is the tensor the forward convolution consumed, i.e. silu?(scale*x + shift) of [x0 | x1] (optionally nearest-x2
+// upsampled); it is rebuilt in the staging pass exactly as pd_conv builds it, never materialised in HBM.
+//
+// Workgroup = 4 waves = a 64(co) x 64(ci) x taps weight tile; wave (cf, cif) owns the 32x32xtaps sub-tile in
+// 16*taps accumulator registers (144 for 3x3).  The workgroup walks a contiguous range of 16-pixel-wide output tiles
+// (its "split" of the K dimension): per tile dY [TH*16 px][64 co] and the Z halo tile [(TH-1)s+k][(16-1)s+k][64 ci] are
+// staged NHWC into LDS as two 32-channel planes with 64-byte pixels (conflict-free for the transposed reads), and both
+// MFMA operands -- which need 8 consecutive PIXELS per lane for a fixed channel -- are fetched with ds_read_b64_tr_b16:
+// the lanes supply per-pixel row addresses, so a filter tap is just an immediate offset on the Z address and the 9 taps
+// reuse one dY fragment.  fp32 validation mode reads the same image with ds_read_b32 and runs the exact-fp32 MFMA.
+// Each workgroup leaves its partial tile in a slab [split][tap][co][ci]; pd_wgrad_reduce sums the splits in a fixed order
+// (bitwise reproducible, no atomics) into the OIHW fp32 gradient buffer.
+#include "pd_common.h"
+#include "pd_stage.h"
+
+namespace pd {
+
+struct WgradP {
+  int B, Hin, Win, Hout, Wout, C0, C1, Cout, pad, upsample, silu;
+  int tiles_x, tiles_y, ntiles, tiles_per_split, n_ci_t, n_co_t, splits, nwork;
+  int COP, CIP;                    // slab dims (multiples of 64)
+  unsigned bytes0, bytes1, bytesdy;
+  const void* x0; const void* x1;
+  const float* scale; const float* shift;
+  const void* dy;
+  float* slab;
+};
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+template <typename T> struct FragLd;
+template <> struct FragLd<bf16_t> {
+  // lane base address: pixel 8h+q, channels 16*cg + 4*pp (see file header); second read 4 pixels further
+  static __device__ __forceinline__ unsigned lane_off(int lane, int pitch) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    return (unsigned)((8 * (g >> 1) + q) * pitch + (16 * (g & 1) + 4 * pp) * 2);
+  }
+  template <int PITCH>
+  static __device__ __forceinline__ Elem<bf16_t>::Frag load(const unsigned char* base) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lp;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + 4 * PITCH));
+    Elem<bf16_t>::Frag f;
+    f.v = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+  }
+};
+template <> struct FragLd<float> {
+  static __device__ __forceinline__ unsigned lane_off(int lane, int pitch) {
+    return (unsigned)(8 * (lane >> 5) * pitch + (lane & 31) * 4);
+  }
+  template <int PITCH>
+  static __device__ __forceinline__ Elem<float>::Frag load(const unsigned char* base) {
+    Elem<float>::Frag f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.lo[j] = *(const float*)(base + j * PITCH); f.hi[j] = *(const float*)(base + (4 + j) * PITCH); }
+    return f;
+  }
+};
+
+template <typename T, int KS, int STRIDE, int TH>
+struct WgradCfg {
+  static constexpr int TW = 16, TP = TH * TW, TAPS = KS * KS;
+  static constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS, NPIX = HH * HWD;
+  static constexpr int PXB = 32 * Elem<T>::BYTES;                       // one pixel of a 32-channel plane
+  static constexpr int ZP = PXB + (STRIDE == 2 ? PXB / 2 : 0);         // stride 2: 96-B pixels keep every other pixel conflict-free
+  static constexpr int DY_PLANE = TP * PXB;
+  static constexpr int Z_PLANE = ((NPIX * ZP + 15) / 16) * 16;
+  static constexpr int DY_BASE = 0, Z_BASE = 2 * DY_PLANE, SCSH_BASE = Z_BASE + 2 * Z_PLANE;
+  static constexpr int LDS_BYTES = SCSH_BASE + 128 * 4;
+  static constexpr int NITD = (TP * 8 + 255) / 256;
+  static constexpr int NITZ = (NPIX * 4 + 255) / 256;
+};
+
+template <typename T, int KS, int STRIDE, int TH>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  using SR = typename Stage<T>::R;
+  using Cf = WgradCfg<T, KS, STRIDE, TH>;
+  constexpr int TW = Cf::TW, TAPS = Cf::TAPS, HWD = Cf::HWD, NPIX = Cf::NPIX, PXB = Cf::PXB, ZP = Cf::ZP;
+  constexpr int NITD = Cf::NITD, NITZ = Cf::NITZ;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  // ---- block -> work item: consecutive work items (the weight tiles of one pixel split) share an XCD / L2
+  const unsigned nb = gridDim.x;                 // multiple of 8
+  const int L = (int)((blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3));
+  if (L >= p.nwork) return;
+  const int ncombo = p.n_co_t * p.n_ci_t;
+  const int split = L / ncombo, combo = L - split * ncombo;
+  const int ct = combo / p.n_ci_t, cc = combo - ct * p.n_ci_t;
+  const int co0 = ct * 64, ci0 = cc * 64;
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(p.ntiles, t_begin + p.tiles_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cf = wave & 1, cif = wave >> 1;
+  const int cin = p.C0 + p.C1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0, 0, p.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1 ? p.x1 : p.x0), 0, p.x1 ? p.bytes1 : p.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.bytesdy, 0x00020000);
+
+  // per-plane source of the 64 input channels of this weight tile: 0 = x0, 1 = x1, 2 = beyond the input (zeros)
+  int psrc[2], pch[2], pcs[2];
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    const int c = ci0 + 32 * pl;
+    psrc[pl] = c < p.C0 ? 0 : (c < cin ? 1 : 2);
+    pch[pl] = c < p.C0 ? c : c - p.C0;
+    pcs[pl] = c < p.C0 ? p.C0 : p.C1;
+  }
+  const bool affine = p.scale != nullptr;
+  const bool do_silu = p.silu != 0;
+  const int Hc = p.upsample ? p.Hin * 2 : p.Hin, Wc = p.upsample ? p.Win * 2 : p.Win;
+  const int sub4 = tid & 3;
+
+  SR sdy[NITD], sz[2][NITZ];
+  unsigned zvalid = 0;      // bit (pl*NITZ + i): the piece is an in-image pixel
+  int n_staged = -1;        // sample whose scale/shift sit in LDS
+  int n_next = -1;
+  float scsh_reg = 0.f;
+
+  auto decode = [&](int t, int& n, int& oy0, int& ox0) {
+    const int per = p.tiles_x * p.tiles_y;
+    n = t / per;
+    const int rem = t - n * per;
+    const int ty = rem / p.tiles_x;
+    oy0 = ty * TH; ox0 = (rem - ty * p.tiles_x) * TW;
+  };
+
+  auto issue = [&](int t) {
+    int n, oy0, ox0;
+    decode(t, n, oy0, ox0);
+    n_next = n;
+#pragma unroll
+    for (int i = 0; i < NITD; ++i) {
+      const int q = tid + 256 * i, pix = q >> 3, sub = q & 7;
+      const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+      const bool ok = pix < Cf::TP && oy < p.Hout && ox < p.Wout && (co0 + sub * 8) < p.Cout;
+      const unsigned off = ok ? (unsigned)((((n * p.Hout + oy) * p.Wout + ox) * p.Cout + co0 + sub * 8) * E::BYTES) : OOB_OFF;
+      sdy[i] = Stage<T>::load(rsd, off);
+    }
+    zvalid = 0;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int i = 0; i < NITZ; ++i) {
+        const int q = tid + 256 * i, pix = q >> 2;
+        unsigned off = OOB_OFF;
+        if (pix < NPIX && psrc[pl] < 2) {
+          const int u = pix / HWD, v = pix - u * HWD;
+          const int iy = oy0 * STRIDE - p.pad + u, ix = ox0 * STRIDE - p.pad + v;
+          if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) {
+            const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+            off = (unsigned)((((n * p.Hin + sy) * p.Win + sx) * pcs[pl] + pch[pl] + sub4 * 8) * E::BYTES);
+            zvalid |= 1u << (pl * NITZ + i);
+          }
+        }
+        sz[pl][i] = psrc[pl] == 0 ? Stage<T>::load(rs0, off) : Stage<T>::load(rs1, off);
+      }
+    }
+    if (affine && n != n_staged && tid < 128) {
+      const int c = ci0 + (tid & 63);
+      scsh_reg = c < cin ? (tid < 64 ? p.scale : p.shift)[(size_t)n * cin + c] : 0.f;
+    }
+  };
+
+  auto write_tile = [&]() {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NITD; ++i) {
+      const int q = tid + 256 * i, pix = q >> 3, sub = q & 7;
+      if (pix < Cf::TP)
+        Stage<T>::xform_store(lds + Cf::DY_BASE + (sub >> 2) * Cf::DY_PLANE + pix * PXB + (sub & 3) * 8 * E::BYTES, sdy[i], sc, sh,
+                              false, false, true);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      if (affine) {
+        const float* ps = (const float*)(lds + Cf::SCSH_BASE) + pl * 32 + sub4 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = ps[j]; sh[j] = ps[64 + j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < NITZ; ++i) {
+        const int q = tid + 256 * i, pix = q >> 2;
+        if (pix < NPIX)
+          Stage<T>::xform_store(lds + Cf::Z_BASE + pl * Cf::Z_PLANE + pix * ZP + sub4 * 8 * E::BYTES, sz[pl][i], sc, sh, affine,
+                                do_silu, (zvalid >> (pl * NITZ + i)) & 1u);
+      }
+    }
+  };
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int k = 0; k < TAPS; ++k) acc[k] = (f32x16)(0.f);
+
+  const unsigned char* a_base = lds + Cf::DY_BASE + cf * Cf::DY_PLANE + FragLd<T>::lane_off(lane, PXB);
+  const unsigned char* b_base = lds + Cf::Z_BASE + cif * Cf::Z_PLANE + FragLd<T>::lane_off(lane, STRIDE * ZP);
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int y = 0; y < TH; ++y) {
+      const Frag a = FragLd<T>::template load<PXB>(a_base + y * TW * PXB);
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const Frag b = FragLd<T>::template load<STRIDE * ZP>(b_base + ((y * STRIDE + ky) * HWD + kx) * ZP);
+          acc[ky * KS + kx] = E::mma(a, b, acc[ky * KS + kx]);
+        }
+    }
+  };
+
+  auto publish_scsh = [&]() {     // workgroup-uniform: the next tile belongs to another sample
+    if (affine && n_next != n_staged) {
+      if (tid < 128) ((float*)(lds + Cf::SCSH_BASE))[tid] = scsh_reg;
+      n_staged = n_next;
+      __syncthreads();
+    }
+  };
+
+  if (t_begin < t_end) {
+    issue(t_begin);
+    publish_scsh();
+    write_tile();
+    __syncthreads();
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool have_next = t + 1 < t_end;
+    if (have_next) issue(t + 1);
+    __builtin_amdgcn_s_setprio(1);
+    compute();
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (have_next) { publish_scsh(); write_tile(); }
+    __syncthreads();
+  }
+
+  // ---- partial tile -> slab[split][tap][co][ci]
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int k = 0; k < TAPS; ++k) {
+    float* out = p.slab + (((size_t)split * TAPS + k) * p.COP + co0 + cf * 32) * p.CIP + ci0 + cif * 32 + r;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) out[(size_t)((g & 3) + 8 * (g >> 2) + 4 * h) * p.CIP] = acc[k][g];
+  }
+}
+
+// dw[co][ci][tap] (+)= sum over splits of slab[split][tap][co][ci]; thread = (co, ci)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int taps,
+                                                            int COP, int CIP, int cout_valid, int cin_valid, int accumulate) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cout_valid * cin_valid) return;
+  const int co = idx / cin_valid, ci = idx - co * cin_valid;
+  for (int k = 0; k < taps; ++k) {
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += slab[(((size_t)sp * taps + k) * COP + co) * CIP + ci];
+    float* o = dw + ((size_t)co * cin_valid + ci) * taps + k;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// 3x3 taps of a <=3-channel fp32 NCHW image gathered into 32 channels k = ci*9 + ky*3 + kx (NHWC): the input the forward's
+// conv_in im2col mode builds in LDS, materialised for the weight gradient of conv_in (cond_unet_2d.py:127-129)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H, int W, int Cr) {
+  const size_t total = (size_t)B * H * W * 4;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int sub = (int)(idx & 3);
+    size_t pix = idx >> 2;
+    const int xx = (int)(pix % W); pix /= W;
+    const int yy = (int)(pix % H); const int n = (int)(pix / H);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = sub * 8 + j, ci = k / 9, tap = k - ci * 9, ky = tap / 3, kx = tap - ky * 3;
+      const int iy = yy + ky - 1, ix = xx + kx - 1;
+      v[j] = (ci < Cr && iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)n * Cr + ci) * H + iy) * W + ix] : 0.f;
+    }
+    Elem<T>::store(out + (idx >> 2) * 32 + sub * 8, Elem<T>::pack(v));
+  }
+}
+
+static int pick_splits(int ntiles, int ncombo) {
+  int want = (512 + ncombo - 1) / ncombo;          // fill 256 CUs x 2 resident workgroups
+  int amort = ntiles / 8 > 1 ? ntiles / 8 : 1;      // >= 8 pixel tiles per slab written
+  int s = want < amort ? want : amort;
+  if (s > ntiles) s = ntiles;
+  return s < 1 ? 1 : s;
+}
+
+template <typename T, int KS, int STRIDE, int TH>
+static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
+  using Cf = WgradCfg<T, KS, STRIDE, TH>;
+  static_assert(Cf::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+  WgradP p;
+  p.B = a->B; p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout; p.C0 = a->C0; p.C1 = a->C1; p.Cout = a->Cout;
+  p.pad = a->pad; p.upsample = a->upsample; p.silu = a->silu;
+  p.tiles_x = (a->Wout + Cf::TW - 1) / Cf::TW; p.tiles_y = (a->Hout + TH - 1) / TH;
+  p.ntiles = a->B * p.tiles_x * p.tiles_y;
+  const int cin = a->C0 + a->C1;
+  p.n_co_t = (a->Cout + 63) / 64; p.n_ci_t = (cin + 63) / 64;
+  p.COP = p.n_co_t * 64; p.CIP = p.n_ci_t * 64;
+  const int ncombo = p.n_co_t * p.n_ci_t;
+  const size_t per_split = (size_t)Cf::TAPS * p.COP * p.CIP * sizeof(float);
+  int splits = pick_splits(p.ntiles, ncombo);
+  if ((size_t)splits * per_split > a->slab_bytes) splits = (int)(a->slab_bytes / per_split);
+  PD_CHECK(splits >= 1, PD_ERR_ARG, "pd_conv_wgrad: slab of %zu bytes cannot hold one split (%zu bytes)", a->slab_bytes, per_split);
+  p.splits = splits;
+  p.tiles_per_split = (p.ntiles + splits - 1) / splits;
+  p.nwork = splits * ncombo;
+  const size_t es = sizeof(T);
+  p.bytes0 = (unsigned)((size_t)a->B * a->Hin * a->Win * a->C0 * es);
+  p.bytes1 = (unsigned)((size_t)a->B * a->Hin * a->Win * a->C1 * es);
+  p.bytesdy = (unsigned)((size_t)a->B * a->Hout * a->Wout * a->Cout * es);
+  p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.dy = a->dy; p.slab = a->slab;
+  auto kern = wgrad_kernel<T, KS, STRIDE, TH>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES) != hipSuccess) {
+      set_error("pd_conv_wgrad: cannot reserve %d bytes of LDS", Cf::LDS_BYTES);
+      return PD_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)((p.nwork + 7) / 8 * 8);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cf::LDS_BYTES, st, p);
+  PD_LAUNCH_CHECK();
+  const int cout_v = a->Cout_valid > 0 ? a->Cout_valid : a->Cout, cin_v = a->Cin_valid > 0 ? a->Cin_valid : cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cout_v * cin_v + 255) / 256), dim3(256), 0, st, (const float*)a->slab, a->dw, splits,
+                     Cf::TAPS, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+}  // namespace pd
+
+using namespace pd;
+
+extern "C" size_t pd_conv_wgrad_workspace(const pd_wgrad_args* a) {
+  if (!a || a->ksize < 1 || a->B < 1) return 0;
+  const int th = (a->dtype == PD_BF16 ? 8 : 4) / (a->stride == 2 ? 2 : 1);
+  const int ntiles = a->B * ((a->Wout + 15) / 16) * ((a->Hout + th - 1) / th);
+  const int nco = (a->Cout + 63) / 64, nci = (a->C0 + a->C1 + 63) / 64;
+  return (size_t)pick_splits(ntiles, nco * nci) * a->ksize * a->ksize * nco * 64 * nci * 64 * sizeof(float);
+}
+
+extern "C" int pd_conv_wgrad(const pd_wgrad_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_conv_wgrad: null args");
+  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16, PD_ERR_ARG, "pd_conv_wgrad: bad dtype");
+  PD_CHECK(a->B > 0 && a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0, PD_ERR_SHAPE, "pd_conv_wgrad: bad shape");
+  PD_CHECK(a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: C0=%d C1=%d must be multiples of 32", a->C0, a->C1);
+  PD_CHECK(a->Cout > 0 && a->Cout % 8 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: Cout=%d (channel stride of dy) must be a multiple of 8", a->Cout);
+  PD_CHECK((a->ksize == 3 && (a->stride == 1 || a->stride == 2)) || (a->ksize == 1 && a->stride == 1 && a->pad == 0), PD_ERR_SHAPE,
+           "pd_conv_wgrad: unsupported ksize=%d stride=%d", a->ksize, a->stride);
+  PD_CHECK(!(a->upsample && a->stride != 1) && (a->upsample == 0 || a->upsample == 1), PD_ERR_SHAPE, "pd_conv_wgrad: bad upsample");
+  const int hc = a->upsample ? 2 * a->Hin : a->Hin, wc = a->upsample ? 2 * a->Win : a->Win;
+  const int extra = (a->ksize == 3 && a->pad == 0) ? 1 : 0;
+  PD_CHECK(a->pad == 0 || a->pad == 1, PD_ERR_SHAPE, "pd_conv_wgrad: pad=%d", a->pad);
+  PD_CHECK(a->Hout == (hc + 2 * a->pad + extra - a->ksize) / a->stride + 1 && a->Wout == (wc + 2 * a->pad + extra - a->ksize) / a->stride + 1,
+           PD_ERR_SHAPE, "pd_conv_wgrad: Hout/Wout inconsistent with the forward convolution");
+  PD_CHECK(a->x0 && a->dy && a->slab && a->dw, PD_ERR_ARG, "pd_conv_wgrad: null pointer");
+  PD_CHECK((a->C1 == 0) == (a->x1 == nullptr), PD_ERR_ARG, "pd_conv_wgrad: x1/C1 mismatch");
+  PD_CHECK((a->scale == nullptr) == (a->shift == nullptr), PD_ERR_ARG, "pd_conv_wgrad: scale/shift must be given together");
+  const size_t es = a->dtype == PD_F32 ? 4 : 2;
+  const size_t lim = (size_t)1 << 31;
+  PD_CHECK((size_t)a->B * a->Hin * a->Win * (a->C0 > a->C1 ? a->C0 : a->C1) * es < lim && (size_t)a->B * a->Hout * a->Wout * a->Cout * es < lim,
+           PD_ERR_SHAPE, "pd_conv_wgrad: tensors must be < 2 GiB (32-bit buffer offsets)");
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PD_BF16) {
+    if (a->ksize == 1) return launch_wgrad<bf16_t, 1, 1, 8>(a, st);
+    if (a->stride == 1) return launch_wgrad<bf16_t, 3, 1, 8>(a, st);
+    return launch_wgrad<bf16_t, 3, 2, 4>(a, st);
+  }
+  if (a->ksize == 1) return launch_wgrad<float, 1, 1, 4>(a, st);
+  if (a->stride == 1) return launch_wgrad<float, 3, 1, 4>(a, st);
+  return launch_wgrad<float, 3, 2, 2>(a, st);
+}
+
+extern "C" int pd_im2col3(const pd_im2col3_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->B > 0 && a->H > 0 && a->W > 0 && a->C >= 1 && a->C <= 3 && a->x && a->out, PD_ERR_ARG, "pd_im2col3: bad args");
+  const size_t total = (size_t)a->B * a->H * a->W * 4;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(im2col3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (float*)a->out, a->B, a->H, a->W, a->C);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(im2col3_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (bf16_t*)a->out, a->B, a->H, a->W, a->C);
+  else { set_error("pd_im2col3: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}

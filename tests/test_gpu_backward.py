@@ -128,3 +128,112 @@ def test_channel_sum(env, mode):
     torch.cuda.synchronize()
     assert rel(out.cpu()[:, :96] - 1.0, x.sum((2, 3))) < 1e-5
     assert torch.equal(out.cpu()[:, 96:], torch.ones(3, 32))
+
+
+def run_wgrad(env, mode, x0, dy, *, x1=None, ksize=3, stride=1, pad=1, upsample=0, silu=0, scale=None, shift=None,
+              cout_valid=0, cin_valid=0, prev=None, slab_splits=None):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, c0, hin, win = x0.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout, hout, wout = dy.shape[1], dy.shape[2], dy.shape[3]
+    X0 = nhwc(x0.to(dev), tdt)
+    X1 = nhwc(x1.to(dev), tdt) if x1 is not None else None
+    DY = nhwc(dy.to(dev), tdt)
+    sc = scale.to(dev).float().contiguous() if scale is not None else None
+    sh = shift.to(dev).float().contiguous() if shift is not None else None
+    cov, civ = cout_valid or cout, cin_valid or (c0 + c1)
+    dw = (prev.clone().to(dev) if prev is not None else torch.full((cov, civ, ksize, ksize), float("nan"), device=dev))
+    a = L.WgradArgs(dtype=code, B=B, Hin=hin, Win=win, Hout=hout, Wout=wout, C0=c0, C1=c1, Cout=cout, ksize=ksize, stride=stride,
+                    pad=pad, upsample=upsample, silu=silu, x0=X0.data_ptr(), x1=L.ptr(X1), scale=L.ptr(sc), shift=L.ptr(sh),
+                    dy=DY.data_ptr(), dw=dw.data_ptr(), Cout_valid=cout_valid, Cin_valid=cin_valid,
+                    accumulate=int(prev is not None))
+    want = lib.pd_conv_wgrad_workspace(C.byref(a))
+    assert want > 0
+    nbytes = want if slab_splits is None else slab_splits * ksize * ksize * ((cout + 63) // 64 * 64) * ((c0 + c1 + 63) // 64 * 64) * 4
+    slab = torch.empty(nbytes // 4, device=dev)
+    a.slab, a.slab_bytes = slab.data_ptr(), nbytes
+    L.check(lib.pd_conv_wgrad(C.byref(a), stream()), "pd_conv_wgrad")
+    torch.cuda.synchronize()
+    return dw.cpu()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 32, 96, 16, 16), (3, 128, 64, 8, 8), (1, 64, 128, 40, 72), (2, 192, 32, 20, 12)])
+def test_conv_weight_gradient_3x3(env, mode, shape):
+    B, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    x = bf16_round(torch.randn(B, cin, H, W, generator=g), mode)
+    dy = bf16_round(torch.randn(B, cout, H, W, generator=g), mode)
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, None, padding=1), w, dy)
+    got = run_wgrad(env, mode, x, dy)
+    assert rel(got, ref) < (2e-5 if mode == "f32" else 1e-4)      # bf16 inputs are exact here: only the fp32 sum order differs
+    one_split = run_wgrad(env, mode, x, dy, slab_splits=1)
+    assert rel(one_split, ref) < (2e-5 if mode == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_conv_weight_gradient_fused_input_transform_and_concat(env, mode):
+    B, c0, c1, cout, H, W = 2, 64, 32, 64, 24, 16
+    g = torch.Generator().manual_seed(22)
+    x = bf16_round(torch.randn(B, c0 + c1, H, W, generator=g), mode)
+    scale, shift = torch.rand(B, c0 + c1, generator=g) + 0.5, torch.randn(B, c0 + c1, generator=g) * 0.3
+    dy = bf16_round(torch.randn(B, cout, H, W, generator=g), mode)
+    z = bf16_round(F.silu(x * scale[:, :, None, None] + shift[:, :, None, None]), mode)
+    w = torch.zeros(cout, c0 + c1, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(z, w, None, padding=1), w, dy)
+    prev = torch.randn(cout, c0 + c1, 3, 3, generator=g)
+    got = run_wgrad(env, mode, x[:, :c0], dy, x1=x[:, c0:], silu=1, scale=scale, shift=shift, prev=prev)
+    assert rel(got - prev, ref) < (2e-5 if mode == "f32" else 4e-3)    # bf16: fast SiLU + rounding of Z to bf16
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(32, 32), (16, 48), (8, 8)])
+def test_conv_weight_gradient_stride2(env, mode, hw):
+    H, W = hw
+    g = torch.Generator().manual_seed(23)
+    x = bf16_round(torch.randn(2, 64, H, W, generator=g), mode)
+    dy = bf16_round(torch.randn(2, 96, H // 2, W // 2, generator=g), mode)
+    w = torch.zeros(96, 64, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, None, stride=2, padding=1), w, dy)
+    got = run_wgrad(env, mode, x, dy, stride=2)
+    assert rel(got, ref) < (2e-5 if mode == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_conv_weight_gradient_upsample_and_1x1_and_padded_channels(env, mode):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    g = torch.Generator().manual_seed(24)
+    # conv fused with the nearest x2 upsample (Upsample2D)
+    x = bf16_round(torch.randn(2, 64, 8, 12, generator=g), mode)
+    dy = bf16_round(torch.randn(2, 64, 16, 24, generator=g), mode)
+    w = torch.zeros(64, 64, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, padding=1), w, dy)
+    assert rel(run_wgrad(env, mode, x, dy, upsample=1), ref) < (2e-5 if mode == "f32" else 1e-4)
+    # 1x1 (attention projections, shortcuts): [q|k|v] 3C output channels
+    x = bf16_round(torch.randn(2, 128, 8, 8, generator=g), mode)
+    dy = bf16_round(torch.randn(2, 384, 8, 8, generator=g), mode)
+    w = torch.zeros(384, 128, 1, 1, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w), w, dy)
+    assert rel(run_wgrad(env, mode, x, dy, ksize=1, pad=0), ref) < (2e-5 if mode == "f32" else 1e-4)
+    # conv_out: 3 real output channels in a 32-channel dy
+    x = bf16_round(torch.randn(2, 64, 16, 16, generator=g), mode)
+    dy = torch.zeros(2, 32, 16, 16)
+    dy[:, :3] = bf16_round(torch.randn(2, 3, 16, 16, generator=g), mode)
+    w = torch.zeros(3, 64, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, None, padding=1), w, dy[:, :3])
+    assert rel(run_wgrad(env, mode, x, dy, cout_valid=3), ref) < (2e-5 if mode == "f32" else 1e-4)
+    # conv_in: im2col3 + 1x1 over 27 (of 32) gathered channels
+    img = torch.randn(2, 3, 20, 24, generator=g)
+    dy = bf16_round(torch.randn(2, 64, 20, 24, generator=g), mode)
+    cols = torch.empty((2, 20, 24, 32), dtype=tdt, device=dev)
+    ximg = img.to(dev).contiguous()
+    a = L.Im2col3Args(dtype=code, B=2, H=20, W=24, C=3, x=ximg.data_ptr(), out=cols.data_ptr())
+    L.check(lib.pd_im2col3(C.byref(a), stream()), "pd_im2col3")
+    torch.cuda.synchronize()
+    w = torch.zeros(64, 3, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(bf16_round(img, mode), w, None, padding=1), w, dy)
+    got = run_wgrad(env, mode, cols.float().cpu().permute(0, 3, 1, 2), dy, ksize=1, pad=0, cin_valid=27)
+    assert rel(got.reshape(64, 3, 3, 3), ref) < (2e-5 if mode == "f32" else 1e-4)
