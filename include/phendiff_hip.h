@@ -175,8 +175,23 @@ typedef struct {
   int B, heads, N;
   const void* q; const void* k; const void* v;
   void* out;
+  float* lse;   /* optional out [B][heads][N]: log2-domain log-sum-exp of the scaled scores (kept for pd_attn_d8_bwd), or NULL */
 } pd_attn_args;
 int pd_attn_d8(const pd_attn_args* a, void* stream);
+
+/* pd_attn_d8_bwd: gradient of pd_attn_d8 (autograd of F.scaled_dot_product_attention), P recomputed from lse.
+ *   q, k, v: as the forward;  o: the forward's output, dout: gradient w.r.t. it (both NHWC [B][N][heads*8]);
+ *   delta: workspace [B][heads][N];  dqkv: out NHWC [B][N][3*heads*8] = [dq | dk | dv] (channel = which*C + head*8 + d),
+ *   the output-gradient layout of the fused q/k/v projection. */
+typedef struct {
+  int dtype;
+  int B, heads, N;
+  const void* q; const void* k; const void* v;
+  const void* o; const void* dout;
+  const float* lse; float* delta;
+  void* dqkv;
+} pd_attn_bwd_args;
+int pd_attn_d8_bwd(const pd_attn_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pd_ddim_step: one fused DDIM / inverse-DDIM update on NCHW fp32 tensors.

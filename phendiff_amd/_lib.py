@@ -84,7 +84,12 @@ class Im2col3Args(C.Structure):
 
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("N", C.c_int),
-                ("q", vp), ("k", vp), ("v", vp), ("out", vp)]
+                ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("N", C.c_int), ("q", vp), ("k", vp), ("v", vp),
+                ("o", vp), ("dout", vp), ("lse", vp), ("delta", vp), ("dqkv", vp)]
 
 
 class DdimStepArgs(C.Structure):
@@ -137,6 +142,7 @@ SYMBOLS = {
     "pd_conv_wgrad_workspace": (C.c_size_t, [C.POINTER(WgradArgs)]),
     "pd_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),
+    "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
     "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),
     "pd_grad_norm": (C.c_int, [vp, C.c_int64, vp, C.c_float, vp, vp, vp]),
     "pd_adamw_ema": (C.c_int, [C.POINTER(AdamWEmaArgs), vp]),

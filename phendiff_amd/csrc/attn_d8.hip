@@ -35,6 +35,12 @@ template <> struct AttnOps<bf16_t> {
     for (int j = 0; j < 8; ++j) { const float v = bf2f((bf16_t)q.v[j]); t += v * v; }
     return t;
   }
+  static __device__ __forceinline__ float dot(const QF& x, const QF& y) {   // this lane's share of sum_d x_d y_d
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += bf2f((bf16_t)x.v[j]) * bf2f((bf16_t)y.v[j]);
+    return t;
+  }
   // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
   static constexpr int KROW = 16;                 // bytes per K row in LDS
   static constexpr int KSTEP = 32 * KROW;         // bytes between consecutive 32-key sub-tiles
@@ -85,6 +91,9 @@ template <> struct AttnOps<float> {
   }
   static __device__ __forceinline__ float q_norm2(const QF& q) {
     return q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3];
+  }
+  static __device__ __forceinline__ float dot(const QF& x, const QF& y) {
+    return x.v[0] * y.v[0] + x.v[1] * y.v[1] + x.v[2] * y.v[2] + x.v[3] * y.v[3];
   }
   static constexpr int KROW = 32;
   static constexpr int KSTEP = 32 * KROW;
@@ -289,9 +298,237 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
     if (query[j] < N) {
       // lane (query, h): registers 0..3 = O^T rows 4h..4h+3 (d), register 4 = row 8 + 4h = l
       const float inv = 1.0f / o[j][4];
+      // log2-domain log-sum-exp of the scaled scores, kept for the backward (p = exp2(s' - lse))
+      if (a.lse && h == 0) a.lse[bh + query[j]] = m[j] + __builtin_amdgcn_logf(o[j][4]);
       T* dst = (T*)a.out + ((size_t)b * N + query[j]) * (a.heads * 8) + head * 8 + 4 * h;
       store4(dst, o[j][0] * inv, o[j][1] * inv, o[j][2] * inv, o[j][3] * inv);
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward (autograd of F.scaled_dot_product_attention, AttnProcessor2_0).  P is recomputed from the forward's
+// log-sum-exp; with head_dim 8 the exp, not the MFMA, prices a tile, so the pass is split in two kernels that each keep
+// their reduction lane-local instead of one kernel with atomics:
+//   dQ  kernel: query on the lane (forward's layout).  S^T = K.Q^T - lse, dP^T = V.dO^T - delta (both constants ride in the
+//               MFMA C operand), dS^T = exp2(S^T) * dP^T stays in registers as the B operand of dQ^T += K^T . dS^T.
+//   dKV kernel: key on the lane.  S = Q.K^T - lse[query], dP = dO.V^T - delta[query] (C operand read per query row from
+//               LDS), P and dS are the B operands of dV^T += dO^T . P and dK^T += Q^T . dS.
+// delta = rowsum(dO * O) is produced by the dQ kernel and reused by the dKV kernel (same stream).
+// Gradients land in one NHWC tensor [B][N][3*heads*8] = [dq | dk | dv], the layout of the fused q/k/v projection's output
+// gradient, so the projection's pd_conv (input gradient) and pd_conv_wgrad consume it directly.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pd_attn_bwd_args a) {
+  using E = Elem<T>;
+  using Ops = AttnOps<T>;
+  constexpr int KROW = Ops::KROW;
+  __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char vlds[2][KT * KROW + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char ktlds[2][9 * Ops::VT_PITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nqb = (a.N + 127) / 128;
+  const int total = nqb * a.heads * a.B;
+  int item = blockIdx.x;
+  if ((total & 7) == 0) item = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int qb = item % nqb;
+  const int head = (item / nqb) % a.heads, b = item / (nqb * a.heads);
+  const int N = a.N, C = a.heads * 8;
+  const size_t bh = ((size_t)b * a.heads + head) * N;
+  const T* kp = (const T*)a.k + bh * 8;
+  const T* vp = (const T*)a.v + bh * 8;
+  const float qscale = 0.35355339059327373f * 1.4426950408889634f;
+
+  const int query = qb * 128 + wave * 32 + r, qc = min(query, N - 1);
+  const typename Ops::QF qf = Ops::load_q((const T*)a.q + (bh + qc) * 8, h, qscale);
+  const typename Ops::QF dof = Ops::load_q((const T*)a.dout + ((size_t)b * N + qc) * C + head * 8, h, 1.0f);
+  const typename Ops::QF of = Ops::load_q((const T*)a.o + ((size_t)b * N + qc) * C + head * 8, h, 1.0f);
+  float delta = Ops::dot(dof, of);
+  delta += __shfl_xor(delta, 32);
+  if (h == 0 && query < N) a.delta[bh + query] = delta;
+  const f32x16 negl = (f32x16)(-a.lse[bh + qc]);
+  const f32x16 negd = (f32x16)(-delta);
+  f32x16 dq = (f32x16)(0.f);
+
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) {
+    if (tid == 0) { *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f); *(f32x4*)(vlds[b2] + KT * KROW) = (f32x4)(0.f); }
+    *(T*)(ktlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
+  }
+  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
+  const int ka0 = Ops::kaddr(r, h), kst = Ops::kstep(h);
+
+  typename E::Frag stk, stv;
+  auto issue = [&](int k0) {
+    const int key = k0 + tid;
+    if (key < N) { stk = E::load(kp + (size_t)key * 8); stv = E::load(vp + (size_t)key * 8); }
+    else { stk = E::zero(); stv = E::zero(); }
+  };
+  auto commit = [&](int b2) {
+    E::store(klds[b2] + tid * KROW, stk);
+    E::store(vlds[b2] + tid * KROW, stv);
+    float kv[8];
+    E::unpack(stk, kv);
+    const int vp_ = Ops::vpos(tid);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) *(T*)(ktlds[b2] + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(kv[d]);
+  };
+  auto body = [&](const unsigned char* kl, const unsigned char* vl, const unsigned char* ktrow, int sub) {
+    const typename Ops::KF kf = Ops::load_k(kl + ka0 + sub * kst);
+    const typename Ops::KF vf = Ops::load_k(vl + ka0 + sub * kst);
+    const typename Ops::VF ktf = Ops::load_v(ktrow, sub * 32);
+    f32x16 s = Ops::qk(kf, qf, negl);
+    const f32x16 dp = Ops::qk(vf, dof, negd);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]) * dp[i];
+    dq = Ops::pv(ktf, s, dq);
+  };
+
+  issue(0);
+  commit(0);
+  if (KT < N) issue(KT);
+  __syncthreads();
+  for (int k0 = 0, cur = 0; k0 < N; k0 += KT, cur ^= 1) {
+    const unsigned char* kl = klds[cur];
+    const unsigned char* vl = vlds[cur];
+    const unsigned char* ktrow = ktlds[cur] + vrow_off;
+    if (k0 + KT <= N) {
+#pragma unroll
+      for (int sub = 0; sub < KT / 32; ++sub) body(kl, vl, ktrow, sub);
+    } else {
+#pragma unroll 1
+      for (int sub = 0; sub < KT / 32 && k0 + sub * 32 < N; ++sub) body(kl, vl, ktrow, sub);   // padded keys: K^T columns are zero
+    }
+    if (k0 + KT < N) {
+      commit(cur ^ 1);
+      if (k0 + 2 * KT < N) issue(k0 + 2 * KT);
+    }
+    __syncthreads();
+  }
+  if (query < N) {
+    const float sc = 0.35355339059327373f;     // d(scale * q.k)/dq
+    T* dst = (T*)a.dqkv + ((size_t)b * N + query) * (3 * C) + head * 8 + 4 * h;
+    store4(dst, dq[0] * sc, dq[1] * sc, dq[2] * sc, dq[3] * sc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_args a) {
+  using E = Elem<T>;
+  using Ops = AttnOps<T>;
+  constexpr int KROW = Ops::KROW;
+  constexpr int QT = sizeof(T) == 4 ? 128 : 256;       // queries per LDS tile (fp32 validation mode: LDS budget)
+  __shared__ __attribute__((aligned(16))) unsigned char qlds[2][QT * KROW + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char dolds[2][QT * KROW + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char qtlds[2][9 * Ops::VT_PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char dotlds[2][9 * Ops::VT_PITCH];
+  __shared__ __attribute__((aligned(16))) float nl[2][QT], nd[2][QT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nkb = (a.N + 127) / 128;
+  const int total = nkb * a.heads * a.B;
+  int item = blockIdx.x;
+  if ((total & 7) == 0) item = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int kb = item % nkb;
+  const int head = (item / nkb) % a.heads, b = item / (nkb * a.heads);
+  const int N = a.N, C = a.heads * 8;
+  const size_t bh = ((size_t)b * a.heads + head) * N;
+  const T* qp = (const T*)a.q + bh * 8;
+  const T* dop = (const T*)a.dout + (size_t)b * N * C + head * 8;
+  const float qscale = 0.35355339059327373f * 1.4426950408889634f;
+
+  const int key = kb * 128 + wave * 32 + r, kc = min(key, N - 1);
+  typename Ops::QF kfr = Ops::load_q((const T*)a.k + (bh + kc) * 8, h, 1.0f);
+  typename Ops::QF vfr = Ops::load_q((const T*)a.v + (bh + kc) * 8, h, 1.0f);
+  f32x16 dk = (f32x16)(0.f), dv = (f32x16)(0.f);
+
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) {
+    if (tid == 0) { *(f32x4*)(qlds[b2] + QT * KROW) = (f32x4)(0.f); *(f32x4*)(dolds[b2] + QT * KROW) = (f32x4)(0.f); }
+    if (tid < QT) {
+      *(T*)(qtlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
+      *(T*)(dotlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
+    }
+  }
+  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
+  // K-row style addressing of the Q / dO row images; the bf16 zero slot sits after QT rows here
+  const int ka0 = (sizeof(T) == 2 && h) ? QT * KROW : Ops::kaddr(r, h);
+  const int kst = Ops::kstep(h);
+
+  typename E::Frag stq, stdo;
+  float stl = 0.f, std_ = 0.f;
+  auto issue = [&](int q0) {
+    const int query = q0 + tid;
+    if (tid < QT && query < N) {
+      stq = E::load(qp + (size_t)query * 8); stdo = E::load(dop + (size_t)query * C);
+      stl = -a.lse[bh + query]; std_ = -a.delta[bh + query];
+    } else { stq = E::zero(); stdo = E::zero(); stl = 0.f; std_ = 0.f; }
+  };
+  auto commit = [&](int b2) {
+    if (tid < QT) {
+      float qv[8], dv_[8];
+      E::unpack(stq, qv);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) qv[d] *= qscale;
+      const typename E::Frag qs = E::pack(qv);
+      E::store(qlds[b2] + tid * KROW, qs);
+      E::store(dolds[b2] + tid * KROW, stdo);
+      E::unpack(qs, qv);
+      E::unpack(stdo, dv_);
+      const int vp_ = Ops::vpos(tid);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        *(T*)(qtlds[b2] + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(qv[d]);
+        *(T*)(dotlds[b2] + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(dv_[d]);
+      }
+      nl[b2][tid] = stl; nd[b2][tid] = std_;
+    }
+  };
+  auto body = [&](int cur, int sub) {
+    const typename Ops::KF qa = Ops::load_k(qlds[cur] + ka0 + sub * kst);
+    const typename Ops::KF doa = Ops::load_k(dolds[cur] + ka0 + sub * kst);
+    f32x16 cl, cd;       // accumulator register i <-> query (i&3) + 8(i>>2) + 4h of the sub-tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *(const f32x4*)&nl[cur][sub * 32 + 8 * g + 4 * h];
+      const f32x4 d4 = *(const f32x4*)&nd[cur][sub * 32 + 8 * g + 4 * h];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { cl[4 * g + i] = l4[i]; cd[4 * g + i] = d4[i]; }
+    }
+    f32x16 p = Ops::qk(qa, kfr, cl);
+    f32x16 ds = Ops::qk(doa, vfr, cd);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { p[i] = __builtin_amdgcn_exp2f(p[i]); ds[i] *= p[i]; }
+    dv = Ops::pv(Ops::load_v(dotlds[cur] + vrow_off, sub * 32), p, dv);
+    dk = Ops::pv(Ops::load_v(qtlds[cur] + vrow_off, sub * 32), ds, dk);
+  };
+
+  issue(0);
+  commit(0);
+  if (QT < N) issue(QT);
+  __syncthreads();
+  for (int q0 = 0, cur = 0; q0 < N; q0 += QT, cur ^= 1) {
+    if (q0 + QT <= N) {
+#pragma unroll
+      for (int sub = 0; sub < QT / 32; ++sub) body(cur, sub);
+    } else {
+#pragma unroll 1
+      for (int sub = 0; sub < QT / 32 && q0 + sub * 32 < N; ++sub) body(cur, sub);   // padded queries: zero rows, p = 1, ds = 0
+    }
+    if (q0 + QT < N) {
+      commit(cur ^ 1);
+      if (q0 + 2 * QT < N) issue(q0 + 2 * QT);
+    }
+    __syncthreads();
+  }
+  if (key < N) {
+    const float ln2 = 0.6931471805599453f;      // Q^T carried scale * log2(e); dK = scale * dS^T q
+    T* dst = (T*)a.dqkv + ((size_t)b * N + key) * (3 * C) + head * 8 + 4 * h;
+    store4(dst + C, dk[0] * ln2, dk[1] * ln2, dk[2] * ln2, dk[3] * ln2);
+    store4(dst + 2 * C, dv[0], dv[1], dv[2], dv[3]);
   }
 }
 
@@ -320,6 +557,26 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
     if (qbw == 2) hipLaunchKernelGGL((attn_kernel<bf16_t, 2>), grid, dim3(256), 0, st, *a);
     else hipLaunchKernelGGL((attn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, *a);
   } else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+
+extern "C" int pd_attn_d8_bwd(const pd_attn_bwd_args* a, void* stream) {
+  using namespace pd;
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_attn_d8_bwd: null args");
+  PD_CHECK(a->B > 0 && a->heads > 0 && a->N > 0, PD_ERR_SHAPE, "pd_attn_d8_bwd: bad shape");
+  PD_CHECK(a->q && a->k && a->v && a->o && a->dout && a->lse && a->delta && a->dqkv, PD_ERR_ARG, "pd_attn_d8_bwd: null pointer");
+  PD_CHECK((long long)((a->N + 127) / 128) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8_bwd: grid too large");
+  const dim3 grid(((a->N + 127) / 128) * a->heads * a->B);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PD_F32) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), 0, st, *a);
+  } else if (a->dtype == PD_BF16) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
+  } else { set_error("pd_attn_d8_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

@@ -237,3 +237,40 @@ def test_conv_weight_gradient_upsample_and_1x1_and_padded_channels(env, mode):
     (ref,) = torch.autograd.grad(F.conv2d(bf16_round(img, mode), w, None, padding=1), w, dy)
     got = run_wgrad(env, mode, cols.float().cpu().permute(0, 3, 1, 2), dy, ksize=1, pad=0, cin_valid=27)
     assert rel(got.reshape(64, 3, 3, 3), ref) < (2e-5 if mode == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 4, 64), (1, 8, 1024), (2, 8, 200), (1, 2, 16), (1, 3, 300)])
+def test_attention_backward(env, mode, cfg):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, N = cfg
+    Cc = heads * 8
+    g = torch.Generator().manual_seed(31)
+    q, k, v = (bf16_round(torch.randn(B, heads, N, 8, generator=g) * 1.2, mode).requires_grad_(True) for _ in range(3))
+    dout = bf16_round(torch.randn(B, N, Cc, generator=g), mode)
+    ref_o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, Cc)
+    rq, rk, rv = torch.autograd.grad(ref_o, (q, k, v), dout)
+
+    Q, K, V = (t.detach().to(tdt).to(dev).contiguous() for t in (q, k, v))
+    out = torch.empty((B, N, Cc), dtype=tdt, device=dev)
+    lse = torch.full((B, heads, N), float("nan"), device=dev)
+    a = L.AttnArgs(dtype=code, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), out=out.data_ptr(),
+                   lse=lse.data_ptr())
+    L.check(lib.pd_attn_d8(C.byref(a), stream()), "pd_attn_d8")
+    scores = torch.einsum("bhqd,bhkd->bhqk", q.detach().double(), k.detach().double()) / 8 ** 0.5
+    want_lse = torch.logsumexp(scores, -1) * 1.4426950408889634
+    torch.cuda.synchronize()
+    assert float((lse.cpu().double() - want_lse).abs().max()) < (1e-4 if mode == "f32" else 8e-2)   # bf16: q*scale is rounded to bf16 before the MFMA (forward and backward alike)
+
+    DO = dout.to(tdt).to(dev).contiguous()
+    delta = torch.empty((B, heads, N), device=dev)
+    dqkv = torch.full((B, N, 3 * Cc), float("nan"), dtype=tdt, device=dev)
+    b = L.AttnBwdArgs(dtype=code, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), o=out.data_ptr(),
+                      dout=DO.data_ptr(), lse=lse.data_ptr(), delta=delta.data_ptr(), dqkv=dqkv.data_ptr())
+    L.check(lib.pd_attn_d8_bwd(C.byref(b), stream()), "pd_attn_d8_bwd")
+    torch.cuda.synchronize()
+    got = dqkv.float().cpu().reshape(B, N, 3, heads, 8).permute(2, 0, 3, 1, 4)     # [which][B][heads][N][8]
+    tol = 3e-5 if mode == "f32" else 2.5e-2       # bf16: P, dS and the outputs are rounded to 8 mantissa bits
+    for name, gg, rr in (("dq", got[0], rq), ("dk", got[1], rk), ("dv", got[2], rv)):
+        assert rel(gg, rr) < tol, name
