@@ -63,6 +63,8 @@ typedef struct {
   const float* wp; const float* bp;   /* stacked time_emb_proj^T [tdim][proj_dim], [proj_dim] */
   float* emb;               /* out [rows][tdim] (may be NULL) */
   float* proj;              /* out [rows][proj_dim] */
+  float* feat;              /* optional out [rows][c0]: the sinusoid features (kept for the backward), or NULL */
+  float* z1;                /* optional out [rows][tdim]: linear_1's pre-activation (kept for the backward), or NULL */
 } pd_temb_args;
 int pd_temb(const pd_temb_args* a, void* stream);
 
@@ -265,6 +267,8 @@ typedef struct {
   void* dx0; void* dx1;                  /* outputs (either may be NULL) */
   int accumulate0, accumulate1;          /* 1: dx += */
   float* dgamma; float* dbeta;           /* [C0+C1], accumulated (+=), or NULL */
+  int dz_combined;                       /* 1: dz0 holds all C0+C1 channels (stride C0+C1), dz1 must be NULL */
+  const void* res;                       /* optional [B][HW][C0+C1]: added to dx (gradient of the skip / shortcut around the block) */
 } pd_gn_bwd_args;
 int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream);
 
@@ -273,8 +277,27 @@ typedef struct { int dtype; int B, H, W, C; const void* du; void* dx; int accumu
 int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream);
 
 /* pd_channel_sum: out[n*out_stride + c] (+)= sum over pixels of x[n][p][c]  (bias gradients after a sum over n; d temb_proj) */
-typedef struct { int dtype; int B, HW, C; const void* x; float* out; int out_stride; int accumulate; } pd_channel_sum_args;
+typedef struct {
+  int dtype; int B, HW, C; const void* x; float* out; int out_stride; int accumulate;
+  float* total; int total_valid;   /* optional [total_valid <= C]: total[c] += sum over samples of this call's per-sample sums */
+} pd_channel_sum_args;
 int pd_channel_sum(const pd_channel_sum_args* a, void* stream);
+
+/* pd_nchw_to_nhwc: out[n][p][c] = c < C ? x[n][c][p] : 0 for c < Cpad (the loss gradient w.r.t. the UNet output, NCHW fp32,
+ * as conv_out's NHWC output gradient). */
+typedef struct { int dtype; int B, C, HW, Cpad; const float* x; void* out; } pd_nchw_to_nhwc_args;
+int pd_nchw_to_nhwc(const pd_nchw_to_nhwc_args* a, void* stream);
+
+/* Backward of the fp32 Linear layers of the time-embedding path (TimestepEmbedding, class embedding, time_emb_proj):
+ *   pd_linear_wgrad:  dw[o][i] += sum_r dy[r][o] * act(x[r][i]);  db[o] += sum_r dy[r][o]      (act = SiLU when x_silu)
+ *   pd_linear_dgrad:  dx[r][i]  = (sum_o dy[r][o] * w[o][i]) * (pre ? silu'(pre[r][i]) : 1)       (w: nn.Linear layout [out][in])
+ *   pd_embedding_grad: dtable[k][i] += sum over rows with labels[r] == k of d[r][i]                (deterministic order)  */
+typedef struct { int rows, in_dim, out_dim, x_silu; const float* dy; const float* x; float* dw; float* db; } pd_linear_wgrad_args;
+int pd_linear_wgrad(const pd_linear_wgrad_args* a, void* stream);
+typedef struct { int rows, in_dim, out_dim; const float* dy; const float* w; const float* pre; float* dx; } pd_linear_dgrad_args;
+int pd_linear_dgrad(const pd_linear_dgrad_args* a, void* stream);
+typedef struct { int rows, dim, num_classes; const int64_t* labels; const float* d; float* dtable; } pd_embedding_grad_args;
+int pd_embedding_grad(const pd_embedding_grad_args* a, void* stream);
 
 /* pd_conv_wgrad: weight gradient of a convolution pd_conv ran in the forward:
  *   dw[co][ci][ky][kx] (+)= sum_{n,oy,ox} dy[n][oy][ox][co] * Z[n][oy*stride+ky-pad][ox*stride+kx-pad][ci],

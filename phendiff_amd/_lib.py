@@ -24,7 +24,7 @@ class TembArgs(C.Structure):
                 ("flip_sin_to_cos", C.c_int), ("freq_shift", C.c_float), ("num_classes", C.c_int),
                 ("timesteps", vp), ("labels", vp), ("class_emb", vp),
                 ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("class_table", vp), ("wp", vp), ("bp", vp),
-                ("emb", vp), ("proj", vp)]
+                ("emb", vp), ("proj", vp), ("feat", vp), ("z1", vp)]
 
 
 class ConvInArgs(C.Structure):
@@ -57,7 +57,8 @@ class GnBwdArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C0", C.c_int), ("C1", C.c_int), ("groups", C.c_int),
                 ("silu", C.c_int), ("x0", vp), ("x1", vp), ("dz0", vp), ("dz1", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
                 ("beta", vp), ("partial", vp), ("splits", C.c_int), ("coef", vp), ("dx0", vp), ("dx1", vp),
-                ("accumulate0", C.c_int), ("accumulate1", C.c_int), ("dgamma", vp), ("dbeta", vp)]
+                ("accumulate0", C.c_int), ("accumulate1", C.c_int), ("dgamma", vp), ("dbeta", vp),
+                ("dz_combined", C.c_int), ("res", vp)]
 
 
 class Pool2x2Args(C.Structure):
@@ -67,7 +68,24 @@ class Pool2x2Args(C.Structure):
 
 class ChannelSumArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("x", vp), ("out", vp),
-                ("out_stride", C.c_int), ("accumulate", C.c_int)]
+                ("out_stride", C.c_int), ("accumulate", C.c_int), ("total", vp), ("total_valid", C.c_int)]
+
+
+class NchwToNhwcArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("Cpad", C.c_int), ("x", vp), ("out", vp)]
+
+
+class LinearWgradArgs(C.Structure):
+    _fields_ = [("rows", C.c_int), ("in_dim", C.c_int), ("out_dim", C.c_int), ("x_silu", C.c_int), ("dy", vp), ("x", vp),
+                ("dw", vp), ("db", vp)]
+
+
+class LinearDgradArgs(C.Structure):
+    _fields_ = [("rows", C.c_int), ("in_dim", C.c_int), ("out_dim", C.c_int), ("dy", vp), ("w", vp), ("pre", vp), ("dx", vp)]
+
+
+class EmbeddingGradArgs(C.Structure):
+    _fields_ = [("rows", C.c_int), ("dim", C.c_int), ("num_classes", C.c_int), ("labels", vp), ("d", vp), ("dtable", vp)]
 
 
 class WgradArgs(C.Structure):
@@ -139,6 +157,10 @@ SYMBOLS = {
     "pd_gn_silu_bwd": (C.c_int, [C.POINTER(GnBwdArgs), vp]),
     "pd_pool2x2_sum": (C.c_int, [C.POINTER(Pool2x2Args), vp]),
     "pd_channel_sum": (C.c_int, [C.POINTER(ChannelSumArgs), vp]),
+    "pd_nchw_to_nhwc": (C.c_int, [C.POINTER(NchwToNhwcArgs), vp]),
+    "pd_linear_wgrad": (C.c_int, [C.POINTER(LinearWgradArgs), vp]),
+    "pd_linear_dgrad": (C.c_int, [C.POINTER(LinearDgradArgs), vp]),
+    "pd_embedding_grad": (C.c_int, [C.POINTER(EmbeddingGradArgs), vp]),
     "pd_conv_wgrad_workspace": (C.c_size_t, [C.POINTER(WgradArgs)]),
     "pd_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),

@@ -32,8 +32,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args
     const int piece = tid % PP, prow = tid / PP, c8 = piece * 8;
     const bool first = c8 < a.C0;
     const T* xs = (const T*)(first ? a.x0 : a.x1);
-    const T* ds = (const T*)(first ? a.dz0 : a.dz1);
+    const T* ds = (const T*)((first || a.dz_combined) ? a.dz0 : a.dz1);
     const int cs = first ? a.C0 : a.C1, coff = first ? c8 : c8 - a.C0;
+    const int dcs = a.dz_combined ? C : cs, dcoff = a.dz_combined ? c8 : coff;
     float mu[8], rs[8], ga[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args
     for (int p = p0 + prow; p < p1; p += ppi) {
       float xv[8], dv[8];
       E::unpack(E::load(xs + ((size_t)n * a.HW + p) * cs + coff), xv);
-      E::unpack(E::load(ds + ((size_t)n * a.HW + p) * cs + coff), dv);
+      E::unpack(E::load(ds + ((size_t)n * a.HW + p) * dcs + dcoff), dv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xh = (xv[j] - mu[j]) * rs[j];
@@ -118,9 +119,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args 
     if (!dxp) continue;
     float xv[8], dv[8], acc[8];
     E::unpack(E::load((const T*)(first ? a.x0 : a.x1) + off), xv);
-    E::unpack(E::load((const T*)(first ? a.dz0 : a.dz1) + off), dv);
+    const size_t doff = a.dz_combined ? pixl * C + c8 : off;
+    E::unpack(E::load((const T*)((first || a.dz_combined) ? a.dz0 : a.dz1) + doff), dv);
     const bool accum = first ? a.accumulate0 : a.accumulate1;
     if (accum) E::unpack(E::load(dxp + off), acc);
+    float rv[8];
+    const bool has_res = a.res != nullptr;
+    if (has_res) E::unpack(E::load((const T*)a.res + pixl * C + c8), rv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c8 + j, g = c / gs;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args 
       const float xh = (xv[j] - mu) * rs;
       const float dy = a.silu ? dv[j] * dsilu(a.gamma[c] * xh + a.beta[c]) : dv[j];
       const float dx = rs * (a.gamma[c] * dy - a.coef[(n * a.groups + g) * 2] - xh * a.coef[(n * a.groups + g) * 2 + 1]);
-      acc[j] = accum ? acc[j] + dx : dx;
+      acc[j] = (accum ? acc[j] + dx : dx) + (has_res ? rv[j] : 0.f);
     }
     E::store(dxp + off, E::pack(acc));
   }
@@ -194,6 +199,67 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_a
   }
 }
 
+// total[c] += sum_n per[n*stride + c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ per, int B, int stride, int C, float* __restrict__ total) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int n = 0; n < B; ++n) s += per[(size_t)n * stride + c];
+  total[c] += s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const pd_nchw_to_nhwc_args a) {
+  const size_t total = (size_t)a.B * a.HW * (a.Cpad / 8);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int sub = (int)(idx % (a.Cpad / 8));
+    const size_t pix = idx / (a.Cpad / 8);
+    const int n = (int)(pix / a.HW), p = (int)(pix % a.HW);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = sub * 8 + j;
+      v[j] = c < a.C ? a.x[((size_t)n * a.C + c) * a.HW + p] : 0.f;
+    }
+    Elem<T>::store((T*)a.out + pix * a.Cpad + sub * 8, Elem<T>::pack(v));
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const pd_linear_wgrad_args a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.out_dim * a.in_dim) return;
+  const int o = (int)(idx / a.in_dim), i = (int)(idx % a.in_dim);
+  float s = 0.f, sb = 0.f;
+  for (int r = 0; r < a.rows; ++r) {
+    const float d = a.dy[(size_t)r * a.out_dim + o];
+    float x = a.x[(size_t)r * a.in_dim + i];
+    if (a.x_silu) x = silu_f(x);
+    s += d * x; sb += d;
+  }
+  a.dw[idx] += s;
+  if (i == 0 && a.db) a.db[o] += sb;
+}
+
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const pd_linear_dgrad_args a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.rows * a.in_dim) return;
+  const int r = (int)(idx / a.in_dim), i = (int)(idx % a.in_dim);
+  float s = 0.f;
+  for (int o = 0; o < a.out_dim; ++o) s += a.dy[(size_t)r * a.out_dim + o] * a.w[(size_t)o * a.in_dim + i];
+  if (a.pre) s *= dsilu(a.pre[idx]);
+  a.dx[idx] = s;
+}
+
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const pd_embedding_grad_args a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.num_classes * a.dim) return;
+  const int k = idx / a.dim, i = idx % a.dim;
+  float s = 0.f;
+  for (int r = 0; r < a.rows; ++r)
+    if (a.labels[r] == k) s += a.d[(size_t)r * a.dim + i];
+  a.dtable[idx] += s;
+}
+
 }  // namespace pd
 
 using namespace pd;
@@ -204,7 +270,7 @@ extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
   PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0 && C <= 1024, PD_ERR_SHAPE, "pd_gn_silu_bwd: bad shape");
   PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0 && C / 8 <= 256, PD_ERR_SHAPE, "pd_gn_silu_bwd: groups=%d C=%d", a->groups, C);
   PD_CHECK(a->x0 && a->dz0 && a->mean && a->rstd && a->gamma && a->beta && a->partial && a->coef && a->splits >= 1, PD_ERR_ARG, "pd_gn_silu_bwd: null pointer");
-  PD_CHECK((a->C1 == 0) == (a->x1 == nullptr) && (a->C1 == 0) == (a->dz1 == nullptr), PD_ERR_ARG, "pd_gn_silu_bwd: source 1 mismatch");
+  PD_CHECK((a->C1 == 0) == (a->x1 == nullptr) && (a->C1 == 0 || a->dz_combined) == (a->dz1 == nullptr), PD_ERR_ARG, "pd_gn_silu_bwd: source 1 mismatch");
   PD_CHECK(a->dx0 || a->dx1, PD_ERR_ARG, "pd_gn_silu_bwd: no output");
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)a->B * a->HW * (C / 8);
@@ -238,6 +304,47 @@ extern "C" int pd_channel_sum(const pd_channel_sum_args* a, void* stream) {
   if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_channel_sum: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  if (a->total) {
+    PD_CHECK(a->total_valid > 0 && a->total_valid <= a->C, PD_ERR_ARG, "pd_channel_sum: total_valid=%d", a->total_valid);
+    PD_CHECK(!a->accumulate, PD_ERR_ARG, "pd_channel_sum: total needs this call's own per-sample sums (accumulate = 0)");
+    hipLaunchKernelGGL(colsum_kernel, dim3((a->total_valid + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)a->out, a->B,
+                       a->out_stride, a->total_valid, a->total);
+    PD_LAUNCH_CHECK();
+  }
+  return PD_OK;
+}
+
+extern "C" int pd_nchw_to_nhwc(const pd_nchw_to_nhwc_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->B > 0 && a->C > 0 && a->HW > 0 && a->Cpad >= a->C && a->Cpad % 8 == 0 && a->x && a->out, PD_ERR_ARG, "pd_nchw_to_nhwc: bad args");
+  const size_t total = (size_t)a->B * a->HW * (a->Cpad / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_nchw_to_nhwc: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_linear_wgrad(const pd_linear_wgrad_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->in_dim > 0 && a->out_dim > 0 && a->dy && a->x && a->dw, PD_ERR_ARG, "pd_linear_wgrad: bad args");
+  const size_t total = (size_t)a->out_dim * a->in_dim;
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_linear_dgrad(const pd_linear_dgrad_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->in_dim > 0 && a->out_dim > 0 && a->dy && a->w && a->dx, PD_ERR_ARG, "pd_linear_dgrad: bad args");
+  const size_t total = (size_t)a->rows * a->in_dim;
+  hipLaunchKernelGGL(linear_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_embedding_grad(const pd_embedding_grad_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->dim > 0 && a->num_classes > 0 && a->labels && a->d && a->dtable, PD_ERR_ARG, "pd_embedding_grad: bad args");
+  hipLaunchKernelGGL(embedding_grad_kernel, dim3((a->num_classes * a->dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

@@ -34,11 +34,13 @@ __global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a) {
     const float arg = t * expf(expo);
     const bool want_sin = a.flip_sin_to_cos ? second : !second;
     se[i] = want_sin ? sinf(arg) : cosf(arg);
+    if (a.feat) a.feat[(size_t)row * a.c0 + i] = se[i];
   }
   __syncthreads();
   for (int o = tid; o < a.tdim; o += 256) {
     float acc = a.b1[o];
     for (int i = 0; i < a.c0; ++i) acc += a.w1[(size_t)i * a.tdim + o] * se[i];
+    if (a.z1) a.z1[(size_t)row * a.tdim + o] = acc;
     h1[o] = silu_f(acc);
   }
   __syncthreads();

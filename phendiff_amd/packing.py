@@ -19,7 +19,7 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cout_pad: int | None =
     cp = cout_pad or cout
     assert cp % 32 == 0 and cp >= cout
     taps = k * k
-    wf = torch.zeros((cp, cin, taps), dtype=torch.float32)
+    wf = torch.zeros((cp, cin, taps), dtype=torch.float32, device=w.device)
     wf[:cout] = w.reshape(cout, cin, taps).float()
     # [ct, r, chunk, s, h, j, tap] -> [ct, chunk, tap, s, h, r, j]
     wf = wf.reshape(cp // 32, 32, cin // 32, 2, 2, 8, taps).permute(0, 2, 6, 3, 4, 1, 5).contiguous()

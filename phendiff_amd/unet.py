@@ -184,7 +184,7 @@ class CustomCondUNet2DModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
         self._plans = {}
         self._weights = None
-        self.requires_grad_(False)  # inference engine; training kernels are a later round
+        self.requires_grad_(False)  # no autograd graph: gradients come from the HIP backward plan (phendiff_amd.unet_train)
 
     # ---- diffusers-like conveniences ------------------------------------------------------------
     @classmethod
@@ -295,9 +295,9 @@ class _PackedWeights:
         if cin > 3:
             raise NotImplementedError("conv_in on the HIP path takes <= 3 input channels (pixel-space UNet)")
         # conv_in as a 1x1 conv over 32 virtual channels k = ci*9 + ky*3 + kx (pd_conv im2col3 mode)
-        wv = torch.zeros((m.conv_in.weight.shape[0], 32, 1, 1), dtype=torch.float32)
-        wv[:, :cin * 9, 0, 0] = m.conv_in.weight.detach().float().cpu().reshape(-1, cin * 9)
-        self.conv_in_wv = pack_conv_weight(wv, self.tdt).to(dev)
+        wv = torch.zeros((m.conv_in.weight.shape[0], 32, 1, 1), dtype=torch.float32, device=dev)
+        wv[:, :cin * 9, 0, 0] = f32(m.conv_in.weight).reshape(-1, cin * 9)
+        self.conv_in_wv = pack_conv_weight(wv, self.tdt)
         te = m.time_embedding
         self.w1T, self.b1 = f32(te.linear_1.weight.t()), f32(te.linear_1.bias)
         self.w2T, self.b2 = f32(te.linear_2.weight.t()), f32(te.linear_2.bias)
@@ -348,9 +348,9 @@ class _PackedWeights:
         co = m.conv_out.weight.shape[0]
         self.conv_out_pad = ((co + 31) // 32) * 32
         self.conv_out_w = self._pack(m.conv_out.weight, self.conv_out_pad)
-        b = torch.zeros(self.conv_out_pad, dtype=torch.float32)
-        b[:co] = m.conv_out.bias.detach().float().cpu()
-        self.conv_out_b = b.to(dev)
+        b = torch.zeros(self.conv_out_pad, dtype=torch.float32, device=dev)
+        b[:co] = f32(m.conv_out.bias)
+        self.conv_out_b = b
 
     @staticmethod
     def _iter(m, cls):
@@ -359,7 +359,27 @@ class _PackedWeights:
                 yield name, mod
 
     def _pack(self, w, cout_pad=None):
-        return pack_conv_weight(w.detach().float().cpu(), self.tdt, cout_pad).to(self.conv_in_w.device)
+        # packed on the device the plan runs on (a training step re-packs after every optimizer update)
+        return pack_conv_weight(w.detach().to(device=self.conv_in_w.device, dtype=torch.float32), self.tdt, cout_pad)
+
+    def refresh(self, m):
+        """Re-derive every kernel-layout tensor from ``m``'s current parameters IN PLACE (device pointers held by launch
+        plans stay valid).  Called after each optimizer step of a training run."""
+        _copy_into(self, type(self)(m, self.conv_in_w.device))
+
+
+def _copy_into(dst, src):
+    items = src.items() if isinstance(src, dict) else vars(src).items()
+    for k, v in items:
+        d = dst[k] if isinstance(dst, dict) else getattr(dst, k)
+        if torch.is_tensor(v):
+            d.copy_(v)
+        elif isinstance(v, (dict, SimpleNamespace)):
+            _copy_into(d, v)
+        elif isinstance(v, tuple):
+            for dd, vv in zip(d, v):
+                if torch.is_tensor(vv):
+                    dd.copy_(vv)
 
 
 class _Op:
@@ -383,6 +403,9 @@ class UNetPlan:
         nlev = len(c.block_out_channels)
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise ValueError(f"sample size {(H, W)} must be a multiple of {1 << (nlev - 1)}")
+        self.train = bool(getattr(self, "train", False))   # set by UNetTrainPlan before the forward is laid out
+        self.tape = []          # block-level records of the forward (what a backward plan walks in reverse)
+        self.gn_saved = {}      # id(scale) -> GroupNorm inputs / statistics kept for the backward (train plans only)
         self.ops = []
         self.bufs = []          # keep every device buffer alive
         self.stats = {}         # id(NHWC activation) -> (per-tile channel sums [B][T][C][2], T) written by its producer
@@ -417,6 +440,10 @@ class UNetPlan:
         a = L.GnFinalizeArgs(B=self.B, HW=h * w, groups=self.groups, eps=eps, C0=c0, T0=t0, stats0=st0.data_ptr(),
                              C1=c1, T1=t1, stats1=L.ptr(st1), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
                              scale=scale.data_ptr(), shift=shift.data_ptr())
+        if self.train:
+            mean, rstd = self._f32(self.B, self.groups), self._f32(self.B, self.groups)
+            a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+            self.gn_saved[id(scale)] = SimpleNamespace(mean=mean, rstd=rstd, gamma=gamma, beta=beta, x0=x0, x1=x1)
         self.ops.append(_Op(self.lib.pd_gn_finalize, a, "gn_finalize", 0.0, self.B * (t0 * c0 + t1 * c1) * 8.0))
         return scale, shift
 
@@ -474,6 +501,7 @@ class UNetPlan:
         else:
             assert x1 is None
             out, _ = self._conv(h1, None, e.w2, e.b2, e.cout, silu=1, gn=gn2, residual=x0)
+        self.tape.append(SimpleNamespace(kind="resnet", name=name, x0=x0, x1=x1, h1=h1, out=out, gn1=gn1, gn2=gn2, e=e))
         return out
 
     def _attn(self, name, x):
@@ -485,12 +513,14 @@ class UNetPlan:
         qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, out_mode=L.PD_OUT_QKV_HEADS,
                             heads=e.heads)
         o = self._act(h, w, ch)
+        lse = self._f32(B, e.heads, h * w) if self.train else None
         a = L.AttnArgs(dtype=self.code, B=B, heads=e.heads, N=h * w, q=qkv[0].data_ptr(), k=qkv[1].data_ptr(),
-                       v=qkv[2].data_ptr(), out=o.data_ptr())
+                       v=qkv[2].data_ptr(), out=o.data_ptr(), lse=L.ptr(lse))
         esz = 2 if self.code == L.PD_BF16 else 4
         N = h * w
         self.ops.append(_Op(self.lib.pd_attn_d8, a, "attn_d8", 4.0 * B * e.heads * N * N * 8, 4.0 * B * N * ch * esz))
         out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
+        self.tape.append(SimpleNamespace(kind="attn", name=name, x=x, qkv=qkv, o=o, out=out, lse=lse, gn=gn, e=e))
         return out
 
     def _build(self):
@@ -509,6 +539,7 @@ class UNetPlan:
         self.ops[-1].what = "conv_in"
         self.ops[-1].flops = 2.0 * B * H * W * boc[0] * c.in_channels * 9
         self.ops[-1].bytes = B * H * W * (c.in_channels * 4 + boc[0] * (2 if self.code == L.PD_BF16 else 4))
+        self.tape.append(SimpleNamespace(kind="conv_in", out=a0))
         h = a0
         skips = [a0]
         for i, blk in enumerate(m.down_blocks):
@@ -520,7 +551,9 @@ class UNetPlan:
                 skips.append(h)
             if blk.downsamplers is not None:
                 s = w.samplers[f"down_blocks.{i}.downsamplers.0"]
-                h, _ = self._conv(h, None, s.w, s.b, h.shape[3], stride=2, pad=s.padding)
+                hd, _ = self._conv(h, None, s.w, s.b, h.shape[3], stride=2, pad=s.padding)
+                self.tape.append(SimpleNamespace(kind="down", name=f"down_blocks.{i}.downsamplers.0", x=h, out=hd, e=s))
+                h = hd
                 skips.append(h)
         h = self._resnet("mid_block.resnets.0", h)
         if m.mid_block.attentions[0] is not None:
@@ -535,11 +568,14 @@ class UNetPlan:
                     h = self._attn(f"up_blocks.{i}.attentions.{j}", h)
             if blk.upsamplers is not None:
                 s = w.samplers[f"up_blocks.{i}.upsamplers.0"]
-                h, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+                hu, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+                self.tape.append(SimpleNamespace(kind="up", name=f"up_blocks.{i}.upsamplers.0", x=h, out=hu, e=s))
+                h = hu
         g, be, eps = w.gn_out
         gn = self._gn(h, None, g, be, eps)
         _, self._out_args = self._conv(h, None, w.conv_out_w, w.conv_out_b, c.out_channels, silu=1, gn=gn,
                                        out_mode=L.PD_OUT_NCHW_F32, cout_pad=w.conv_out_pad, y=None)
+        self.tape.append(SimpleNamespace(kind="conv_out", x=h, gn=gn))
         self._cur = (None, None, None)
 
     # ---- execution -------------------------------------------------------------------------------

@@ -1,0 +1,441 @@
+"""Backward of ``CustomCondUNet2DModel`` on MI355X: what ``accelerator.backward(loss)`` (``utils_training.py:436``) asks
+autograd to do over the reference's UNet, as a static plan of hand-written HIP launches.
+
+``UNetTrainPlan`` lays out the forward exactly as :class:`phendiff_amd.unet.UNetPlan` does (same kernels, every activation
+already lives in its own buffer) and additionally keeps the GroupNorm statistics and the attention log-sum-exp; it then
+walks the forward's block tape in reverse and emits, per block:
+
+* convolution input gradients: ``pd_conv`` with transposed + flipped weights (zero-stuffed for the stride-2 convs, pooled
+  2x2 for the convs fused with the nearest upsample); gradient accumulation over skip connections rides in ``residual``;
+* weight gradients: ``pd_conv_wgrad`` (pixel-K MFMA GEMM, the GroupNorm-affine + SiLU input rebuilt on the fly);
+* GroupNorm(+SiLU) backward: ``pd_gn_silu_bwd`` (also folds the identity-skip / shortcut gradient into ``dx``);
+* attention backward: ``pd_attn_d8_bwd``; bias / time-embedding-projection gradients: ``pd_channel_sum``;
+* the fp32 time-embedding path: ``pd_linear_wgrad`` / ``pd_linear_dgrad`` / ``pd_embedding_grad``.
+
+Parameter gradients are accumulated (``+=``) in fp32 into caller-provided tensors that alias one flat buffer
+(:func:`training_param_order` gives the parameter order that makes the fused q/k/v and stacked ``time_emb_proj``
+gradients contiguous), which is what :class:`phendiff_amd.training.FlatAdamWEMA` updates in a single pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .packing import dgrad_weight, pack_conv_weight
+from .unet import CustomCondUNet2DModel, UNetPlan, _Attention, _Op, _PackedWeights, _Resnet, _Sampler, _copy_into
+
+
+def training_param_order(m: CustomCondUNet2DModel) -> List[Tuple[str, torch.nn.Parameter]]:
+    """(name, parameter) pairs in the order the flat training buffers use: all ``time_emb_proj`` weights (then biases)
+    stacked in module order -- one [proj_dim][tdim] matrix, as ``pd_temb`` sees them --, each attention's
+    to_q / to_k / to_v weights (then biases) adjacent -- the fused [3C][C] projection --, then everything else."""
+    named = dict(m.named_parameters())
+    out, seen = [], set()
+
+    def take(n):
+        out.append((n, named[n]))
+        seen.add(n)
+
+    res = [n for n, mod in m.named_modules() if isinstance(mod, _Resnet)]
+    for suffix in ("weight", "bias"):
+        for n in res:
+            take(f"{n}.time_emb_proj.{suffix}")
+    for n, mod in m.named_modules():
+        if isinstance(mod, _Attention):
+            for suffix in ("weight", "bias"):
+                for which in ("to_q", "to_k", "to_v"):
+                    take(f"{n}.{which}.{suffix}")
+    for n in named:
+        if n not in seen:
+            take(n)
+    return out
+
+
+def _contiguous_after(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()
+
+
+class TrainWeights:
+    """Input-gradient ("dgrad") weights in ``pd_conv``'s packed layout: W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx]."""
+
+    def __init__(self, m: CustomCondUNet2DModel, device, tdt):
+        self.tdt, self.device = tdt, device
+        pk = lambda w: pack_conv_weight(dgrad_weight(w.detach().to(device=device, dtype=torch.float32)), tdt)
+        lin = lambda w: w.detach()[:, :, None, None]
+        self.resnets, self.attns, self.samplers = {}, {}, {}
+        for name, mod in m.named_modules():
+            if isinstance(mod, _Resnet):
+                e = SimpleNamespace(w1d=pk(mod.conv1.weight), w2d=pk(mod.conv2.weight))
+                if mod.conv_shortcut is not None:
+                    e.wsd = pk(mod.conv_shortcut.weight)
+                self.resnets[name] = e
+            elif isinstance(mod, _Attention):
+                wqkv = torch.cat([mod.to_q.weight, mod.to_k.weight, mod.to_v.weight], 0)
+                self.attns[name] = SimpleNamespace(wqkvd=pk(lin(wqkv)), wod=pk(lin(mod.to_out[0].weight)))
+            elif isinstance(mod, _Sampler):
+                self.samplers[name] = SimpleNamespace(wd=pk(mod.conv.weight))
+        co = m.conv_out.weight.shape[0]
+        wo = torch.zeros((((co + 31) // 32) * 32,) + tuple(m.conv_out.weight.shape[1:]), dtype=torch.float32, device=device)
+        wo[:co] = m.conv_out.weight.detach().to(device=device, dtype=torch.float32)
+        self.conv_out_d = pk(wo)           # 32 (3 real) output-gradient channels -> block_out_channels[0]
+
+    def refresh(self, m):
+        _copy_into(self, TrainWeights(m, self.device, self.tdt))
+
+
+class UNetTrainPlan(UNetPlan):
+    """Forward (with saved statistics) + backward launch plan for a fixed (B, H, W).
+
+    ``params`` / ``grads``: state_dict-name -> fp32 device tensor (master parameter / its gradient), laid out as
+    :func:`training_param_order` prescribes.  ``backward`` ACCUMULATES into ``grads`` (zero them between steps)."""
+
+    def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, tw: TrainWeights, B, H, W, device,
+                 params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]):
+        self.train = True
+        super().__init__(m, w, B, H, W, device)
+        self.tw, self.params, self.grads = tw, params, grads
+        self._check_layout()
+        c0, tdim = m.config.block_out_channels[0], m.time_embed_dim
+        self.t_feat, self.t_z1, self.t_emb = self._f32(B, c0), self._f32(B, tdim), self._f32(B, tdim)
+        self.temb_table = self._f32(B, w.proj_dim)
+        self.bwd_ops: List[_Op] = []
+        self._emb_grad_op = None
+        self._gact = {}
+        self._tmp_cache = {}
+        self._wgrad_args = []
+        self._sample_ptr_args = []
+        self._build_backward()
+
+    # ---- layout checks ---------------------------------------------------------------------------
+    def _check_layout(self):
+        for d in (self.params, self.grads):
+            res = [n for n, mod in self.m.named_modules() if isinstance(mod, _Resnet)]
+            for suffix in ("weight", "bias"):
+                for a, b in zip(res[:-1], res[1:]):
+                    if not _contiguous_after(d[f"{a}.time_emb_proj.{suffix}"], d[f"{b}.time_emb_proj.{suffix}"]):
+                        raise ValueError("time_emb_proj parameters must be stacked contiguously (use training_param_order)")
+            for n, mod in self.m.named_modules():
+                if isinstance(mod, _Attention):
+                    for suffix in ("weight", "bias"):
+                        q, k, v = (d[f"{n}.{x}.{suffix}"] for x in ("to_q", "to_k", "to_v"))
+                        if not (_contiguous_after(q, k) and _contiguous_after(k, v)):
+                            raise ValueError("to_q/to_k/to_v parameters must be adjacent (use training_param_order)")
+            for t in d.values():
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != torch.device(self.device):
+                    raise ValueError("training parameters / gradients must be contiguous fp32 tensors on the plan's device")
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, sample: torch.Tensor, timesteps: torch.Tensor, labels: Optional[torch.Tensor],
+                class_emb: Optional[torch.Tensor], out: torch.Tensor, stream):
+        """One training forward: fp32 NCHW ``sample`` -> fp32 NCHW ``out``; keeps what ``backward`` needs."""
+        a = self.temb_args
+        a.rows = self.B
+        a.timesteps, a.labels, a.class_emb = timesteps.data_ptr(), L.ptr(labels), L.ptr(class_emb)
+        a.emb, a.proj = self.t_emb.data_ptr(), self.temb_table.data_ptr()
+        a.feat, a.z1 = self.t_feat.data_ptr(), self.t_z1.data_ptr()
+        L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
+        a.feat, a.z1 = None, None
+        self.run(sample.data_ptr(), self.temb_table.data_ptr(), out.data_ptr(), stream)
+        self._labels = labels
+        for args in self._sample_ptr_args:
+            args.x = sample.data_ptr()
+        self.keepalive = (sample, timesteps, labels, class_emb, out)
+
+    # ---- backward emitters -----------------------------------------------------------------------
+    def _g(self, act):
+        """[gradient buffer of an activation, already holds a contribution?]"""
+        e = self._gact.get(id(act))
+        if e is None:
+            t = torch.empty_like(act)
+            self.bufs.append(t)
+            e = [t, False]
+            self._gact[id(act)] = e
+        return e
+
+    def _tmp(self, shape, tag, dtype=None):
+        key = (tuple(shape), tag, dtype or self.tdt)
+        t = self._tmp_cache.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
+            self.bufs.append(t)
+            self._tmp_cache[key] = t
+        return t
+
+    def _b(self, fn, args, what, flops=0.0, nbytes=0.0):
+        self.bwd_ops.append(_Op(fn, args, what, flops, nbytes))
+
+    def _esz(self):
+        return 2 if self.code == L.PD_BF16 else 4
+
+    def _bias_grad(self, dy, total, valid=None, per_sample=None, per_stride=None):
+        B, h, w, ch = dy.shape
+        out = per_sample if per_sample is not None else self._tmp((B, ch), "chsum", torch.float32)
+        a = L.ChannelSumArgs(dtype=self.code, B=B, HW=h * w, C=ch, x=dy.data_ptr(), out=out.data_ptr(),
+                             out_stride=per_stride or ch, accumulate=0, total=total.data_ptr(), total_valid=valid or ch)
+        self._b(self.lib.pd_channel_sum, a, "channel_sum", 0.0, dy.numel() * self._esz())
+
+    def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0):
+        B, hin, win, c0 = x0.shape
+        c1 = x1.shape[3] if x1 is not None else 0
+        _, hout, wout, cout = dy.shape
+        a = L.WgradArgs(dtype=self.code, B=B, Hin=hin, Win=win, Hout=hout, Wout=wout, C0=c0, C1=c1, Cout=cout, ksize=ksize,
+                        stride=stride, pad=pad, upsample=upsample, silu=silu, x0=x0.data_ptr(), x1=L.ptr(x1),
+                        scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None, dy=dy.data_ptr(),
+                        dw=dw.data_ptr(), Cout_valid=cout_valid, Cin_valid=cin_valid, accumulate=1)
+        self._wgrad_args.append(a)
+        flops = 2.0 * B * hout * wout * cout * (c0 + c1) * ksize * ksize
+        nbytes = (x0.numel() + (x1.numel() if x1 is not None else 0) + dy.numel()) * self._esz() + dw.numel() * 4
+        self._b(self.lib.pd_conv_wgrad, a, f"wgrad{ksize}x{ksize}", flops, nbytes)
+
+    def _dgrad(self, dy, wpk, cout, *, ksize=3, zero_stuff=False, into=None, tag="dz"):
+        """Input gradient of a convolution: ``pd_conv`` over dy with the transposed/flipped weights.  ``into`` = [buffer,
+        initialised]: write (or accumulate, through ``residual``) straight into a gradient buffer."""
+        B, h, w, cin = dy.shape
+        ho, wo = (2 * h, 2 * w) if zero_stuff else (h, w)
+        if into is not None:
+            y, res = into[0], (into[0] if into[1] else None)
+            into[1] = True
+        else:
+            y, res = self._tmp((B, ho, wo, cout), tag), None
+        ops, self.ops = self.ops, self.bwd_ops
+        try:
+            self._conv(dy, None, wpk, self._zero_bias, cout, ksize=ksize, pad=ksize // 2, upsample=2 if zero_stuff else 0,
+                       residual=res, y=y, stats=False)
+        finally:
+            self.ops = ops
+        self.bwd_ops[-1].what = f"dgrad{ksize}x{ksize}"
+        return y
+
+    def _gn_bwd(self, gn, dz, silu, *, combined=False, res=None, wname=None):
+        s = self.gn_saved[id(gn[0])]
+        x0, x1 = s.x0, s.x1
+        B, h, w, c0 = x0.shape
+        c1 = x1.shape[3] if x1 is not None else 0
+        g0 = self._g(x0)
+        g1 = self._g(x1) if x1 is not None else None
+        splits = max(1, min(64, (h * w) // 256))
+        partial = self._tmp((B * splits * (c0 + c1) * 2,), "gnpart", torch.float64)
+        coef = self._tmp((B, self.groups, 2), "gncoef", torch.float32)
+        a = L.GnBwdArgs(dtype=self.code, B=B, HW=h * w, C0=c0, C1=c1, groups=self.groups, silu=silu, x0=x0.data_ptr(),
+                        x1=L.ptr(x1), dz0=dz.data_ptr(), dz1=None, mean=s.mean.data_ptr(), rstd=s.rstd.data_ptr(),
+                        gamma=s.gamma.data_ptr(), beta=s.beta.data_ptr(), partial=partial.data_ptr(), splits=splits,
+                        coef=coef.data_ptr(), dx0=g0[0].data_ptr(), dx1=(g1[0].data_ptr() if g1 else None),
+                        accumulate0=int(g0[1]), accumulate1=int(g1[1]) if g1 else 0,
+                        dgamma=self.grads[wname + ".weight"].data_ptr(), dbeta=self.grads[wname + ".bias"].data_ptr(),
+                        dz_combined=1 if (combined and c1) else 0, res=L.ptr(res))
+        g0[1] = True
+        if g1:
+            g1[1] = True
+        n = B * h * w * (c0 + c1)
+        self._b(self.lib.pd_gn_silu_bwd, a, "gn_silu_bwd", 0.0, n * self._esz() * (5 + (1 if res is not None else 0)))
+
+    # ---- backward plan ---------------------------------------------------------------------------
+    def _build_backward(self):
+        m, w, tw, c = self.m, self.w, self.tw, self.m.config
+        B, H, W = self.B, self.H, self.W
+        G = self.grads
+        boc0 = c.block_out_channels[0]
+        maxc = max(max(c.block_out_channels) * 3, 64)
+        self._zero_bias = torch.zeros(maxc + 64, dtype=torch.float32, device=self.device)
+        self.dproj = self._f32(B, w.proj_dim)
+        for rec in reversed(self.tape):
+            k = rec.kind
+            if k == "conv_out":
+                dy = self._tmp((B, H, W, w.conv_out_pad), "dy_out")
+                a = L.NchwToNhwcArgs(dtype=self.code, B=B, C=c.out_channels, HW=H * W, Cpad=w.conv_out_pad, x=None,
+                                     out=dy.data_ptr())
+                self._dout_args = a
+                self._b(self.lib.pd_nchw_to_nhwc, a, "nchw_to_nhwc", 0.0, B * H * W * c.out_channels * 4.0)
+                self._bias_grad(dy, G["conv_out.bias"], valid=c.out_channels)
+                self._wgrad(rec.x, None, rec.gn, 1, dy, G["conv_out.weight"], cout_valid=c.out_channels)
+                dz = self._dgrad(dy, tw.conv_out_d, boc0)
+                self._gn_bwd(rec.gn, dz, 1, wname="conv_norm_out")
+            elif k == "resnet":
+                self._resnet_bwd(rec)
+            elif k == "attn":
+                self._attn_bwd(rec)
+            elif k == "down":
+                if rec.e.padding != 1:
+                    raise NotImplementedError("training: Downsample2D with padding != 1")
+                dout = self._g(rec.out)[0]
+                self._bias_grad(dout, G[rec.name + ".conv.bias"])
+                self._wgrad(rec.x, None, None, 0, dout, G[rec.name + ".conv.weight"], stride=2, pad=1)
+                self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], zero_stuff=True, into=self._g(rec.x))
+            elif k == "up":
+                dout = self._g(rec.out)[0]
+                self._bias_grad(dout, G[rec.name + ".conv.bias"])
+                self._wgrad(rec.x, None, None, 0, dout, G[rec.name + ".conv.weight"], upsample=1)
+                du = self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], tag="du")
+                gx = self._g(rec.x)
+                _, h, ww, ch = rec.x.shape
+                a = L.Pool2x2Args(dtype=self.code, B=B, H=h, W=ww, C=ch, du=du.data_ptr(), dx=gx[0].data_ptr(),
+                                  accumulate=int(gx[1]))
+                gx[1] = True
+                self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
+            elif k == "conv_in":
+                dout = self._g(rec.out)[0]
+                self._bias_grad(dout, G["conv_in.bias"])
+                cols = self._tmp((B, H, W, 32), "im2col")
+                a = L.Im2col3Args(dtype=self.code, B=B, H=H, W=W, C=c.in_channels, x=None, out=cols.data_ptr())
+                self._sample_ptr_args.append(a)
+                self._b(self.lib.pd_im2col3, a, "im2col3", 0.0, cols.numel() * self._esz())
+                self._wgrad(cols, None, None, 0, dout, G["conv_in.weight"], ksize=1, pad=0, cin_valid=c.in_channels * 9)
+        self._temb_bwd()
+        # one slab serves every weight-gradient launch (they run back to back on one stream)
+        need = max(self.lib.pd_conv_wgrad_workspace(C.byref(a)) for a in self._wgrad_args)
+        self.slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
+        for a in self._wgrad_args:
+            a.slab, a.slab_bytes = self.slab.data_ptr(), need
+
+    def _resnet_bwd(self, rec):
+        G, e, te = self.grads, rec.e, self.tw.resnets[rec.name]
+        n = rec.name
+        x0, x1 = rec.x0, rec.x1
+        cin = e.cin
+        dout = self._g(rec.out)[0]
+        self._bias_grad(dout, G[n + ".conv2.bias"])
+        self._wgrad(rec.h1, None, rec.gn2, 1, dout, G[n + ".conv2.weight"])
+        if e.fused_shortcut:
+            self._bias_grad(dout, G[n + ".conv_shortcut.bias"])
+            self._wgrad(x0, x1, None, 0, dout, G[n + ".conv_shortcut.weight"], ksize=1, pad=0)
+            res = self._dgrad(dout, te.wsd, cin, ksize=1, tag="dshort")
+        else:
+            res = dout
+        dz2 = self._dgrad(dout, te.w2d, e.cout)
+        self._gn_bwd(rec.gn2, dz2, 1, wname=n + ".norm2")
+        dh1 = self._g(rec.h1)[0]
+        # d time_emb_proj output [n][co] = sum over pixels of d h1 (the projection is broadcast over the pixels)
+        per = self.dproj[:, e.temb_off:]
+        self._bias_grad(dh1, G[n + ".conv1.bias"], per_sample=per, per_stride=self.w.proj_dim)
+        self._wgrad(x0, x1, rec.gn1, 1, dh1, G[n + ".conv1.weight"])
+        dz1 = self._dgrad(dh1, te.w1d, cin, tag="dz1")
+        self._gn_bwd(rec.gn1, dz1, 1, combined=True, res=res, wname=n + ".norm1")
+
+    def _attn_bwd(self, rec):
+        G, e, te, n = self.grads, rec.e, self.tw.attns[rec.name], rec.name
+        B, h, w, ch = rec.x.shape
+        N = h * w
+        dout = self._g(rec.out)[0]
+        self._bias_grad(dout, G[n + ".to_out.0.bias"])
+        self._wgrad(rec.o, None, None, 0, dout, G[n + ".to_out.0.weight"], ksize=1, pad=0)
+        do = self._dgrad(dout, te.wod, ch, ksize=1, tag="do")
+        dqkv = self._tmp((B, h, w, 3 * ch), "dqkv")
+        delta = self._tmp((B, e.heads, N), "delta", torch.float32)
+        a = L.AttnBwdArgs(dtype=self.code, B=B, heads=e.heads, N=N, q=rec.qkv[0].data_ptr(), k=rec.qkv[1].data_ptr(),
+                          v=rec.qkv[2].data_ptr(), o=rec.o.data_ptr(), dout=do.data_ptr(), lse=rec.lse.data_ptr(),
+                          delta=delta.data_ptr(), dqkv=dqkv.data_ptr())
+        self._b(self.lib.pd_attn_d8_bwd, a, "attn_d8_bwd", 10.0 * B * e.heads * N * N * 8, 8.0 * B * N * ch * self._esz())
+        self._bias_grad(dqkv, G[n + ".to_q.bias"])                       # [dq | dk | dv] biases are adjacent
+        self._wgrad(rec.x, None, rec.gn, 0, dqkv, G[n + ".to_q.weight"], ksize=1, pad=0)
+        dz = self._dgrad(dqkv, te.wqkvd, ch, ksize=1, tag="dzattn")
+        self._gn_bwd(rec.gn, dz, 0, res=dout, wname=n + ".group_norm")
+
+    def _temb_bwd(self):
+        m, w, G, P = self.m, self.w, self.grads, self.params
+        B, tdim, c0, pd = self.B, m.time_embed_dim, m.config.block_out_channels[0], w.proj_dim
+        first = next(n for n, mod in m.named_modules() if isinstance(mod, _Resnet))
+        lib = self.lib
+        demb, dz1 = self._f32(B, tdim), self._f32(B, tdim)
+        self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=tdim, out_dim=pd, x_silu=1, dy=self.dproj.data_ptr(),
+                x=self.t_emb.data_ptr(), dw=G[first + ".time_emb_proj.weight"].data_ptr(),
+                db=G[first + ".time_emb_proj.bias"].data_ptr()), "linear_wgrad")
+        self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=pd, dy=self.dproj.data_ptr(),
+                w=P[first + ".time_emb_proj.weight"].data_ptr(), pre=self.t_emb.data_ptr(), dx=demb.data_ptr()), "linear_dgrad")
+        if m.class_embedding is not None:
+            self._emb_grad_args = L.EmbeddingGradArgs(rows=B, dim=tdim, num_classes=m.class_embedding.weight.shape[0], labels=None,
+                                                      d=demb.data_ptr(), dtable=G["class_embedding.weight"].data_ptr())
+            self._emb_grad_at = len(self.bwd_ops)
+        self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=tdim, out_dim=tdim, x_silu=1, dy=demb.data_ptr(),
+                x=self.t_z1.data_ptr(), dw=G["time_embedding.linear_2.weight"].data_ptr(),
+                db=G["time_embedding.linear_2.bias"].data_ptr()), "linear_wgrad")
+        self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=tdim, dy=demb.data_ptr(),
+                w=P["time_embedding.linear_2.weight"].data_ptr(), pre=self.t_z1.data_ptr(), dx=dz1.data_ptr()), "linear_dgrad")
+        self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=c0, out_dim=tdim, x_silu=0, dy=dz1.data_ptr(),
+                x=self.t_feat.data_ptr(), dw=G["time_embedding.linear_1.weight"].data_ptr(),
+                db=G["time_embedding.linear_1.bias"].data_ptr()), "linear_wgrad")
+
+    # ---- execution -------------------------------------------------------------------------------
+    def backward(self, dout: torch.Tensor, stream):
+        """Accumulate d loss / d parameters into ``grads`` given ``dout`` = d loss / d (UNet output), fp32 NCHW."""
+        self._dout_args.x = dout.data_ptr()
+        byref, check = C.byref, L.check
+        labels = getattr(self, "_labels", None)
+        emb_at = getattr(self, "_emb_grad_at", -1)
+        for i, op in enumerate(self.bwd_ops):
+            if i == emb_at and labels is not None:
+                self._emb_grad_args.labels = labels.data_ptr()
+                check(self.lib.pd_embedding_grad(byref(self._emb_grad_args), stream), "pd_embedding_grad")
+            rc = op.fn(byref(op.args), stream)
+            if rc:
+                check(rc, op.what)
+        self._keep_dout = dout
+
+
+class UNetTrainer:
+    """One optimisation step of ``perform_training_epoch`` (``utils_training.py:244-454``) on the HIP engine:
+    forward -> loss (+ d loss / d out) -> backward -> [gradient all-reduce] -> clip + AdamW + EMA -> re-pack weights."""
+
+    def __init__(self, model: CustomCondUNet2DModel, scheduler, lr: float, *, device=None, use_ema: bool = True,
+                 max_grad_norm: Optional[float] = 1.0, **adamw):
+        from .training import DiffusionLoss, FlatAdamWEMA
+        self.model, self.scheduler = model, scheduler
+        dev = device or model.device
+        if torch.device(dev).type != "cuda":
+            raise L.PhenDiffHipError("phendiff_amd trains on MI355X only (no CPU fallback): move the model to 'cuda'")
+        order = training_param_order(model)
+        self.opt = FlatAdamWEMA([p for _, p in order], lr, use_ema=use_ema, max_grad_norm=max_grad_norm, **adamw)
+        self.params = {n: p.data for n, p in order}
+        self.grads = {n: p.grad for n, p in order}
+        model.invalidate()
+        self.loss_fn = DiffusionLoss(scheduler, dev)
+        self.device = dev
+        self._plans = {}
+        self._tw = None
+
+    def plan_for(self, B, H, W):
+        key = (B, H, W)
+        p = self._plans.get(key)
+        if p is None:
+            m = self.model
+            if m._weights is None:
+                m._weights = _PackedWeights(m, self.device)
+            if self._tw is None:
+                self._tw = TrainWeights(m, self.device, m._weights.tdt)
+            p = UNetTrainPlan(m, m._weights, self._tw, B, H, W, self.device, self.params, self.grads)
+            self._plans[key] = p
+        return p
+
+    def forward_backward(self, noisy, timesteps, clean, noise, class_labels=None, class_emb=None):
+        """Loss of one batch and its parameter gradients (accumulated into the flat gradient buffer)."""
+        B, _, H, W = noisy.shape
+        plan = self.plan_for(B, H, W)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        x = noisy.contiguous().float()
+        ts = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
+        labels = class_labels.to(device=self.device, dtype=torch.int64).contiguous() if class_labels is not None else None
+        cemb = class_emb.to(device=self.device, dtype=torch.float32).contiguous() if class_emb is not None else None
+        out = torch.empty_like(x)
+        plan.forward(x, ts, labels, cemb, out, st)
+        loss, dout = self.loss_fn(out, clean, noise, timesteps)
+        plan.backward(dout, st)
+        return loss, out
+
+    def step(self, noisy, timesteps, clean, noise, class_labels=None, class_emb=None, lr: Optional[float] = None, group=None):
+        from .training import allreduce_mean_
+        loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb)
+        allreduce_mean_(self.opt.grad, group)
+        self.opt.step(lr)
+        self.refresh_weights()
+        return loss
+
+    def refresh_weights(self):
+        """Parameters changed in place: rebuild the kernel-layout copies (same device buffers, plans stay valid)."""
+        m = self.model
+        if m._weights is not None:
+            m._weights.refresh(m)
+        if self._tw is not None:
+            self._tw.refresh(m)

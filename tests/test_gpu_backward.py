@@ -66,8 +66,9 @@ def test_conv_input_gradient_fused_upsample(env, mode):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("combined", [0, 1])
 @pytest.mark.parametrize("cfg", [(2, 64, 0, 16, 16, 1), (2, 128, 64, 8, 8, 1), (1, 256, 256, 8, 4, 0), (3, 32, 32, 4, 4, 1)])
-def test_groupnorm_silu_backward(env, mode, cfg):
+def test_groupnorm_silu_backward(env, mode, cfg, combined):
     L, lib, _, dev = env
     code, tdt = DT[mode]
     B, c0, c1, H, W, silu = cfg
@@ -84,6 +85,12 @@ def test_groupnorm_silu_backward(env, mode, cfg):
     xd = x.detach()
     X0, X1 = nhwc(xd[:, :c0].to(dev), tdt), (nhwc(xd[:, c0:].to(dev), tdt) if c1 else None)
     D0, D1 = nhwc(dz[:, :c0].to(dev), tdt), (nhwc(dz[:, c0:].to(dev), tdt) if c1 else None)
+    res = None
+    if combined:      # dz as one [C0+C1]-channel tensor + a skip gradient added to dx (the resnet-block use)
+        D0, D1 = nhwc(dz.to(dev), tdt), None
+        res = bf16_round(torch.randn(B, Cc, H, W, generator=g), mode)
+        rx = rx + res
+    RES = nhwc(res.to(dev), tdt) if res is not None else None
     splits = 4
     partial = torch.empty((B, splits, Cc, 2), dtype=torch.float64, device=dev)
     scale, shift = torch.empty((B, Cc), device=dev), torch.empty((B, Cc), device=dev)
@@ -105,7 +112,7 @@ def test_groupnorm_silu_backward(env, mode, cfg):
                     dz0=D0.data_ptr(), dz1=L.ptr(D1), mean=mean.data_ptr(), rstd=rstd.data_ptr(), gamma=gm.data_ptr(),
                     beta=bt.data_ptr(), partial=partial.data_ptr(), splits=splits, coef=coef.data_ptr(),
                     dx0=dx0.data_ptr(), dx1=L.ptr(dx1), accumulate0=1, accumulate1=0, dgamma=dgamma.data_ptr(),
-                    dbeta=dbeta.data_ptr())
+                    dbeta=dbeta.data_ptr(), dz_combined=int(bool(combined and c1)), res=L.ptr(RES))
     L.check(lib.pd_gn_silu_bwd(C.byref(b), stream()), "pd_gn_silu_bwd")
     torch.cuda.synchronize()
     tol = 2e-5 if mode == "f32" else TOL[mode]
