@@ -280,6 +280,7 @@ int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream);
 typedef struct {
   int dtype; int B, HW, C; const void* x; float* out; int out_stride; int accumulate;
   float* total; int total_valid;   /* optional [total_valid <= C]: total[c] += sum over samples of this call's per-sample sums */
+  float* workspace; int splits;    /* optional [B][splits][C] scratch: the pixels of a sample are split over `splits` workgroups */
 } pd_channel_sum_args;
 int pd_channel_sum(const pd_channel_sum_args* a, void* stream);
 
@@ -319,6 +320,19 @@ typedef struct {
 } pd_wgrad_args;
 size_t pd_conv_wgrad_workspace(const pd_wgrad_args* a);
 int pd_conv_wgrad(const pd_wgrad_args* a, void* stream);
+
+/* pd_pack_weight: fp32 master weights (nn.Conv2d OIHW / nn.Linear [out][in]) -> pd_conv's packed MFMA fragment order
+ * (phendiff_amd/packing.py: pack_conv_weight), on the device, after each optimizer step of a training run.
+ *   dgrad = 0: packed[co][ci][tap] = src[co][ci][tap]                   (src rows of src_in input channels)
+ *   dgrad = 1: packed[co][ci][tap] = src[ci][co][taps-1-tap]            (input-gradient weights, packing.dgrad_weight)
+ * cout/cin: valid packed rows / columns (zero beyond, up to cout_pad / cin_pad); dst_ct_stride: elements between consecutive
+ * 32-row tiles of dst (> the tile size when another conv's fragments follow each tile: the fused conv_shortcut). */
+typedef struct {
+  int dtype;
+  int cout, cin, cout_pad, cin_pad, ksize, src_in, dgrad;
+  const float* src; void* dst; long long dst_ct_stride;
+} pd_pack_weight_args;
+int pd_pack_weight(const pd_pack_weight_args* a, void* stream);
 
 /* pd_im2col3: out[n][y][x][ci*9+ky*3+kx] = x[n][ci][y+ky-1][x+kx-1] (zero padded; 27 of 32 channels used): the input of
  * conv_in seen as a 1x1 convolution, for its weight gradient (cond_unet_2d.py:127-129). x: NCHW fp32, C <= 3; out: NHWC dtype. */

@@ -68,7 +68,8 @@ class Pool2x2Args(C.Structure):
 
 class ChannelSumArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("x", vp), ("out", vp),
-                ("out_stride", C.c_int), ("accumulate", C.c_int), ("total", vp), ("total_valid", C.c_int)]
+                ("out_stride", C.c_int), ("accumulate", C.c_int), ("total", vp), ("total_valid", C.c_int),
+                ("workspace", vp), ("splits", C.c_int)]
 
 
 class NchwToNhwcArgs(C.Structure):
@@ -94,6 +95,12 @@ class WgradArgs(C.Structure):
                 ("upsample", C.c_int), ("silu", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("dy", vp),
                 ("slab", vp), ("slab_bytes", C.c_size_t), ("dw", vp), ("Cout_valid", C.c_int), ("Cin_valid", C.c_int),
                 ("accumulate", C.c_int)]
+
+
+class PackWeightArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("cout", C.c_int), ("cin", C.c_int), ("cout_pad", C.c_int), ("cin_pad", C.c_int),
+                ("ksize", C.c_int), ("src_in", C.c_int), ("dgrad", C.c_int), ("src", vp), ("dst", vp),
+                ("dst_ct_stride", C.c_longlong)]
 
 
 class Im2col3Args(C.Structure):
@@ -164,6 +171,7 @@ SYMBOLS = {
     "pd_conv_wgrad_workspace": (C.c_size_t, [C.POINTER(WgradArgs)]),
     "pd_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),
+    "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
     "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),
     "pd_grad_norm": (C.c_int, [vp, C.c_int64, vp, C.c_float, vp, vp, vp]),

@@ -13,43 +13,68 @@ __device__ __forceinline__ float dsilu(float y) {          // d/dy [y * sigmoid(
   const float s = 1.0f / (1.0f + __expf(-y));
   return s * (1.0f + y * (1.0f - s));
 }
+// bf16 path: v_exp_f32 + v_rcp_f32 (as the forward's silu_fast); fp32 validation path: accurate division
+template <typename T> __device__ __forceinline__ float dsilu_t(float y);
+template <> __device__ __forceinline__ float dsilu_t<float>(float y) { return dsilu(y); }
+template <> __device__ __forceinline__ float dsilu_t<bf16_t>(float y) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
+  return s * (1.0f + y * (1.0f - s));
+}
+
+// Thread -> (8-channel piece, pixel row) of one (sample, pixel split); the per-channel constants of the piece sit in
+// registers for the whole pixel loop.
+template <typename T>
+struct GnPiece {
+  int c8, cs, coff, dcs, dcoff;
+  bool first, active;
+  const T* xs; const T* ds;
+  float mu[8], rs[8], sc[8], sh[8];
+  __device__ __forceinline__ void init(const pd_gn_bwd_args& a, int n, int tid, int& prow, int& ppi) {
+    const int C = a.C0 + a.C1, gs = C / a.groups, PP = C / 8;
+    ppi = 256 / PP;
+    active = tid < ppi * PP;
+    const int piece = tid % PP;
+    prow = tid / PP;
+    c8 = piece * 8;
+    first = c8 < a.C0;
+    xs = (const T*)(first ? a.x0 : a.x1);
+    ds = (const T*)((first || a.dz_combined) ? a.dz0 : a.dz1);
+    cs = first ? a.C0 : a.C1; coff = first ? c8 : c8 - a.C0;
+    dcs = a.dz_combined ? C : cs; dcoff = a.dz_combined ? c8 : coff;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (c8 + j) / gs;
+      mu[j] = a.mean[n * a.groups + g]; rs[j] = a.rstd[n * a.groups + g];
+      sc[j] = rs[j] * a.gamma[c8 + j]; sh[j] = a.beta[c8 + j] - mu[j] * sc[j];     // y = sc*x + sh (the forward's affine)
+    }
+  }
+};
 
 // (1) per-(sample, split, channel) partial sums of dy and dy * xhat, coalesced 8-channel pieces
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args a) {
   using E = Elem<T>;
   __shared__ float red[256 * 16];
-  const int C = a.C0 + a.C1, gs = C / a.groups;
-  const int PP = C / 8, ppi = 256 / PP, nthr = ppi * PP;
+  const int C = a.C0 + a.C1, PP = C / 8;
   const int n = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
   const int per = (a.HW + a.splits - 1) / a.splits;
   const int p0 = split * per, p1 = min(a.HW, p0 + per);
   const int tid = threadIdx.x;
+  GnPiece<T> g;
+  int prow, ppi;
+  g.init(a, n, tid, prow, ppi);
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  if (tid < nthr) {
-    const int piece = tid % PP, prow = tid / PP, c8 = piece * 8;
-    const bool first = c8 < a.C0;
-    const T* xs = (const T*)(first ? a.x0 : a.x1);
-    const T* ds = (const T*)((first || a.dz_combined) ? a.dz0 : a.dz1);
-    const int cs = first ? a.C0 : a.C1, coff = first ? c8 : c8 - a.C0;
-    const int dcs = a.dz_combined ? C : cs, dcoff = a.dz_combined ? c8 : coff;
-    float mu[8], rs[8], ga[8], be[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int g = (c8 + j) / gs;
-      mu[j] = a.mean[n * a.groups + g]; rs[j] = a.rstd[n * a.groups + g]; ga[j] = a.gamma[c8 + j]; be[j] = a.beta[c8 + j];
-    }
+  if (g.active) {
     for (int p = p0 + prow; p < p1; p += ppi) {
       float xv[8], dv[8];
-      E::unpack(E::load(xs + ((size_t)n * a.HW + p) * cs + coff), xv);
-      E::unpack(E::load(ds + ((size_t)n * a.HW + p) * dcs + dcoff), dv);
+      E::unpack(E::load(g.xs + ((size_t)n * a.HW + p) * g.cs + g.coff), xv);
+      E::unpack(E::load(g.ds + ((size_t)n * a.HW + p) * g.dcs + g.dcoff), dv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float xh = (xv[j] - mu[j]) * rs[j];
-        const float dy = a.silu ? dv[j] * dsilu(ga[j] * xh + be[j]) : dv[j];
-        s1[j] += dy; s2[j] += dy * xh;
+        const float dy = a.silu ? dv[j] * dsilu_t<T>(g.sc[j] * xv[j] + g.sh[j]) : dv[j];
+        s1[j] += dy; s2[j] += dy * ((xv[j] - g.mu[j]) * g.rs[j]);
       }
     }
   }
@@ -65,7 +90,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args
   }
 }
 
-// (2) per-(sample, group) coefficients A/M, B/M and the parameter gradients dgamma, dbeta (+=)
+// (2) per-(sample, group) coefficients rstd*A/M, rstd*B/M and the parameter gradients dgamma, dbeta (+=)
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_args a) {
   __shared__ double s1[1024], s2[1024];
   const int C = a.C0 + a.C1, gs = C / a.groups, tid = threadIdx.x;
@@ -83,56 +108,63 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_ar
     if (tid < a.groups) {
       double A = 0.0, Bq = 0.0;
       for (int c = tid * gs; c < (tid + 1) * gs; ++c) { A += s1[c]; Bq += s2[c]; }
-      const double M = (double)gs * (double)a.HW;
-      a.coef[(n * a.groups + tid) * 2] = (float)(A / M);
-      a.coef[(n * a.groups + tid) * 2 + 1] = (float)(Bq / M);
+      const double M = (double)gs * (double)a.HW, r = (double)a.rstd[n * a.groups + tid];
+      a.coef[(n * a.groups + tid) * 2] = (float)(r * A / M);
+      a.coef[(n * a.groups + tid) * 2 + 1] = (float)(r * Bq / M);
     }
-  } else {   // last block: parameter gradients, summed over samples in a fixed order
-    for (int c = tid; c < C; c += 256) {
-      double d1 = 0.0, d2 = 0.0;
-      for (int n = 0; n < a.B; ++n)
-        for (int sp = 0; sp < a.splits; ++sp) {
-          const double* in = a.partial + (((size_t)n * a.splits + sp) * C + c) * 2;
-          d1 += in[0]; d2 += in[1];
-        }
+  } else {   // parameter gradients of 32 channels per block: 8 lanes share the (sample, split) terms of a channel, fixed order
+    const int c = (blockIdx.x - a.B) * 32 + (tid >> 3), q = tid & 7;
+    double d1 = 0.0, d2 = 0.0;
+    if (c < C) {
+      const int terms = a.B * a.splits;
+      for (int t = q; t < terms; t += 8) {
+        const double* in = a.partial + ((size_t)t * C + c) * 2;
+        d1 += in[0]; d2 += in[1];
+      }
+    }
+#pragma unroll
+    for (int msk = 1; msk < 8; msk <<= 1) { d1 += __shfl_xor(d1, msk); d2 += __shfl_xor(d2, msk); }
+    if (c < C && q == 0) {
       if (a.dbeta) a.dbeta[c] += (float)d1;
       if (a.dgamma) a.dgamma[c] += (float)d2;
     }
   }
 }
 
-// (3) dx = rstd * (gamma*dy - A/M - xhat*B/M)   (+= into dx when accumulate)
+// (3) dx = sc*dy - rstd*A/M - xhat*rstd*B/M   (+ dx when accumulate, + res)
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args a) {
   using E = Elem<T>;
-  const int C = a.C0 + a.C1, gs = C / a.groups, PP = C / 8;
-  const size_t total = (size_t)a.B * a.HW * PP;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int piece = (int)(idx % PP);
-    const size_t pixl = idx / PP;
-    const int n = (int)(pixl / a.HW);
-    const int c8 = piece * 8;
-    const bool first = c8 < a.C0;
-    const int cs = first ? a.C0 : a.C1, coff = first ? c8 : c8 - a.C0;
-    const size_t off = pixl * cs + coff;
-    T* dxp = (T*)(first ? a.dx0 : a.dx1);
-    if (!dxp) continue;
-    float xv[8], dv[8], acc[8];
-    E::unpack(E::load((const T*)(first ? a.x0 : a.x1) + off), xv);
-    const size_t doff = a.dz_combined ? pixl * C + c8 : off;
-    E::unpack(E::load((const T*)((first || a.dz_combined) ? a.dz0 : a.dz1) + doff), dv);
-    const bool accum = first ? a.accumulate0 : a.accumulate1;
+  const int C = a.C0 + a.C1, gs = C / a.groups;
+  const int n = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int per = (a.HW + a.splits - 1) / a.splits;
+  const int p0 = split * per, p1 = min(a.HW, p0 + per);
+  GnPiece<T> g;
+  int prow, ppi;
+  g.init(a, n, threadIdx.x, prow, ppi);
+  if (!g.active) return;
+  T* dxp = (T*)(g.first ? a.dx0 : a.dx1);
+  if (!dxp) return;
+  float ka[8], kb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int grp = (g.c8 + j) / gs;
+    ka[j] = a.coef[(n * a.groups + grp) * 2]; kb[j] = a.coef[(n * a.groups + grp) * 2 + 1];
+  }
+  const bool accum = g.first ? a.accumulate0 : a.accumulate1;
+  const bool has_res = a.res != nullptr;
+  for (int p = p0 + prow; p < p1; p += ppi) {
+    const size_t pixl = (size_t)n * a.HW + p;
+    const size_t off = pixl * g.cs + g.coff;
+    float xv[8], dv[8], acc[8], rv[8];
+    E::unpack(E::load(g.xs + off), xv);
+    E::unpack(E::load(g.ds + pixl * g.dcs + g.dcoff), dv);
     if (accum) E::unpack(E::load(dxp + off), acc);
-    float rv[8];
-    const bool has_res = a.res != nullptr;
-    if (has_res) E::unpack(E::load((const T*)a.res + pixl * C + c8), rv);
+    if (has_res) E::unpack(E::load((const T*)a.res + pixl * C + g.c8), rv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = c8 + j, g = c / gs;
-      const float mu = a.mean[n * a.groups + g], rs = a.rstd[n * a.groups + g];
-      const float xh = (xv[j] - mu) * rs;
-      const float dy = a.silu ? dv[j] * dsilu(a.gamma[c] * xh + a.beta[c]) : dv[j];
-      const float dx = rs * (a.gamma[c] * dy - a.coef[(n * a.groups + g) * 2] - xh * a.coef[(n * a.groups + g) * 2 + 1]);
+      const float dy = a.silu ? dv[j] * dsilu_t<T>(g.sc[j] * xv[j] + g.sh[j]) : dv[j];
+      const float dx = g.sc[j] * dy - ka[j] - ((xv[j] - g.mu[j]) * g.rs[j]) * kb[j];
       acc[j] = (accum ? acc[j] + dx : dx) + (has_res ? rv[j] : 0.f);
     }
     E::store(dxp + off, E::pack(acc));
@@ -175,13 +207,16 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_a
   using E = Elem<T>;
   __shared__ float red[256 * 8];
   const int PP = a.C / 8, ppi = 256 / PP, nthr = ppi * PP;
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int nsp = a.workspace ? a.splits : 1;
+  const int n = blockIdx.x / nsp, sp = blockIdx.x - n * nsp, tid = threadIdx.x;
+  const int per = (a.HW + nsp - 1) / nsp;
+  const int p_lo = sp * per, p_hi = min(a.HW, p_lo + per);
   float s[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
   if (tid < nthr) {
     const int piece = tid % PP, prow = tid / PP;
-    for (int p = prow; p < a.HW; p += ppi) {
+    for (int p = p_lo + prow; p < p_hi; p += ppi) {
       float v[8];
       E::unpack(E::load((const T*)a.x + ((size_t)n * a.HW + p) * a.C + piece * 8), v);
 #pragma unroll
@@ -194,9 +229,21 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_a
   for (int c = tid; c < a.C; c += 256) {
     double d = 0.0;
     for (int k = 0; k < ppi; ++k) d += (double)red[(k * PP + (c >> 3)) * 8 + (c & 7)];
+    if (a.workspace) { a.workspace[((size_t)n * nsp + sp) * a.C + c] = (float)d; continue; }
     float* o = a.out + (size_t)n * a.out_stride + c;
     *o = a.accumulate ? *o + (float)d : (float)d;
   }
+}
+
+// out[n][c] (+)= sum over splits of workspace[n][split][c]
+__global__ __launch_bounds__(256) void channel_sum_combine_kernel(const pd_channel_sum_args a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.B * a.C) return;
+  const int n = idx / a.C, c = idx - n * a.C;
+  float s = 0.f;
+  for (int sp = 0; sp < a.splits; ++sp) s += a.workspace[((size_t)n * a.splits + sp) * a.C + c];
+  float* o = a.out + (size_t)n * a.out_stride + c;
+  *o = a.accumulate ? *o + s : s;
 }
 
 // total[c] += sum_n per[n*stride + c]
@@ -240,14 +287,24 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const pd_linear_wgrad
   if (i == 0 && a.db) a.db[o] += sb;
 }
 
+// block = (row, 32 inputs) x 8 groups of outputs, combined in a fixed order
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const pd_linear_dgrad_args a) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)a.rows * a.in_dim) return;
-  const int r = (int)(idx / a.in_dim), i = (int)(idx % a.in_dim);
+  __shared__ float red[256];
+  const int chunks = (a.in_dim + 31) / 32;
+  const int r = blockIdx.x / chunks, i = (blockIdx.x - r * chunks) * 32 + (threadIdx.x & 31), og = threadIdx.x >> 5;
   float s = 0.f;
-  for (int o = 0; o < a.out_dim; ++o) s += a.dy[(size_t)r * a.out_dim + o] * a.w[(size_t)o * a.in_dim + i];
-  if (a.pre) s *= dsilu(a.pre[idx]);
-  a.dx[idx] = s;
+  if (i < a.in_dim)
+    for (int o = og; o < a.out_dim; o += 8) s += a.dy[(size_t)r * a.out_dim + o] * a.w[(size_t)o * a.in_dim + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (og == 0 && i < a.in_dim) {
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k * 32 + (threadIdx.x & 31)];
+    const size_t idx = (size_t)r * a.in_dim + i;
+    if (a.pre) s *= dsilu(a.pre[idx]);
+    a.dx[idx] = s;
+  }
 }
 
 __global__ __launch_bounds__(256) void embedding_grad_kernel(const pd_embedding_grad_args a) {
@@ -273,15 +330,14 @@ extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
   PD_CHECK((a->C1 == 0) == (a->x1 == nullptr) && (a->C1 == 0 || a->dz_combined) == (a->dz1 == nullptr), PD_ERR_ARG, "pd_gn_silu_bwd: source 1 mismatch");
   PD_CHECK(a->dx0 || a->dx1, PD_ERR_ARG, "pd_gn_silu_bwd: no output");
   hipStream_t st = (hipStream_t)stream;
-  const size_t total = (size_t)a->B * a->HW * (C / 8);
-  const unsigned agrid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const unsigned agrid = (unsigned)(a->B * a->splits);
   if (a->dtype == PD_F32) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + 1), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 31) / 32), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(agrid), dim3(256), 0, st, *a);
   } else if (a->dtype == PD_BF16) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + 1), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 31) / 32), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(agrid), dim3(256), 0, st, *a);
   } else { set_error("pd_gn_silu_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
@@ -301,10 +357,16 @@ extern "C" int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream) {
 
 extern "C" int pd_channel_sum(const pd_channel_sum_args* a, void* stream) {
   PD_CHECK(a != nullptr && a->B > 0 && a->HW > 0 && a->C > 0 && a->C % 8 == 0 && a->C / 8 <= 256 && a->x && a->out, PD_ERR_ARG, "pd_channel_sum: bad args");
-  if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
-  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_CHECK(!a->workspace || a->splits >= 1, PD_ERR_ARG, "pd_channel_sum: workspace without splits");
+  const int nblk = a->B * (a->workspace ? a->splits : 1);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_channel_sum: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
+  if (a->workspace) {
+    hipLaunchKernelGGL(channel_sum_combine_kernel, dim3((a->B * a->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    PD_LAUNCH_CHECK();
+  }
   if (a->total) {
     PD_CHECK(a->total_valid > 0 && a->total_valid <= a->C, PD_ERR_ARG, "pd_channel_sum: total_valid=%d", a->total_valid);
     PD_CHECK(!a->accumulate, PD_ERR_ARG, "pd_channel_sum: total needs this call's own per-sample sums (accumulate = 0)");
@@ -336,8 +398,7 @@ extern "C" int pd_linear_wgrad(const pd_linear_wgrad_args* a, void* stream) {
 
 extern "C" int pd_linear_dgrad(const pd_linear_dgrad_args* a, void* stream) {
   PD_CHECK(a != nullptr && a->rows > 0 && a->in_dim > 0 && a->out_dim > 0 && a->dy && a->w && a->dx, PD_ERR_ARG, "pd_linear_dgrad: bad args");
-  const size_t total = (size_t)a->rows * a->in_dim;
-  hipLaunchKernelGGL(linear_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(linear_dgrad_kernel, dim3((unsigned)(a->rows * ((a->in_dim + 31) / 32))), dim3(256), 0, (hipStream_t)stream, *a);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

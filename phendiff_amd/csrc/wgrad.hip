@@ -256,17 +256,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
   }
 }
 
-// dw[co][ci][tap] (+)= sum over splits of slab[split][tap][co][ci]; thread = (co, ci)
+// dw[co][ci][tap] (+)= sum over splits of slab[split][tap][co][ci].  Block = 64 consecutive slab elements (ci fastest:
+// coalesced) x 4 split groups; the groups are combined in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int taps,
                                                             int COP, int CIP, int cout_valid, int cin_valid, int accumulate) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= cout_valid * cin_valid) return;
-  const int co = idx / cin_valid, ci = idx - co * cin_valid;
-  for (int k = 0; k < taps; ++k) {
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += slab[(((size_t)sp * taps + k) * COP + co) * CIP + ci];
-    float* o = dw + ((size_t)co * cin_valid + ci) * taps + k;
-    *o = accumulate ? *o + s : s;
+  __shared__ float red[256];
+  const int tid = threadIdx.x, sg = tid >> 6;
+  const size_t per = (size_t)taps * COP * CIP;
+  const size_t e = (size_t)blockIdx.x * 64 + (tid & 63);       // (tap, co, ci) in slab order; per is a multiple of 64
+  float s = 0.f;
+  for (int sp = sg; sp < splits; sp += 4) s += slab[(size_t)sp * per + e];
+  red[tid] = s;
+  __syncthreads();
+  if (sg == 0) {
+    s = ((red[tid] + red[tid + 64]) + red[tid + 128]) + red[tid + 192];
+    const int ci = (int)(e % CIP);
+    const int co = (int)((e / CIP) % COP), k = (int)(e / ((size_t)CIP * COP));
+    if (co < cout_valid && ci < cin_valid) {
+      float* o = dw + ((size_t)co * cin_valid + ci) * taps + k;
+      *o = accumulate ? *o + s : s;
+    }
   }
 }
 
@@ -289,6 +298,40 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ 
     }
     Elem<T>::store(out + (idx >> 2) * 32 + sub * 8, Elem<T>::pack(v));
   }
+}
+
+// OIHW fp32 master weights -> pd_conv's packed fragment order [ct][chunk][tap][s][lane][j] (packing.py), optionally as the
+// input-gradient weights W'[ci][co][K-1-ky][K-1-kx]; thread = one 8-element lane fragment
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const pd_pack_weight_args a) {
+  const int taps = a.ksize * a.ksize;
+  const int chunks = a.cin_pad / 32, cts = a.cout_pad / 32;
+  const size_t total = (size_t)cts * chunks * taps * 2 * 64;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  size_t rest = idx >> 6;
+  const int sidx = (int)(rest & 1); rest >>= 1;
+  const int tap = (int)(rest % taps); rest /= taps;
+  const int chunk = (int)(rest % chunks);
+  const int ct = (int)(rest / chunks);
+  const int r = lane & 31, h = lane >> 5;
+  const int co = ct * 32 + r;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = chunk * 32 + sidx * 16 + h * 8 + j;
+    float x = 0.f;
+    if (co < a.cout && ci < a.cin) {
+      // packed (co, ci, tap) reads src[o][i][t]: forward o=co,i=ci,t=tap; input-gradient o=ci,i=co,t=taps-1-tap
+      const size_t o = a.dgrad ? ci : co, i = a.dgrad ? co : ci;
+      const int t = a.dgrad ? taps - 1 - tap : tap;
+      x = a.src[(o * a.src_in + i) * taps + t];
+    }
+    v[j] = x;
+  }
+  T* dst = (T*)a.dst + (size_t)ct * a.dst_ct_stride + ((((size_t)chunk * taps + tap) * 2 + sidx) * 64 + lane) * 8;
+  Elem<T>::store(dst, Elem<T>::pack(v));
 }
 
 static int pick_splits(int ntiles, int ncombo) {
@@ -337,8 +380,8 @@ static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cf::LDS_BYTES, st, p);
   PD_LAUNCH_CHECK();
   const int cout_v = a->Cout_valid > 0 ? a->Cout_valid : a->Cout, cin_v = a->Cin_valid > 0 ? a->Cin_valid : cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cout_v * cin_v + 255) / 256), dim3(256), 0, st, (const float*)a->slab, a->dw, splits,
-                     Cf::TAPS, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((size_t)Cf::TAPS * p.COP * p.CIP / 64)), dim3(256), 0, st, (const float*)a->slab,
+                     a->dw, splits, Cf::TAPS, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
@@ -394,6 +437,21 @@ extern "C" int pd_im2col3(const pd_im2col3_args* a, void* stream) {
   if (a->dtype == PD_F32) hipLaunchKernelGGL(im2col3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (float*)a->out, a->B, a->H, a->W, a->C);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(im2col3_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (bf16_t*)a->out, a->B, a->H, a->W, a->C);
   else { set_error("pd_im2col3: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_pack_weight(const pd_pack_weight_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->src && a->dst && a->cout > 0 && a->cin > 0 && a->ksize >= 1 && a->src_in > 0, PD_ERR_ARG, "pd_pack_weight: bad args");
+  PD_CHECK(a->cout_pad % 32 == 0 && a->cin_pad % 32 == 0 && a->cout_pad >= a->cout && a->cin_pad >= a->cin, PD_ERR_SHAPE,
+           "pd_pack_weight: padded sizes must be multiples of 32 (cout %d/%d, cin %d/%d)", a->cout, a->cout_pad, a->cin, a->cin_pad);
+  const size_t per_ct = (size_t)(a->cin_pad / 32) * a->ksize * a->ksize * 2 * 64 * 8;
+  PD_CHECK((size_t)a->dst_ct_stride >= per_ct, PD_ERR_ARG, "pd_pack_weight: dst_ct_stride too small");
+  const size_t total = (size_t)(a->cout_pad / 32) * (a->cin_pad / 32) * a->ksize * a->ksize * 2 * 64;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_pack_weight: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

@@ -595,9 +595,12 @@ class UNetPlan:
         """Per-kernel-kind device time of one UNet evaluation, measured with HIP events recorded on the launch
         stream between consecutive launches (``pd_event_*``).  Returns {kind: dict(ms, launches, flops, bytes)}
         averaged over ``reps`` evaluations."""
-        lib = self.lib
         self.run(x_ptr, temb_ptr, out_ptr, stream)  # warm (also sets the pointers)
-        nev = len(self.ops) + 1
+        return self._profile_ops(self.ops, stream, reps)
+
+    def _profile_ops(self, ops, stream, reps=3):
+        lib = self.lib
+        nev = len(ops) + 1
         evs = []
         for _ in range(nev):
             e = C.c_void_p()
@@ -605,12 +608,12 @@ class UNetPlan:
             evs.append(e)
         acc = {}
         for _ in range(reps):
-            for i, op in enumerate(self.ops):
+            for i, op in enumerate(ops):
                 L.check(lib.pd_event_record(evs[i], stream), "pd_event_record")
                 L.check(op.fn(C.byref(op.args), stream), op.what)
             L.check(lib.pd_event_record(evs[-1], stream), "pd_event_record")
             ms = C.c_float()
-            for i, op in enumerate(self.ops):
+            for i, op in enumerate(ops):
                 L.check(lib.pd_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)), "pd_event_elapsed_ms")
                 d = acc.setdefault(op.what, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
                 d["ms"] += ms.value / reps

@@ -174,8 +174,11 @@ class UNetTrainPlan(UNetPlan):
     def _bias_grad(self, dy, total, valid=None, per_sample=None, per_stride=None):
         B, h, w, ch = dy.shape
         out = per_sample if per_sample is not None else self._tmp((B, ch), "chsum", torch.float32)
+        splits = max(1, min(64, (h * w) // 64))
+        ws = self._tmp((B * splits * ch,), "chsum_ws", torch.float32)
         a = L.ChannelSumArgs(dtype=self.code, B=B, HW=h * w, C=ch, x=dy.data_ptr(), out=out.data_ptr(),
-                             out_stride=per_stride or ch, accumulate=0, total=total.data_ptr(), total_valid=valid or ch)
+                             out_stride=per_stride or ch, accumulate=0, total=total.data_ptr(), total_valid=valid or ch,
+                             workspace=ws.data_ptr(), splits=splits)
         self._b(self.lib.pd_channel_sum, a, "channel_sum", 0.0, dy.numel() * self._esz())
 
     def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0):
@@ -217,7 +220,7 @@ class UNetTrainPlan(UNetPlan):
         c1 = x1.shape[3] if x1 is not None else 0
         g0 = self._g(x0)
         g1 = self._g(x1) if x1 is not None else None
-        splits = max(1, min(64, (h * w) // 256))
+        splits = max(1, min(64, (h * w) // 64, -(-1024 // B)))
         partial = self._tmp((B * splits * (c0 + c1) * 2,), "gnpart", torch.float64)
         coef = self._tmp((B, self.groups, 2), "gncoef", torch.float32)
         a = L.GnBwdArgs(dtype=self.code, B=B, HW=h * w, C0=c0, C1=c1, groups=self.groups, silu=silu, x0=x0.data_ptr(),
@@ -375,6 +378,94 @@ class UNetTrainPlan(UNetPlan):
         self._keep_dout = dout
 
 
+class _Repacker:
+    """After an optimizer step: fp32 master parameters -> every kernel-layout copy the plans read (``_PackedWeights`` and
+    ``TrainWeights`` tensors, IN PLACE), as ``pd_pack_weight`` launches plus a handful of small fp32 copies.  Parameters
+    that the kernels read as plain fp32 vectors (GroupNorm affine, most biases, the class table) alias the flat master
+    buffer and need nothing."""
+
+    def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, tw: TrainWeights):
+        self.lib = L.lib()
+        self.jobs, self.small = [], []
+        code = w.code
+
+        def job(dst, src, cout, cin, k, *, dgrad=0, cout_pad=None, cin_pad=None, src_in=None, ct_stride=None, dst_off=0):
+            cp = cout_pad or ((cout + 31) // 32) * 32
+            ip = cin_pad or ((cin + 31) // 32) * 32
+            per_ct = (ip // 32) * k * k * 2 * 64 * 8
+            esz = dst.element_size()
+            self.jobs.append(L.PackWeightArgs(dtype=code, cout=cout, cin=cin, cout_pad=cp, cin_pad=ip, ksize=k,
+                                              src_in=src_in or (cout if dgrad else cin), dgrad=dgrad, src=src.data_ptr(),
+                                              dst=dst.data_ptr() + dst_off * esz, dst_ct_stride=ct_stride or per_ct))
+
+        ci = m.conv_in.weight.shape[1]
+        job(w.conv_in_wv, m.conv_in.weight, m.conv_in.weight.shape[0], ci * 9, 1, cin_pad=32)
+        for name, mod in m.named_modules():
+            if isinstance(mod, _Resnet):
+                e, t = w.resnets[name], tw.resnets[name]
+                cin, cout = mod.in_channels, mod.out_channels
+                job(e.w1, mod.conv1.weight, cout, cin, 3)
+                stride = e.w2[0].numel()
+                job(e.w2, mod.conv2.weight, cout, cout, 3, ct_stride=stride)
+                job(t.w1d, mod.conv1.weight, cin, cout, 3, dgrad=1)
+                job(t.w2d, mod.conv2.weight, cout, cout, 3, dgrad=1)
+                if mod.conv_shortcut is not None:
+                    job(e.w2, mod.conv_shortcut.weight, cout, cin, 1, ct_stride=stride, dst_off=(cout // 32) * 9 * 2 * 512)
+                    job(t.wsd, mod.conv_shortcut.weight, cin, cout, 1, dgrad=1)
+                    b2, bs, dst = mod.conv2.bias, mod.conv_shortcut.bias, e.b2
+                    self.small.append(lambda b2=b2, bs=bs, dst=dst: torch.add(b2.data, bs.data, out=dst))
+            elif isinstance(mod, _Attention):
+                e, t = w.attns[name], tw.attns[name]
+                ch = mod.to_q.weight.shape[0]
+                if not (_contiguous_after(mod.to_q.weight.data, mod.to_k.weight.data)
+                        and _contiguous_after(mod.to_k.weight.data, mod.to_v.weight.data)
+                        and _contiguous_after(mod.to_q.bias.data, mod.to_k.bias.data)
+                        and _contiguous_after(mod.to_k.bias.data, mod.to_v.bias.data)):
+                    raise ValueError("to_q/to_k/to_v parameters must be adjacent (use training_param_order)")
+                job(e.wqkv, mod.to_q.weight, 3 * ch, ch, 1)
+                job(e.wo, mod.to_out[0].weight, ch, ch, 1)
+                job(t.wqkvd, mod.to_q.weight, ch, 3 * ch, 1, dgrad=1)
+                job(t.wod, mod.to_out[0].weight, ch, ch, 1, dgrad=1)
+                qb, dst = mod.to_q.bias, e.bqkv
+                self.small.append(lambda qb=qb, dst=dst, ch=ch: dst.copy_(torch.as_strided(qb.data, (3 * ch,), (1,))))
+            elif isinstance(mod, _Sampler):
+                ch = mod.conv.weight.shape[0]
+                job(w.samplers[name].w, mod.conv.weight, ch, ch, 3)
+                job(tw.samplers[name].wd, mod.conv.weight, ch, ch, 3, dgrad=1)
+        co, c0 = m.conv_out.weight.shape[0], m.conv_out.weight.shape[1]
+        job(w.conv_out_w, m.conv_out.weight, co, c0, 3, cout_pad=w.conv_out_pad)
+        job(tw.conv_out_d, m.conv_out.weight, c0, co, 3, dgrad=1, cin_pad=w.conv_out_pad)
+        te = m.time_embedding
+        res = [mod for _, mod in m.named_modules() if isinstance(mod, _Resnet)]
+        pd_, tdim = w.proj_dim, m.time_embed_dim
+        first = res[0].time_emb_proj
+        self.small += [
+            lambda: w.w1T.copy_(te.linear_1.weight.data.t()),
+            lambda: w.w2T.copy_(te.linear_2.weight.data.t()),
+            lambda: w.wpT.copy_(torch.as_strided(first.weight.data, (pd_, tdim), (tdim, 1)).t()),
+            lambda: w.bp.copy_(torch.as_strided(first.bias.data, (pd_,), (1,))),
+            lambda: w.conv_out_b[:co].copy_(m.conv_out.bias.data),
+        ]
+        for t in (w.b1, w.b2, w.conv_in_b):
+            pass  # alias the master parameters (fp32, contiguous, same device): nothing to refresh
+        self._alias_check = [(w.b1, te.linear_1.bias), (w.b2, te.linear_2.bias), (w.conv_in_b, m.conv_in.bias),
+                             (w.gn_out[0], m.conv_norm_out.weight)]
+        for a, b in self._alias_check:
+            if a.data_ptr() != b.data_ptr():
+                raise RuntimeError("kernel-side fp32 vectors must alias the master parameters (build the packed weights "
+                                   "after the parameters were moved into the flat training buffer)")
+
+    def run(self, stream):
+        byref, check, fn = C.byref, L.check, self.lib.pd_pack_weight
+        for a in self.jobs:
+            rc = fn(byref(a), stream)
+            if rc:
+                check(rc, "pd_pack_weight")
+        with torch.no_grad():
+            for f in self.small:
+                f()
+
+
 class UNetTrainer:
     """One optimisation step of ``perform_training_epoch`` (``utils_training.py:244-454``) on the HIP engine:
     forward -> loss (+ d loss / d out) -> backward -> [gradient all-reduce] -> clip + AdamW + EMA -> re-pack weights."""
@@ -395,6 +486,7 @@ class UNetTrainer:
         self.device = dev
         self._plans = {}
         self._tw = None
+        self._repack = None
 
     def plan_for(self, B, H, W):
         key = (B, H, W)
@@ -435,7 +527,8 @@ class UNetTrainer:
     def refresh_weights(self):
         """Parameters changed in place: rebuild the kernel-layout copies (same device buffers, plans stay valid)."""
         m = self.model
-        if m._weights is not None:
-            m._weights.refresh(m)
-        if self._tw is not None:
-            self._tw.refresh(m)
+        if m._weights is None or self._tw is None:
+            return
+        if self._repack is None:
+            self._repack = _Repacker(m, m._weights, self._tw)
+        self._repack.run(torch.cuda.current_stream(self.device).cuda_stream)

@@ -119,3 +119,31 @@ def test_training_step_bf16_reduces_loss():
     tr = UNetTrainer(m, sched, lr=5e-4)
     losses = [float(tr.step(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())) for _ in range(8)]
     assert all(l == l for l in losses) and losses[-1] < 0.8 * losses[0], losses
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_device_repack_equals_host_packing(mode):
+    """After an optimizer step the pd_pack_weight path must leave exactly what packing.py builds from the new parameters."""
+    from phendiff_amd.unet import _PackedWeights
+    from phendiff_amd.unet_train import TrainWeights, UNetTrainer
+    _, m = make_pair("super_small", 32, mode)
+    sched, clean, noise, ts, labels, noisy, _ = batch(2, 32)
+    tr = UNetTrainer(m, sched, lr=1e-3)
+    tr.step(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    fresh_w, fresh_t = _PackedWeights(m, "cuda:0"), TrainWeights(m, "cuda:0", m._weights.tdt)
+
+    def same(a, b, path):
+        items = b.items() if isinstance(b, dict) else vars(b).items()
+        for k, v in items:
+            d = a[k] if isinstance(a, dict) else getattr(a, k)
+            if torch.is_tensor(v):
+                assert torch.equal(d, v), f"{path}.{k}"
+            elif isinstance(v, (dict,)) or hasattr(v, "__dict__") and not isinstance(v, (str, torch.dtype, torch.device)):
+                same(d, v, f"{path}.{k}")
+            elif isinstance(v, tuple):
+                for i, (dd, vv) in enumerate(zip(d, v)):
+                    if torch.is_tensor(vv):
+                        assert torch.equal(dd, vv), f"{path}.{k}[{i}]"
+    same(m._weights, fresh_w, "w")
+    same(tr._tw, fresh_t, "tw")
