@@ -13,3 +13,4 @@ from .img2img import (inversion, ddib, inverted_regeneration, classifier_free_gu
                       CFGForwardStartGraph, shard_batches, swap_binary_labels)
 from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401
 from . import training  # noqa: F401
+from .unet_train import UNetTrainer, UNetTrainPlan, training_param_order  # noqa: F401

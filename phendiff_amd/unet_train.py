@@ -103,6 +103,7 @@ class UNetTrainPlan(UNetPlan):
         self.t_feat, self.t_z1, self.t_emb = self._f32(B, c0), self._f32(B, tdim), self._f32(B, tdim)
         self.temb_table = self._f32(B, w.proj_dim)
         self.bwd_ops: List[_Op] = []
+        self.grad_ready: Dict[str, int] = {}   # parameter name -> index of the last backward op that writes its gradient
         self._emb_grad_op = None
         self._gact = {}
         self._tmp_cache = {}
@@ -168,6 +169,13 @@ class UNetTrainPlan(UNetPlan):
     def _b(self, fn, args, what, flops=0.0, nbytes=0.0):
         self.bwd_ops.append(_Op(fn, args, what, flops, nbytes))
 
+    def _G(self, name, span=()):
+        """Gradient tensor of a parameter, noting that the NEXT emitted op writes it (and the parameters fused behind it:
+        ``span``) -- the schedule the overlapped data-parallel all-reduce follows."""
+        for n in (name,) + tuple(span):
+            self.grad_ready[n] = len(self.bwd_ops)
+        return self.grads[name]
+
     def _esz(self):
         return 2 if self.code == L.PD_BF16 else 4
 
@@ -228,7 +236,7 @@ class UNetTrainPlan(UNetPlan):
                         gamma=s.gamma.data_ptr(), beta=s.beta.data_ptr(), partial=partial.data_ptr(), splits=splits,
                         coef=coef.data_ptr(), dx0=g0[0].data_ptr(), dx1=(g1[0].data_ptr() if g1 else None),
                         accumulate0=int(g0[1]), accumulate1=int(g1[1]) if g1 else 0,
-                        dgamma=self.grads[wname + ".weight"].data_ptr(), dbeta=self.grads[wname + ".bias"].data_ptr(),
+                        dgamma=self._G(wname + ".weight").data_ptr(), dbeta=self._G(wname + ".bias").data_ptr(),
                         dz_combined=1 if (combined and c1) else 0, res=L.ptr(res))
         g0[1] = True
         if g1:
@@ -239,8 +247,8 @@ class UNetTrainPlan(UNetPlan):
     # ---- backward plan ---------------------------------------------------------------------------
     def _build_backward(self):
         m, w, tw, c = self.m, self.w, self.tw, self.m.config
+        G = self._G
         B, H, W = self.B, self.H, self.W
-        G = self.grads
         boc0 = c.block_out_channels[0]
         maxc = max(max(c.block_out_channels) * 3, 64)
         self._zero_bias = torch.zeros(maxc + 64, dtype=torch.float32, device=self.device)
@@ -253,8 +261,8 @@ class UNetTrainPlan(UNetPlan):
                                      out=dy.data_ptr())
                 self._dout_args = a
                 self._b(self.lib.pd_nchw_to_nhwc, a, "nchw_to_nhwc", 0.0, B * H * W * c.out_channels * 4.0)
-                self._bias_grad(dy, G["conv_out.bias"], valid=c.out_channels)
-                self._wgrad(rec.x, None, rec.gn, 1, dy, G["conv_out.weight"], cout_valid=c.out_channels)
+                self._bias_grad(dy, G("conv_out.bias"), valid=c.out_channels)
+                self._wgrad(rec.x, None, rec.gn, 1, dy, G("conv_out.weight"), cout_valid=c.out_channels)
                 dz = self._dgrad(dy, tw.conv_out_d, boc0)
                 self._gn_bwd(rec.gn, dz, 1, wname="conv_norm_out")
             elif k == "resnet":
@@ -265,13 +273,13 @@ class UNetTrainPlan(UNetPlan):
                 if rec.e.padding != 1:
                     raise NotImplementedError("training: Downsample2D with padding != 1")
                 dout = self._g(rec.out)[0]
-                self._bias_grad(dout, G[rec.name + ".conv.bias"])
-                self._wgrad(rec.x, None, None, 0, dout, G[rec.name + ".conv.weight"], stride=2, pad=1)
+                self._bias_grad(dout, G(rec.name + ".conv.bias"))
+                self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), stride=2, pad=1)
                 self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], zero_stuff=True, into=self._g(rec.x))
             elif k == "up":
                 dout = self._g(rec.out)[0]
-                self._bias_grad(dout, G[rec.name + ".conv.bias"])
-                self._wgrad(rec.x, None, None, 0, dout, G[rec.name + ".conv.weight"], upsample=1)
+                self._bias_grad(dout, G(rec.name + ".conv.bias"))
+                self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), upsample=1)
                 du = self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], tag="du")
                 gx = self._g(rec.x)
                 _, h, ww, ch = rec.x.shape
@@ -281,12 +289,12 @@ class UNetTrainPlan(UNetPlan):
                 self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
             elif k == "conv_in":
                 dout = self._g(rec.out)[0]
-                self._bias_grad(dout, G["conv_in.bias"])
+                self._bias_grad(dout, G("conv_in.bias"))
                 cols = self._tmp((B, H, W, 32), "im2col")
                 a = L.Im2col3Args(dtype=self.code, B=B, H=H, W=W, C=c.in_channels, x=None, out=cols.data_ptr())
                 self._sample_ptr_args.append(a)
                 self._b(self.lib.pd_im2col3, a, "im2col3", 0.0, cols.numel() * self._esz())
-                self._wgrad(cols, None, None, 0, dout, G["conv_in.weight"], ksize=1, pad=0, cin_valid=c.in_channels * 9)
+                self._wgrad(cols, None, None, 0, dout, G("conv_in.weight"), ksize=1, pad=0, cin_valid=c.in_channels * 9)
         self._temb_bwd()
         # one slab serves every weight-gradient launch (they run back to back on one stream)
         need = max(self.lib.pd_conv_wgrad_workspace(C.byref(a)) for a in self._wgrad_args)
@@ -295,16 +303,17 @@ class UNetTrainPlan(UNetPlan):
             a.slab, a.slab_bytes = self.slab.data_ptr(), need
 
     def _resnet_bwd(self, rec):
-        G, e, te = self.grads, rec.e, self.tw.resnets[rec.name]
+        e, te = rec.e, self.tw.resnets[rec.name]
+        G = self._G
         n = rec.name
         x0, x1 = rec.x0, rec.x1
         cin = e.cin
         dout = self._g(rec.out)[0]
-        self._bias_grad(dout, G[n + ".conv2.bias"])
-        self._wgrad(rec.h1, None, rec.gn2, 1, dout, G[n + ".conv2.weight"])
+        self._bias_grad(dout, G(n + ".conv2.bias"))
+        self._wgrad(rec.h1, None, rec.gn2, 1, dout, G(n + ".conv2.weight"))
         if e.fused_shortcut:
-            self._bias_grad(dout, G[n + ".conv_shortcut.bias"])
-            self._wgrad(x0, x1, None, 0, dout, G[n + ".conv_shortcut.weight"], ksize=1, pad=0)
+            self._bias_grad(dout, G(n + ".conv_shortcut.bias"))
+            self._wgrad(x0, x1, None, 0, dout, G(n + ".conv_shortcut.weight"), ksize=1, pad=0)
             res = self._dgrad(dout, te.wsd, cin, ksize=1, tag="dshort")
         else:
             res = dout
@@ -313,18 +322,19 @@ class UNetTrainPlan(UNetPlan):
         dh1 = self._g(rec.h1)[0]
         # d time_emb_proj output [n][co] = sum over pixels of d h1 (the projection is broadcast over the pixels)
         per = self.dproj[:, e.temb_off:]
-        self._bias_grad(dh1, G[n + ".conv1.bias"], per_sample=per, per_stride=self.w.proj_dim)
-        self._wgrad(x0, x1, rec.gn1, 1, dh1, G[n + ".conv1.weight"])
+        self._bias_grad(dh1, G(n + ".conv1.bias"), per_sample=per, per_stride=self.w.proj_dim)
+        self._wgrad(x0, x1, rec.gn1, 1, dh1, G(n + ".conv1.weight"))
         dz1 = self._dgrad(dh1, te.w1d, cin, tag="dz1")
         self._gn_bwd(rec.gn1, dz1, 1, combined=True, res=res, wname=n + ".norm1")
 
     def _attn_bwd(self, rec):
-        G, e, te, n = self.grads, rec.e, self.tw.attns[rec.name], rec.name
+        e, te, n = rec.e, self.tw.attns[rec.name], rec.name
+        G = self._G
         B, h, w, ch = rec.x.shape
         N = h * w
         dout = self._g(rec.out)[0]
-        self._bias_grad(dout, G[n + ".to_out.0.bias"])
-        self._wgrad(rec.o, None, None, 0, dout, G[n + ".to_out.0.weight"], ksize=1, pad=0)
+        self._bias_grad(dout, G(n + ".to_out.0.bias"))
+        self._wgrad(rec.o, None, None, 0, dout, G(n + ".to_out.0.weight"), ksize=1, pad=0)
         do = self._dgrad(dout, te.wod, ch, ksize=1, tag="do")
         dqkv = self._tmp((B, h, w, 3 * ch), "dqkv")
         delta = self._tmp((B, e.heads, N), "delta", torch.float32)
@@ -332,38 +342,42 @@ class UNetTrainPlan(UNetPlan):
                           v=rec.qkv[2].data_ptr(), o=rec.o.data_ptr(), dout=do.data_ptr(), lse=rec.lse.data_ptr(),
                           delta=delta.data_ptr(), dqkv=dqkv.data_ptr())
         self._b(self.lib.pd_attn_d8_bwd, a, "attn_d8_bwd", 10.0 * B * e.heads * N * N * 8, 8.0 * B * N * ch * self._esz())
-        self._bias_grad(dqkv, G[n + ".to_q.bias"])                       # [dq | dk | dv] biases are adjacent
-        self._wgrad(rec.x, None, rec.gn, 0, dqkv, G[n + ".to_q.weight"], ksize=1, pad=0)
+        self._bias_grad(dqkv, G(n + ".to_q.bias", (n + ".to_k.bias", n + ".to_v.bias")))                       # [dq | dk | dv] biases are adjacent
+        self._wgrad(rec.x, None, rec.gn, 0, dqkv, G(n + ".to_q.weight", (n + ".to_k.weight", n + ".to_v.weight")), ksize=1, pad=0)
         dz = self._dgrad(dqkv, te.wqkvd, ch, ksize=1, tag="dzattn")
         self._gn_bwd(rec.gn, dz, 0, res=dout, wname=n + ".group_norm")
 
     def _temb_bwd(self):
-        m, w, G, P = self.m, self.w, self.grads, self.params
+        m, w, P = self.m, self.w, self.params
+        G = self._G
         B, tdim, c0, pd = self.B, m.time_embed_dim, m.config.block_out_channels[0], w.proj_dim
-        first = next(n for n, mod in m.named_modules() if isinstance(mod, _Resnet))
+        res = [n for n, mod in m.named_modules() if isinstance(mod, _Resnet)]
+        first = res[0]
         lib = self.lib
         demb, dz1 = self._f32(B, tdim), self._f32(B, tdim)
         self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=tdim, out_dim=pd, x_silu=1, dy=self.dproj.data_ptr(),
-                x=self.t_emb.data_ptr(), dw=G[first + ".time_emb_proj.weight"].data_ptr(),
-                db=G[first + ".time_emb_proj.bias"].data_ptr()), "linear_wgrad")
+                x=self.t_emb.data_ptr(),
+                dw=G(first + ".time_emb_proj.weight", [r + ".time_emb_proj.weight" for r in res[1:]]).data_ptr(),
+                db=G(first + ".time_emb_proj.bias", [r + ".time_emb_proj.bias" for r in res[1:]]).data_ptr()), "linear_wgrad")
         self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=pd, dy=self.dproj.data_ptr(),
                 w=P[first + ".time_emb_proj.weight"].data_ptr(), pre=self.t_emb.data_ptr(), dx=demb.data_ptr()), "linear_dgrad")
         if m.class_embedding is not None:
             self._emb_grad_args = L.EmbeddingGradArgs(rows=B, dim=tdim, num_classes=m.class_embedding.weight.shape[0], labels=None,
-                                                      d=demb.data_ptr(), dtable=G["class_embedding.weight"].data_ptr())
+                                                      d=demb.data_ptr(), dtable=G("class_embedding.weight").data_ptr())
             self._emb_grad_at = len(self.bwd_ops)
         self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=tdim, out_dim=tdim, x_silu=1, dy=demb.data_ptr(),
-                x=self.t_z1.data_ptr(), dw=G["time_embedding.linear_2.weight"].data_ptr(),
-                db=G["time_embedding.linear_2.bias"].data_ptr()), "linear_wgrad")
+                x=self.t_z1.data_ptr(), dw=G("time_embedding.linear_2.weight").data_ptr(),
+                db=G("time_embedding.linear_2.bias").data_ptr()), "linear_wgrad")
         self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=tdim, dy=demb.data_ptr(),
                 w=P["time_embedding.linear_2.weight"].data_ptr(), pre=self.t_z1.data_ptr(), dx=dz1.data_ptr()), "linear_dgrad")
         self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=c0, out_dim=tdim, x_silu=0, dy=dz1.data_ptr(),
-                x=self.t_feat.data_ptr(), dw=G["time_embedding.linear_1.weight"].data_ptr(),
-                db=G["time_embedding.linear_1.bias"].data_ptr()), "linear_wgrad")
+                x=self.t_feat.data_ptr(), dw=G("time_embedding.linear_1.weight").data_ptr(),
+                db=G("time_embedding.linear_1.bias").data_ptr()), "linear_wgrad")
 
     # ---- execution -------------------------------------------------------------------------------
-    def backward(self, dout: torch.Tensor, stream):
-        """Accumulate d loss / d parameters into ``grads`` given ``dout`` = d loss / d (UNet output), fp32 NCHW."""
+    def backward(self, dout: torch.Tensor, stream, after_op=None):
+        """Accumulate d loss / d parameters into ``grads`` given ``dout`` = d loss / d (UNet output), fp32 NCHW.
+        ``after_op``: {op index: callable} run right after that op was enqueued (gradient buckets becoming final)."""
         self._dout_args.x = dout.data_ptr()
         byref, check = C.byref, L.check
         labels = getattr(self, "_labels", None)
@@ -375,7 +389,30 @@ class UNetTrainPlan(UNetPlan):
             rc = op.fn(byref(op.args), stream)
             if rc:
                 check(rc, op.what)
+            if after_op is not None:
+                f = after_op.get(i)
+                if f is not None:
+                    f()
         self._keep_dout = dout
+
+
+def plan_grad_buckets(sizes: List[int], ready: List[int], bucket_elems: int) -> List[Tuple[int, int, int]]:
+    """Cut a flat gradient buffer (parameters of ``sizes`` elements, in buffer order; gradient ``i`` final after backward
+    op ``ready[i]``) into contiguous buckets of about ``bucket_elems`` elements.  Returns (start, end, ready_op) per bucket
+    sorted by ``ready_op``: the order in which the buckets can be all-reduced while the backward is still running.
+    Buckets are few and large on purpose: an xGMI ring all-reduce is per-link bound, so small messages waste it."""
+    out, start, acc, rdy = [], 0, 0, -1
+    off = 0
+    for sz, r in zip(sizes, ready):
+        off += sz
+        acc += sz
+        rdy = max(rdy, r)
+        if acc >= bucket_elems:
+            out.append((start, off, rdy))
+            start, acc, rdy = off, 0, -1
+    if acc:
+        out.append((start, off, rdy))
+    return sorted(out, key=lambda b: b[2])
 
 
 class _Repacker:
@@ -516,12 +553,66 @@ class UNetTrainer:
         plan.backward(dout, st)
         return loss, out
 
-    def step(self, noisy, timesteps, clean, noise, class_labels=None, class_emb=None, lr: Optional[float] = None, group=None):
-        from .training import allreduce_mean_
-        loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb)
-        allreduce_mean_(self.opt.grad, group)
+    def step(self, noisy, timesteps, clean, noise, class_labels=None, class_emb=None, lr: Optional[float] = None, group=None,
+             overlap: bool = True, bucket_bytes: int = 16 << 20):
+        """forward -> loss -> backward, with the data-parallel gradient all-reduce (RCCL; what DDP does under
+        ``accelerator.backward``, train.py:311-326) running bucket by bucket on a second stream WHILE the backward still
+        computes the earlier layers' gradients -> clip + AdamW + EMA -> re-pack."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world == 1 and not getattr(self, "force_collectives", False):
+            loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb)
+        elif not overlap:
+            from .training import allreduce_mean_
+            loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb)
+            allreduce_mean_(self.opt.grad, group)
+        else:
+            loss = self._forward_backward_overlapped(noisy, timesteps, clean, noise, class_labels, class_emb, group, world,
+                                                     bucket_bytes)
         self.opt.step(lr)
         self.refresh_weights()
+        return loss
+
+    def _forward_backward_overlapped(self, noisy, timesteps, clean, noise, class_labels, class_emb, group, world, bucket_bytes):
+        import torch.distributed as dist
+        B, _, H, W = noisy.shape
+        plan = self.plan_for(B, H, W)
+        key = (id(plan), bucket_bytes)
+        if getattr(self, "_bucket_key", None) != key:
+            names = list(self.grads)
+            last = len(plan.bwd_ops) - 1
+            self._buckets = plan_grad_buckets([self.grads[n].numel() for n in names],
+                                              [plan.grad_ready.get(n, last) for n in names], max(1, bucket_bytes // 4))
+            self._bucket_key = key
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        comm = self._comm_stream
+        flat = self.opt.grad
+        works, hooks = [], {}
+
+        def launch(start, end):
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                works.append(dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=group, async_op=True))
+
+        for start, end, rdy in self._buckets:
+            prev = hooks.get(rdy)
+            hooks[rdy] = (lambda s=start, e=end, p=prev: ((p() if p else None), launch(s, e)))
+        st = cur.cuda_stream
+        x = noisy.contiguous().float()
+        ts = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
+        labels = class_labels.to(device=self.device, dtype=torch.int64).contiguous() if class_labels is not None else None
+        cemb = class_emb.to(device=self.device, dtype=torch.float32).contiguous() if class_emb is not None else None
+        out = torch.empty_like(x)
+        plan.forward(x, ts, labels, cemb, out, st)
+        loss, dout = self.loss_fn(out, clean, noise, timesteps)
+        plan.backward(dout, st, after_op=hooks)
+        for wk in works:
+            wk.wait()                      # the compute stream waits for the collectives, the host does not
+        cur.wait_stream(comm)
+        flat.div_(world)
         return loss
 
     def refresh_weights(self):

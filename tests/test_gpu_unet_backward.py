@@ -147,3 +147,34 @@ def test_device_repack_equals_host_packing(mode):
                         assert torch.equal(dd, vv), f"{path}.{k}[{i}]"
     same(m._weights, fresh_w, "w")
     same(tr._tw, fresh_t, "tw")
+
+
+def test_overlapped_gradient_allreduce_path_single_rank():
+    """The bucketed all-reduce issued from inside the backward (second stream, event-ordered) must leave the same gradients
+    as the plain path.  One rank is all a 1-GPU box offers: the collective is an identity, the stream/event/bucket logic is
+    what runs (multi-rank averaging itself: tests/test_training_blocks.py, 2-rank gloo)."""
+    import os
+    import torch.distributed as dist
+    from phendiff_amd.unet_train import UNetTrainer
+    _, m = make_pair("super_small", 32, "f32")
+    sched, clean, noise, ts, labels, noisy, _ = batch(2, 32)
+    args = [t.cuda() for t in (noisy, ts, clean, noise)]
+    tr = UNetTrainer(m, sched, lr=1e-4, use_ema=False)
+    tr.forward_backward(*args, class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    want = tr.opt.grad.clone()
+    tr.opt.grad.zero_()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        plan = tr.plan_for(2, 32, 32)
+        assert set(plan.grad_ready) == set(tr.grads)                      # every parameter has a completion point
+        assert plan.grad_ready["conv_out.weight"] < plan.grad_ready["mid_block.resnets.0.conv1.weight"] \
+            < plan.grad_ready["conv_in.weight"] <= plan.grad_ready["time_embedding.linear_1.weight"]
+        loss = tr._forward_backward_overlapped(*args, labels.cuda(), None, None, 1, 4 << 20)
+        torch.cuda.synchronize()
+        assert len(tr._buckets) >= 4 and float(loss) > 0
+        assert torch.equal(tr.opt.grad, want)
+    finally:
+        dist.destroy_process_group()

@@ -190,3 +190,41 @@ def test_pretrained_folder_roundtrip_and_deprecated_attention_keys(tmp_path):
     torch.save(old, folder / "diffusion_pytorch_model.bin")
     legacy = P.CustomCondUNet2DModel.from_pretrained(str(folder))
     assert all(torch.equal(a, b) for a, b in zip(sd.values(), legacy.state_dict().values()))
+
+
+def test_training_param_order_makes_fused_gradients_contiguous():
+    """Flat-buffer order for training: every parameter exactly once; stacked time_emb_proj and adjacent q/k/v so that the
+    fused [proj_dim][tdim] / [3C][C] gradients pd_linear_wgrad / pd_conv_wgrad write are single contiguous blocks."""
+    import phendiff_amd as P
+    m = P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], sample_size=32))
+    order = P.training_param_order(m)
+    names = [n for n, _ in order]
+    assert sorted(names) == sorted(n for n, _ in m.named_parameters()) and len(set(names)) == len(names)
+    assert sum(p.numel() for _, p in order) == 15_725_443
+    n_res = sum(1 for n in names if n.endswith("time_emb_proj.weight"))
+    assert all(n.endswith("time_emb_proj.weight") for n in names[:n_res])
+    assert all(n.endswith("time_emb_proj.bias") for n in names[n_res:2 * n_res])
+    # module order == the order pd_temb's stacked projection uses (temb_off of each resnet)
+    from phendiff_amd.unet import _Resnet
+    assert [n[:-len(".time_emb_proj.weight")] for n in names[:n_res]] == [n for n, mod in m.named_modules() if isinstance(mod, _Resnet)]
+    i = names.index("down_blocks.2.attentions.0.to_q.weight")
+    assert names[i:i + 6] == [f"down_blocks.2.attentions.0.{w}.{s}" for s in ("weight", "bias") for w in ("to_q", "to_k", "to_v")]
+
+
+def test_trainer_fails_loudly_without_gpu():
+    import phendiff_amd as P
+    m = P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], sample_size=32))
+    sched = P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+    with pytest.raises(P.PhenDiffHipError):
+        P.UNetTrainer(m, sched, lr=1e-4)
+
+
+def test_plan_grad_buckets_cover_buffer_in_ready_order():
+    from phendiff_amd.unet_train import plan_grad_buckets
+    sizes = [10, 30, 5, 5, 50, 20, 40]
+    ready = [99, 90, 80, 70, 40, 20, 5]        # backward finishes the END of the buffer first
+    b = plan_grad_buckets(sizes, ready, 40)
+    assert sorted((s, e) for s, e, _ in b) == [(0, 40), (40, 100), (100, 160)]       # contiguous, complete, no overlap
+    assert [r for _, _, r in b] == sorted(r for _, _, r in b) and b[0] == (100, 160, 20)
+    assert dict(((s, e), r) for s, e, r in b)[(0, 40)] == 99                        # a bucket is ready when its LAST gradient is
+    assert plan_grad_buckets([7], [3], 1 << 20) == [(0, 7, 3)]
