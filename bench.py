@@ -111,13 +111,130 @@ def cpu_baseline(model_name, size, S, state_dict, seconds_budget=30.0):
                       f"t_step={t_step:.3f}s"}
 
 
+def cpu_baseline_train(model_name, size, state_dict, seconds_budget=30.0):
+    """One optimisation step of the CPU oracle under torch.autograd + torch AdamW (what the reference's training loop runs)
+    on a bounded batch."""
+    from oracle import CondUNet2DRef
+    import phendiff_amd as P
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    r = CondUNet2DRef(**{k: v for k, v in dict(P.UNET_CONFIGS[model_name], sample_size=size).items() if k in keys})
+    r.load_state_dict(state_dict)
+    opt = torch.optim.AdamW(r.parameters(), lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    B = 2
+    x, labels = synth_batch(B, size, 99)
+    ts = torch.tensor([1500, 300])
+
+    def step():
+        out = r(x, ts, class_labels=labels).sample
+        loss = torch.nn.functional.mse_loss(out, torch.zeros_like(out))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(r.parameters(), 1.0)
+        opt.step()
+    step()
+    t0, n = time.perf_counter(), 0
+    while n < 1 or (time.perf_counter() - t0 < seconds_budget and n < 20):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} optimisation step(s) of the CPU oracle (torch.autograd + clip_grad_norm_ + AdamW) at batch {B}, "
+                      f"{size}x{size}, fp32, {threads} threads"}
+
+
+def main_train(args, P, world, rank, dev, dist):
+    """configs[1]: DDIM training of cond_unet_2d at 128x128, bf16, data-parallel.  One step = sampling (noise, timesteps,
+    add_noise) + forward + loss + backward + bucketed gradient all-reduce (N > 1) + clip/AdamW/EMA + weight re-pack."""
+    from phendiff_amd.training import scaled_lr
+    B, size = args.batch or 112, args.size or 128
+    torch.manual_seed(0)
+    unet = P.CustomCondUNet2DModel(compute_dtype=args.dtype, **dict(P.UNET_CONFIGS[args.model], sample_size=size))
+    state_dict = {k: v.clone() for k, v in unet.state_dict().items()}
+    sched = P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+    tr = P.UNetTrainer(unet.to(dev), sched, lr=scaled_lr(1e-4, world))
+    clean, labels = synth_batch(B, size, 1234 + rank)
+    clean, labels = clean.to(dev), labels.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+
+    def step():
+        noise = torch.randn(clean.shape, device=dev, generator=gen)
+        ts = torch.randint(0, sched.config.num_train_timesteps, (B,), device=dev, generator=gen)
+        noisy = sched.add_noise(clean, noise, ts)
+        return tr.step(noisy, ts, clean, noise, class_labels=labels)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss).all()
+    value = world * B * args.steps / elapsed
+    res = {
+        "metric": "DDIM training images/sec (128x128 cond_unet_2d, bf16)", "value": round(value, 3), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"configs[1]: {size}x{size} cond_unet_2d DDIM training, {args.model} UNet (random init, seed 0), "
+                               f"3k_steps_clipping_rescaling / v_prediction, batch {B}/GPU (launch_script_DDIM.sh:52) on {world} GPU(s), "
+                               "AdamW(.95,.999) + clip 1.0 + EMA, data-parallel gradient all-reduce overlapped with the backward",
+                   "batch_per_gpu": B, "global_batch": B * world, "image_size": size, "final_loss": round(float(loss), 5)},
+    }
+    if rank == 0 and not args.no_roofline:
+        plan = tr.plan_for(B, size, size)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        prof = {}
+        for title, ops in (("fwd", plan.ops), ("bwd", plan.bwd_ops)):
+            for k, d in plan._profile_ops(ops, st, reps=2).items():
+                prof[f"{title}.{k}"] = d
+        torch.cuda.synchronize(dev)
+        total_ms = sum(d["ms"] for d in prof.values())
+        kind, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        mfma = any(t in kind for t in ("conv", "wgrad", "dgrad", "attn"))
+        if mfma:
+            ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS[args.dtype], "TFLOP/s"
+        else:
+            ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        res["roofline"] = {"kernel": kind, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                           "frac": round(ach / peak, 4), "traffic": None,
+                           "launches_per_step": round(d["launches"]), "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                           "share_of_fwd_bwd": round(d["ms"] / total_ms, 3),
+                           "method": "HIP events between consecutive launches of one forward + backward (same plan and buffers)",
+                           "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                           "per_kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items()
+                                                 if v["ms"] > 0 and v["flops"] > 0}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_train(args.model, size, state_dict)
+        res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workload", default="img2img", choices=["img2img", "train"],
+                    help="img2img = BASELINE.json's metric (default); train = configs[1], one optimisation step per 'step'")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; train: 112 = launch_script_DDIM.sh:52)")
+    ap.add_argument("--size", type=int, default=None, help="image size (default 256; train: 128)")
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--model", default="super_small")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -144,6 +261,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "train":
+        return main_train(args, P, world, rank, dev, dist)
+    args.batch, args.size = args.batch or 32, args.size or 256
 
     B, S, size = args.batch, args.inference_steps, args.size
     torch.manual_seed(0)  # identical random-init weights on every rank (no checkpoint: no network)
