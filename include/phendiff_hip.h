@@ -269,6 +269,9 @@ typedef struct {
   float* dgamma; float* dbeta;           /* [C0+C1], accumulated (+=), or NULL */
   int dz_combined;                       /* 1: dz0 holds all C0+C1 channels (stride C0+C1), dz1 must be NULL */
   const void* res;                       /* optional [B][HW][C0+C1]: added to dx (gradient of the skip / shortcut around the block) */
+  float* sum0; float* sum1;              /* optional out [B][splits][C0] / [B][splits][C1]: per-channel sums of the dx0 / dx1 values
+                                            this call stores (feeds pd_channel_sum with x = NULL: the producer's bias /
+                                            time-embedding gradients without another pass over dx) */
 } pd_gn_bwd_args;
 int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream);
 
@@ -280,7 +283,8 @@ int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream);
 typedef struct {
   int dtype; int B, HW, C; const void* x; float* out; int out_stride; int accumulate;
   float* total; int total_valid;   /* optional [total_valid <= C]: total[c] += sum over samples of this call's per-sample sums */
-  float* workspace; int splits;    /* optional [B][splits][C] scratch: the pixels of a sample are split over `splits` workgroups */
+  float* workspace; int splits;    /* optional [B][splits][C] scratch: the pixels of a sample are split over `splits` workgroups;
+                                      with x = NULL it already holds the per-split sums (pd_gn_silu_bwd sum0 / sum1) */
 } pd_channel_sum_args;
 int pd_channel_sum(const pd_channel_sum_args* a, void* stream);
 

@@ -58,7 +58,7 @@ class GnBwdArgs(C.Structure):
                 ("silu", C.c_int), ("x0", vp), ("x1", vp), ("dz0", vp), ("dz1", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
                 ("beta", vp), ("partial", vp), ("splits", C.c_int), ("coef", vp), ("dx0", vp), ("dx1", vp),
                 ("accumulate0", C.c_int), ("accumulate1", C.c_int), ("dgamma", vp), ("dbeta", vp),
-                ("dz_combined", C.c_int), ("res", vp)]
+                ("dz_combined", C.c_int), ("res", vp), ("sum0", vp), ("sum1", vp)]
 
 
 class Pool2x2Args(C.Structure):

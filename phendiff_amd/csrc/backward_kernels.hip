@@ -67,14 +67,23 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   if (g.active) {
-    for (int p = p0 + prow; p < p1; p += ppi) {
-      float xv[8], dv[8];
-      E::unpack(E::load(g.xs + ((size_t)n * a.HW + p) * g.cs + g.coff), xv);
-      E::unpack(E::load(g.ds + ((size_t)n * a.HW + p) * g.dcs + g.dcoff), dv);
+    // two pixels per iteration: four 16-byte loads in flight per lane
+    for (int p = p0 + prow; p < p1; p += 2 * ppi) {
+      const bool two = p + ppi < p1;
+      const int pb = two ? p + ppi : p;
+      typename E::Frag fx0 = E::load(g.xs + ((size_t)n * a.HW + p) * g.cs + g.coff);
+      typename E::Frag fd0 = E::load(g.ds + ((size_t)n * a.HW + p) * g.dcs + g.dcoff);
+      typename E::Frag fx1 = E::load(g.xs + ((size_t)n * a.HW + pb) * g.cs + g.coff);
+      typename E::Frag fd1 = E::load(g.ds + ((size_t)n * a.HW + pb) * g.dcs + g.dcoff);
+      float xv[8], dv[8], xw[8], dw[8];
+      E::unpack(fx0, xv); E::unpack(fd0, dv); E::unpack(fx1, xw); E::unpack(fd1, dw);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float dy = a.silu ? dv[j] * dsilu_t<T>(g.sc[j] * xv[j] + g.sh[j]) : dv[j];
         s1[j] += dy; s2[j] += dy * ((xv[j] - g.mu[j]) * g.rs[j]);
+        float dy2 = a.silu ? dw[j] * dsilu_t<T>(g.sc[j] * xw[j] + g.sh[j]) : dw[j];
+        dy2 = two ? dy2 : 0.f;
+        s1[j] += dy2; s2[j] += dy2 * ((xw[j] - g.mu[j]) * g.rs[j]);
       }
     }
   }
@@ -139,12 +148,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args 
   const int n = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
   const int per = (a.HW + a.splits - 1) / a.splits;
   const int p0 = split * per, p1 = min(a.HW, p0 + per);
+  __shared__ float red[256 * 8];
   GnPiece<T> g;
   int prow, ppi;
   g.init(a, n, threadIdx.x, prow, ppi);
-  if (!g.active) return;
   T* dxp = (T*)(g.first ? a.dx0 : a.dx1);
-  if (!dxp) return;
+  float* sump = g.first ? a.sum0 : a.sum1;         // optional per-(sample, split, channel) sums of the dx written here
+  float cs_[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs_[j] = 0.f;
+  if (g.active && dxp) {
   float ka[8], kb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -153,21 +166,56 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args 
   }
   const bool accum = g.first ? a.accumulate0 : a.accumulate1;
   const bool has_res = a.res != nullptr;
-  for (int p = p0 + prow; p < p1; p += ppi) {
-    const size_t pixl = (size_t)n * a.HW + p;
-    const size_t off = pixl * g.cs + g.coff;
-    float xv[8], dv[8], acc[8], rv[8];
-    E::unpack(E::load(g.xs + off), xv);
-    E::unpack(E::load(g.ds + pixl * g.dcs + g.dcoff), dv);
-    if (accum) E::unpack(E::load(dxp + off), acc);
-    if (has_res) E::unpack(E::load((const T*)a.res + pixl * C + g.c8), rv);
+  typedef typename E::Frag Frag;
+  for (int p = p0 + prow; p < p1; p += 2 * ppi) {      // two pixels per iteration: up to eight 16-byte loads in flight
+    const bool two = p + ppi < p1;
+    size_t pixl[2] = {(size_t)n * a.HW + p, (size_t)n * a.HW + (two ? p + ppi : p)};
+    Frag fx[2], fd[2], fa[2], fr[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float dy = a.silu ? dv[j] * dsilu_t<T>(g.sc[j] * xv[j] + g.sh[j]) : dv[j];
-      const float dx = g.sc[j] * dy - ka[j] - ((xv[j] - g.mu[j]) * g.rs[j]) * kb[j];
-      acc[j] = (accum ? acc[j] + dx : dx) + (has_res ? rv[j] : 0.f);
+    for (int u = 0; u < 2; ++u) {
+      const size_t off = pixl[u] * g.cs + g.coff;
+      fx[u] = E::load(g.xs + off);
+      fd[u] = E::load(g.ds + pixl[u] * g.dcs + g.dcoff);
+      if (accum) fa[u] = E::load(dxp + off);
+      if (has_res) fr[u] = E::load((const T*)a.res + pixl[u] * C + g.c8);
     }
-    E::store(dxp + off, E::pack(acc));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      float xv[8], dv[8], acc[8], rv[8];
+      E::unpack(fx[u], xv); E::unpack(fd[u], dv);
+      if (accum) E::unpack(fa[u], acc);
+      if (has_res) E::unpack(fr[u], rv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dy = a.silu ? dv[j] * dsilu_t<T>(g.sc[j] * xv[j] + g.sh[j]) : dv[j];
+        const float dx = g.sc[j] * dy - ka[j] - ((xv[j] - g.mu[j]) * g.rs[j]) * kb[j];
+        acc[j] = (accum ? acc[j] + dx : dx) + (has_res ? rv[j] : 0.f);
+      }
+      const Frag packed = E::pack(acc);
+      E::store(dxp + pixl[u] * g.cs + g.coff, packed);
+      if (sump) {                      // sums of the values as stored (rounded), what a later pass over dx would read
+        E::unpack(packed, acc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs_[j] += acc[j];
+      }
+    }
+  }
+  }
+  if (a.sum0 || a.sum1) {              // workgroup-uniform
+    const int PP = C / 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = cs_[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const bool first = c < a.C0;
+      float* sp = first ? a.sum0 : a.sum1;
+      if (!sp) continue;
+      float t = 0.f;
+      for (int k = 0; k < ppi; ++k) t += red[(k * PP + (c >> 3)) * 8 + (c & 7)];
+      const int cs = first ? a.C0 : a.C1, cc = first ? c : c - a.C0;
+      sp[((size_t)n * a.splits + split) * cs + cc] = t;
+    }
   }
 }
 
@@ -216,11 +264,20 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_a
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
   if (tid < nthr) {
     const int piece = tid % PP, prow = tid / PP;
-    for (int p = p_lo + prow; p < p_hi; p += ppi) {
-      float v[8];
-      E::unpack(E::load((const T*)a.x + ((size_t)n * a.HW + p) * a.C + piece * 8), v);
+    for (int p = p_lo + prow; p < p_hi; p += 4 * ppi) {          // four 16-byte loads in flight per lane
+      typename E::Frag f[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += v[j];
+      for (int u = 0; u < 4; ++u) {
+        const int pu = p + u * ppi;
+        f[u] = pu < p_hi ? E::load((const T*)a.x + ((size_t)n * a.HW + pu) * a.C + piece * 8) : E::zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        E::unpack(f[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+      }
     }
   }
 #pragma unroll
@@ -235,15 +292,36 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_a
   }
 }
 
-// out[n][c] (+)= sum over splits of workspace[n][split][c]
+// out[n][c] (+)= sum over splits of workspace[n][split][c];  total[c] += sum over n of those (when total != NULL).
+// block = 16 channels x 16 sample groups, combined in a fixed order
 __global__ __launch_bounds__(256) void channel_sum_combine_kernel(const pd_channel_sum_args a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.B * a.C) return;
-  const int n = idx / a.C, c = idx - n * a.C;
-  float s = 0.f;
-  for (int sp = 0; sp < a.splits; ++sp) s += a.workspace[((size_t)n * a.splits + sp) * a.C + c];
-  float* o = a.out + (size_t)n * a.out_stride + c;
-  *o = a.accumulate ? *o + s : s;
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 15, ng = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float tot = 0.f;
+  if (c < a.C) {
+    for (int n = ng; n < a.B; n += 16) {
+      const float* w = a.workspace + (size_t)n * a.splits * a.C + c;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // independent chains: the loads overlap
+      int sp = 0;
+      for (; sp + 4 <= a.splits; sp += 4) {
+        s0 += w[(size_t)sp * a.C]; s1 += w[(size_t)(sp + 1) * a.C]; s2 += w[(size_t)(sp + 2) * a.C]; s3 += w[(size_t)(sp + 3) * a.C];
+      }
+      for (; sp < a.splits; ++sp) s0 += w[(size_t)sp * a.C];
+      const float s = (s0 + s1) + (s2 + s3);
+      float* o = a.out + (size_t)n * a.out_stride + c;
+      *o = a.accumulate ? *o + s : s;
+      tot += s;
+    }
+  }
+  red[threadIdx.x] = tot;
+  __syncthreads();
+  if (ng == 0 && c < a.total_valid && a.total) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
+    a.total[c] += t;
+  }
 }
 
 // total[c] += sum_n per[n*stride + c]
@@ -356,19 +434,20 @@ extern "C" int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream) {
 }
 
 extern "C" int pd_channel_sum(const pd_channel_sum_args* a, void* stream) {
-  PD_CHECK(a != nullptr && a->B > 0 && a->HW > 0 && a->C > 0 && a->C % 8 == 0 && a->C / 8 <= 256 && a->x && a->out, PD_ERR_ARG, "pd_channel_sum: bad args");
+  PD_CHECK(a != nullptr && a->B > 0 && a->HW > 0 && a->C > 0 && a->C % 8 == 0 && a->C / 8 <= 256 && a->out, PD_ERR_ARG, "pd_channel_sum: bad args");
+  PD_CHECK(a->x || a->workspace, PD_ERR_ARG, "pd_channel_sum: x = NULL needs a pre-filled workspace (pd_gn_silu_bwd sum0/sum1)");
   PD_CHECK(!a->workspace || a->splits >= 1, PD_ERR_ARG, "pd_channel_sum: workspace without splits");
   const int nblk = a->B * (a->workspace ? a->splits : 1);
-  if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a);
+  if (!a->x) { /* per-split sums already in the workspace */ }
+  else if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_channel_sum: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
+  if (a->total) PD_CHECK(a->total_valid > 0 && a->total_valid <= a->C, PD_ERR_ARG, "pd_channel_sum: total_valid=%d", a->total_valid);
   if (a->workspace) {
-    hipLaunchKernelGGL(channel_sum_combine_kernel, dim3((a->B * a->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(channel_sum_combine_kernel, dim3((a->C + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a);
     PD_LAUNCH_CHECK();
-  }
-  if (a->total) {
-    PD_CHECK(a->total_valid > 0 && a->total_valid <= a->C, PD_ERR_ARG, "pd_channel_sum: total_valid=%d", a->total_valid);
+  } else if (a->total) {
     PD_CHECK(!a->accumulate, PD_ERR_ARG, "pd_channel_sum: total needs this call's own per-sample sums (accumulate = 0)");
     hipLaunchKernelGGL(colsum_kernel, dim3((a->total_valid + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)a->out, a->B,
                        a->out_stride, a->total_valid, a->total);

@@ -106,6 +106,8 @@ class UNetTrainPlan(UNetPlan):
         self.grad_ready: Dict[str, int] = {}   # parameter name -> index of the last backward op that writes its gradient
         self._emb_grad_op = None
         self._gact = {}
+        self._fused_sums = {}      # id(gradient buffer) -> (per-split channel sums [B][splits][C], splits) left by its last writer
+        self._sum_owner = {}       # id(activation) -> (GnBwdArgs, field) currently emitting those sums
         self._tmp_cache = {}
         self._wgrad_args = []
         self._sample_ptr_args = []
@@ -166,6 +168,14 @@ class UNetTrainPlan(UNetPlan):
             self._tmp_cache[key] = t
         return t
 
+    def _drop_fused_sums(self, gbuf):
+        """Another kind of launch writes this gradient buffer after a GroupNorm backward did: its channel sums are stale."""
+        if self._fused_sums.pop(id(gbuf), None) is not None:
+            for key, (args, fld) in list(self._sum_owner.items()):
+                if self._gact.get(key, (None,))[0] is gbuf:
+                    setattr(args, fld, None)
+                    del self._sum_owner[key]
+
     def _b(self, fn, args, what, flops=0.0, nbytes=0.0):
         self.bwd_ops.append(_Op(fn, args, what, flops, nbytes))
 
@@ -182,6 +192,15 @@ class UNetTrainPlan(UNetPlan):
     def _bias_grad(self, dy, total, valid=None, per_sample=None, per_stride=None):
         B, h, w, ch = dy.shape
         out = per_sample if per_sample is not None else self._tmp((B, ch), "chsum", torch.float32)
+        fused = self._fused_sums.get(id(dy))
+        if fused is not None:
+            # the GroupNorm backward that stored the final value of this gradient also left its per-split channel sums
+            ws, splits = fused
+            a = L.ChannelSumArgs(dtype=self.code, B=B, HW=h * w, C=ch, x=None, out=out.data_ptr(), out_stride=per_stride or ch,
+                                 accumulate=0, total=total.data_ptr(), total_valid=valid or ch, workspace=ws.data_ptr(),
+                                 splits=splits)
+            self._b(self.lib.pd_channel_sum, a, "channel_sum_fused", 0.0, B * splits * ch * 4.0)
+            return
         splits = max(1, min(64, (h * w) // 64))
         ws = self._tmp((B * splits * ch,), "chsum_ws", torch.float32)
         a = L.ChannelSumArgs(dtype=self.code, B=B, HW=h * w, C=ch, x=dy.data_ptr(), out=out.data_ptr(),
@@ -210,6 +229,7 @@ class UNetTrainPlan(UNetPlan):
         if into is not None:
             y, res = into[0], (into[0] if into[1] else None)
             into[1] = True
+            self._drop_fused_sums(into[0])
         else:
             y, res = self._tmp((B, ho, wo, cout), tag), None
         ops, self.ops = self.ops, self.bwd_ops
@@ -241,6 +261,20 @@ class UNetTrainPlan(UNetPlan):
         g0[1] = True
         if g1:
             g1[1] = True
+        # this launch is (so far) the last writer of the gradients of x0 / x1: it also emits their per-split channel sums,
+        # which the producer block's bias / time-embedding gradients read instead of another pass (a later writer of the
+        # same buffer re-registers and supersedes these)
+        for src, fld, gb in ((x0, "sum0", g0), (x1, "sum1", g1)):
+            if src is None:
+                continue
+            prev = self._sum_owner.pop(id(src), None)
+            if prev is not None:
+                setattr(prev[0], prev[1], None)            # superseded: that launch no longer needs to emit sums
+            st = torch.empty((B, splits, src.shape[3]), dtype=torch.float32, device=self.device)
+            self.bufs.append(st)
+            setattr(a, fld, st.data_ptr())
+            self._sum_owner[id(src)] = (a, fld)
+            self._fused_sums[id(gb[0])] = (st, splits)
         n = B * h * w * (c0 + c1)
         self._b(self.lib.pd_gn_silu_bwd, a, "gn_silu_bwd", 0.0, n * self._esz() * (5 + (1 if res is not None else 0)))
 
@@ -286,6 +320,7 @@ class UNetTrainPlan(UNetPlan):
                 a = L.Pool2x2Args(dtype=self.code, B=B, H=h, W=ww, C=ch, du=du.data_ptr(), dx=gx[0].data_ptr(),
                                   accumulate=int(gx[1]))
                 gx[1] = True
+                self._drop_fused_sums(gx[0])
                 self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
             elif k == "conv_in":
                 dout = self._g(rec.out)[0]
