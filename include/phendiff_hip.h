@@ -344,8 +344,8 @@ typedef struct { int dtype; int B, H, W, C; const float* x; void* out; } pd_im2c
 int pd_im2col3(const pd_im2col3_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Training-step building blocks.  The UNet backward is not built yet; these are the fused
- * bandwidth-bound passes around it, on flat fp32 buffers.
+ * Training-step building blocks: the fused bandwidth-bound passes around the UNet
+ * forward/backward, on flat fp32 buffers.
  *
  * pd_diffusion_loss (utils_training.py:415-433): loss = mean(w_n (out - target)^2) and d loss / d out, with
  *   epsilon: target = noise, w = 1      sample: target = clean, w_n = alpha_t/(1-alpha_t) (SNR weights, `weight`)

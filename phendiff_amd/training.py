@@ -1,4 +1,4 @@
-"""Training-step building blocks around the (not yet built) UNet backward -- SURVEY.md 8a rows A13-A16.
+"""Training-step building blocks around the UNet forward/backward (``unet_train.py``) -- SURVEY.md 8a rows A13-A16.
 
 Device side (``csrc/train_kernels.hip``): ``pd_diffusion_loss`` (loss + d loss/d out, ``utils_training.py:415-433``),
 ``pd_grad_norm`` (``clip_grad_norm_(params, 1.0)``, ``:438-440``) and ``pd_adamw_ema`` (clip scaling + AdamW +
