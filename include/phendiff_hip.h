@@ -383,6 +383,26 @@ typedef struct {
 int pd_adamw_ema(const pd_adamw_ema_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Gradient-guided transfer (_custom_guided_generation, utils_Img2Img.py:699-760).
+ * pd_lp_guidance: losses[n] = || x0_n - target_n ||_p (Lp_loss, :245-270) with x0 = DDIMScheduler.step(...).pred_original_sample
+ * (prediction type, clipping as pd_ddim_step), and its gradient split the way the chain rule needs it:
+ *   d_model_out = dL/dx0 * dx0/d(model_out)   (fed to the UNet backward)      d_sample_direct = dL/dx0 * dx0/d(sample)
+ * pd_guidance_apply: out = x - scale * (g_direct + g_unet)   (:747-751)
+ */
+typedef struct {
+  int64_t numel, per_sample;
+  int pred_type, clip; float clip_range, sqrt_a, sqrt_b;
+  float p;                                  /* finite, >= 1 */
+  const float* sample; const float* model_out; const float* target;
+  double* partial; int splits;              /* workspace [B][splits] */
+  float* d_model_out; float* d_sample_direct;
+  float* losses;                            /* out [B] or NULL */
+} pd_lp_guidance_args;
+int pd_lp_guidance(const pd_lp_guidance_args* a, void* stream);
+typedef struct { int64_t numel; float scale; const float* x; const float* g_direct; const float* g_unet; float* out; } pd_guidance_apply_args;
+int pd_guidance_apply(const pd_guidance_apply_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stream capture helpers (hipGraph): the S-step sampling loop is captured once and replayed.
  */
 int pd_graph_begin(void* stream);

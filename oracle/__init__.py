@@ -26,4 +26,7 @@ from .pipeline_ref import (  # noqa: F401
     inversion_ref,
     ddib_ref,
     numpy_to_uint8,
+    lp_loss_ref,
+    custom_guided_generation_ref,
+    linear_interp_custom_guidance_inverted_start_ref,
 )

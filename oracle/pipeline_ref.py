@@ -89,6 +89,38 @@ def ddib_ref(pipe, clean_images, orig_class_labels, target_class_labels, num_inf
     return images, inverted
 
 
+def lp_loss_ref(x, y, p=2):
+    """``Lp_loss`` (utils_Img2Img.py:245-270)."""
+    return torch.linalg.vector_norm(x - y, dim=(1, 2, 3), ord=p)
+
+
+def custom_guided_generation_ref(pipe, input_images, target_class_labels, p, guidance_loss_scale, num_inference_steps):
+    """``_custom_guided_generation`` (utils_Img2Img.py:699-760), ConditionalDDIMPipeline branch: every step the image is
+    pushed down the gradient -- taken THROUGH the UNet -- of ``Lp(x0_pred, input_images)``, then the scheduler steps with the
+    model output computed before the push.  (``input_images`` is what the caller passes: the inverted Gaussian.)"""
+    images = input_images.clone().detach()
+    pipe.scheduler.set_timesteps(num_inference_steps)
+    for t in pipe.scheduler.timesteps:
+        images = images.detach().requires_grad_()
+        with torch.enable_grad():
+            model_output = pipe.unet(images, t, target_class_labels).sample
+            x0 = pipe.scheduler.step(model_output, t, images).pred_original_sample
+            losses = lp_loss_ref(x0, input_images, p)
+            guidance_grad = torch.autograd.grad([losses[i] for i in range(len(input_images))], images)[0]
+        images = images.detach() - guidance_loss_scale * guidance_grad
+        images = pipe.scheduler.step(model_output.detach(), t, images).prev_sample
+    return images.detach()
+
+
+def linear_interp_custom_guidance_inverted_start_ref(pipe, clean_images, orig_class_labels, target_class_labels, p,
+                                                     guidance_loss_scale, num_inference_steps, variant="0.18.2"):
+    """``_linear_interp_custom_guidance_inverted_start`` (utils_Img2Img.py:651-696): inversion under the original class, then
+    guided generation under the target class.  Returns the [-1, 1] image tensor (before ``tensor_to_PIL``)."""
+    with torch.no_grad():
+        inverted = inversion_ref(pipe, clean_images, orig_class_labels, num_inference_steps, variant)
+    return custom_guided_generation_ref(pipe, inverted, target_class_labels, p, guidance_loss_scale, num_inference_steps)
+
+
 def numpy_to_uint8(images: np.ndarray) -> np.ndarray:
     """``DiffusionPipeline.numpy_to_pil`` quantisation: ``(images * 255).round().astype("uint8")``."""
     return (images * 255).round().astype("uint8")

@@ -112,6 +112,17 @@ class AttnArgs(C.Structure):
                 ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp)]
 
 
+class LpGuidanceArgs(C.Structure):
+    _fields_ = [("numel", C.c_int64), ("per_sample", C.c_int64), ("pred_type", C.c_int), ("clip", C.c_int),
+                ("clip_range", C.c_float), ("sqrt_a", C.c_float), ("sqrt_b", C.c_float), ("p", C.c_float), ("sample", vp),
+                ("model_out", vp), ("target", vp), ("partial", vp), ("splits", C.c_int), ("d_model_out", vp),
+                ("d_sample_direct", vp), ("losses", vp)]
+
+
+class GuidanceApplyArgs(C.Structure):
+    _fields_ = [("numel", C.c_int64), ("scale", C.c_float), ("x", vp), ("g_direct", vp), ("g_unet", vp), ("out", vp)]
+
+
 class AttnBwdArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("N", C.c_int), ("q", vp), ("k", vp), ("v", vp),
                 ("o", vp), ("dout", vp), ("lse", vp), ("delta", vp), ("dqkv", vp)]
@@ -173,6 +184,8 @@ SYMBOLS = {
     "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
+    "pd_lp_guidance": (C.c_int, [C.POINTER(LpGuidanceArgs), vp]),
+    "pd_guidance_apply": (C.c_int, [C.POINTER(GuidanceApplyArgs), vp]),
     "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),
     "pd_grad_norm": (C.c_int, [vp, C.c_int64, vp, C.c_float, vp, vp, vp]),
     "pd_adamw_ema": (C.c_int, [C.POINTER(AdamWEmaArgs), vp]),

@@ -85,6 +85,62 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(const pd_adamw_ema_args 
   }
 }
 
+
+// ---- gradient-guided transfer (utils_Img2Img.py:699-751): per-sample Lp loss between the predicted x0 and a target, and its
+// gradient w.r.t. the UNet output and (directly) the sample
+__device__ __forceinline__ float lp_x0(const pd_lp_guidance_args& a, float x, float o, bool& inside) {
+  float x0 = a.pred_type == PD_PRED_EPSILON ? (x - a.sqrt_b * o) / a.sqrt_a : (a.pred_type == PD_PRED_SAMPLE ? o : a.sqrt_a * x - a.sqrt_b * o);
+  inside = true;
+  if (a.clip) { inside = x0 >= -a.clip_range && x0 <= a.clip_range; x0 = fminf(fmaxf(x0, -a.clip_range), a.clip_range); }
+  return x0;
+}
+
+__global__ __launch_bounds__(256) void lp_reduce_kernel(const pd_lp_guidance_args a) {
+  __shared__ double red[256];
+  const int n = blockIdx.x / a.splits, sp = blockIdx.x % a.splits;
+  const int64_t per = (a.per_sample + a.splits - 1) / a.splits;
+  const int64_t lo = sp * per, hi = lo + per < a.per_sample ? lo + per : a.per_sample;
+  double s = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const int64_t k = (int64_t)n * a.per_sample + i;
+    bool in;
+    const float d = lp_x0(a, a.sample[k], a.model_out[k], in) - a.target[k];
+    s += (double)(a.p == 2.0f ? d * d : powf(fabsf(d), a.p));
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void lp_grad_kernel(const pd_lp_guidance_args a) {
+  const int n = blockIdx.x / a.splits, sp = blockIdx.x % a.splits;
+  double tot = 0.0;
+  for (int k = 0; k < a.splits; ++k) tot += a.partial[n * a.splits + k];
+  const float L = (float)pow(tot, 1.0 / (double)a.p);
+  if (sp == 0 && threadIdx.x == 0 && a.losses) a.losses[n] = L;
+  const float invL = L > 0.f ? 1.0f / (a.p == 2.0f ? L : powf(L, a.p - 1.0f)) : 0.f;
+  // d x0 / d model_out and d x0 / d sample by prediction type (DDIMScheduler.step, A.7)
+  const float dxo = a.pred_type == PD_PRED_EPSILON ? -a.sqrt_b / a.sqrt_a : (a.pred_type == PD_PRED_SAMPLE ? 1.0f : -a.sqrt_b);
+  const float dxs = a.pred_type == PD_PRED_EPSILON ? 1.0f / a.sqrt_a : (a.pred_type == PD_PRED_SAMPLE ? 0.0f : a.sqrt_a);
+  const int64_t per = (a.per_sample + a.splits - 1) / a.splits;
+  const int64_t lo = sp * per, hi = lo + per < a.per_sample ? lo + per : a.per_sample;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const int64_t k = (int64_t)n * a.per_sample + i;
+    bool in;
+    const float d = lp_x0(a, a.sample[k], a.model_out[k], in) - a.target[k];
+    float g = a.p == 2.0f ? d : copysignf(powf(fabsf(d), a.p - 1.0f), d);
+    g = in ? g * invL : 0.f;               // clamp passes gradient only inside [-r, r]
+    a.d_model_out[k] = g * dxo;
+    a.d_sample_direct[k] = g * dxs;
+  }
+}
+
+__global__ __launch_bounds__(256) void guidance_apply_kernel(const pd_guidance_apply_args a) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.numel; i += (int64_t)gridDim.x * 256)
+    a.out[i] = a.x[i] - a.scale * (a.g_direct[i] + a.g_unet[i]);
+}
+
 }  // namespace pd
 
 using namespace pd;
@@ -119,6 +175,28 @@ extern "C" int pd_adamw_ema(const pd_adamw_ema_args* a, void* stream) {
   PD_CHECK(a->bias_correction2_sqrt > 0.f, PD_ERR_ARG, "pd_adamw_ema: bias_correction2_sqrt must be > 0");
   const int64_t blocks = (a->numel + 255) / 256;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_lp_guidance(const pd_lp_guidance_args* a, void* stream) {
+  using namespace pd;
+  PD_CHECK(a != nullptr && a->numel > 0 && a->per_sample > 0 && a->numel % a->per_sample == 0, PD_ERR_ARG, "pd_lp_guidance: bad sizes");
+  PD_CHECK(a->sample && a->model_out && a->target && a->partial && a->d_model_out && a->d_sample_direct && a->splits >= 1, PD_ERR_ARG, "pd_lp_guidance: null pointer");
+  PD_CHECK(a->p >= 1.0f && a->p < 1e6f, PD_ERR_UNSUPPORTED, "pd_lp_guidance: p = %g (finite p >= 1 only)", (double)a->p);
+  PD_CHECK(a->pred_type >= 0 && a->pred_type <= 2, PD_ERR_ARG, "pd_lp_guidance: bad prediction type");
+  const unsigned grid = (unsigned)((a->numel / a->per_sample) * a->splits);
+  hipLaunchKernelGGL(lp_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(lp_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_guidance_apply(const pd_guidance_apply_args* a, void* stream) {
+  using namespace pd;
+  PD_CHECK(a != nullptr && a->numel > 0 && a->x && a->g_direct && a->g_unet && a->out, PD_ERR_ARG, "pd_guidance_apply: bad args");
+  const unsigned grid = (unsigned)((a->numel + 255) / 256 < 4096 ? (a->numel + 255) / 256 : 4096);
+  hipLaunchKernelGGL(guidance_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

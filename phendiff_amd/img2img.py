@@ -64,6 +64,72 @@ def classifier_free_guidance_forward_start(pipe, clean_images, target_class_labe
                 output_type=output_type).images
 
 
+@torch.no_grad()
+def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labels: torch.Tensor, p: float,
+                             guidance_loss_scale: float, num_inference_steps: int, return_losses: bool = False):
+    """``_custom_guided_generation`` (utils_Img2Img.py:699-760), ConditionalDDIMPipeline branch.  Per step: UNet forward
+    (statistics kept), ``x0 = scheduler.step(...).pred_original_sample``, per-image ``Lp_loss(x0, input_images, p)``
+    (``:245-270``), its gradient w.r.t. the image THROUGH the UNet (what ``torch.autograd.grad(losses_seq, images)`` returns:
+    ``pd_lp_guidance`` -> input-gradient-only UNet backward), ``images -= guidance_loss_scale * grad``, then the scheduler
+    step with the model output computed before the push.  No autograd graph exists: the backward is the HIP plan."""
+    if not isinstance(pipe, ConditionalDDIMPipeline):
+        raise NotImplementedError("only the ConditionalDDIMPipeline branch is implemented")
+    if not input_images.is_cuda:
+        raise L.PhenDiffHipError("phendiff_amd runs on MI355X only (no CPU fallback): move the inputs to 'cuda'")
+    if isinstance(p, str) or not (1.0 <= float(p) < 1e6):
+        raise NotImplementedError("Lp guidance: finite p >= 1 only (the reference config uses p = 2)")
+    lib = L.lib()
+    unet, sched = pipe.unet, pipe.scheduler
+    dev = input_images.device
+    B, _, H, W = input_images.shape
+    plan = unet.input_grad_plan(B, H, W, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    target = input_images.detach().contiguous().float()
+    images = target.clone()
+    labels = target_class_labels.to(device=dev, dtype=torch.int64).contiguous()
+    model_out, d_out, d_direct, pushed = (torch.empty_like(images) for _ in range(4))
+    splits = max(1, min(64, images[0].numel() // 4096))
+    partial = torch.empty(B * splits, dtype=torch.float64, device=dev)
+    losses = torch.empty(B, dtype=torch.float32, device=dev)
+    all_losses = []
+    c = sched.config
+    sched.set_timesteps(num_inference_steps)
+    for t in sched.timesteps:
+        ts = torch.full((B,), float(t), dtype=torch.float32, device=dev)
+        plan.forward(images, ts, labels, None, model_out, st)
+        sa, sb, _, _, _ = sched.step_coefficients(t)
+        a = L.LpGuidanceArgs(numel=images.numel(), per_sample=images[0].numel(), pred_type=L.PD_PRED[c.prediction_type],
+                             clip=int(bool(c.clip_sample)), clip_range=float(c.clip_sample_range), sqrt_a=sa, sqrt_b=sb,
+                             p=float(p), sample=images.data_ptr(), model_out=model_out.data_ptr(), target=target.data_ptr(),
+                             partial=partial.data_ptr(), splits=splits, d_model_out=d_out.data_ptr(),
+                             d_sample_direct=d_direct.data_ptr(), losses=losses.data_ptr())
+        L.check(lib.pd_lp_guidance(C.byref(a), st), "pd_lp_guidance")
+        plan.backward(d_out, st)
+        g = L.GuidanceApplyArgs(numel=images.numel(), scale=float(guidance_loss_scale), x=images.data_ptr(),
+                                g_direct=d_direct.data_ptr(), g_unet=plan.dsample.data_ptr(), out=pushed.data_ptr())
+        L.check(lib.pd_guidance_apply(C.byref(g), st), "pd_guidance_apply")
+        images = sched.step(model_out, t, pushed).prev_sample
+        if return_losses:
+            all_losses.append(losses.clone())
+    return (images, all_losses) if return_losses else images
+
+
+@torch.no_grad()
+def linear_interp_custom_guidance_inverted_start(pipe, clean_images, orig_class_labels, target_class_labels, p: float,
+                                                 guidance_loss_scale: float, num_inference_steps: int,
+                                                 variant: str = "0.18.2", output_type: str = "numpy"):
+    """``_linear_interp_custom_guidance_inverted_start`` (utils_Img2Img.py:651-696): inversion under the original class,
+    then gradient-guided generation under the target class (``p`` / ``guidance_loss_scale``: the method's config keys,
+    defaults 2 / 0.001).  ``output_type``: "pt" = the [-1, 1] tensor the reference hands to ``tensor_to_PIL``; "numpy" =
+    NHWC float in [0, 1]; "pil"."""
+    inverted = inversion(pipe, clean_images, orig_class_labels, num_inference_steps, None, variant)
+    image = custom_guided_generation(pipe, inverted, target_class_labels, p, guidance_loss_scale, num_inference_steps)
+    if output_type == "pt":
+        return image
+    arr = (image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy()
+    return pipe.numpy_to_pil(arr) if output_type == "pil" else arr
+
+
 def swap_binary_labels(orig_class_labels: torch.Tensor) -> torch.Tensor:
     """``target = 1 - orig`` (utils_Img2Img.py:343-344): strictly binary datasets."""
     return 1 - orig_class_labels

@@ -184,6 +184,7 @@ class CustomCondUNet2DModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
         self._plans = {}
         self._weights = None
+        self._grad_weights = None
         self.requires_grad_(False)  # no autograd graph: gradients come from the HIP backward plan (phendiff_amd.unet_train)
 
     # ---- diffusers-like conveniences ------------------------------------------------------------
@@ -231,6 +232,22 @@ class CustomCondUNet2DModel(nn.Module):
         """Drop packed weights / plans (call after changing parameters in place)."""
         self._plans = {}
         self._weights = None
+        self._grad_weights = None
+
+    def input_grad_plan(self, B, H, W, device):
+        """Forward + input-gradient-only backward plan (d loss / d sample through the UNet, no parameter gradients): what
+        ``torch.autograd.grad(losses, images)`` needs in the gradient-guided transfer (utils_Img2Img.py:744-745)."""
+        from .unet_train import TrainWeights, UNetTrainPlan
+        key = ("input_grad", B, H, W, str(device), self.compute_dtype)
+        p = self._plans.get(key)
+        if p is None:
+            if self._weights is None:
+                self._weights = _PackedWeights(self, device)
+            if getattr(self, "_grad_weights", None) is None:
+                self._grad_weights = TrainWeights(self, device, self._weights.tdt)
+            p = UNetTrainPlan(self, self._weights, self._grad_weights, B, H, W, device, input_grad=True)
+            self._plans[key] = p
+        return p
 
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],

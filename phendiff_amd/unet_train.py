@@ -82,6 +82,8 @@ class TrainWeights:
         wo = torch.zeros((((co + 31) // 32) * 32,) + tuple(m.conv_out.weight.shape[1:]), dtype=torch.float32, device=device)
         wo[:co] = m.conv_out.weight.detach().to(device=device, dtype=torch.float32)
         self.conv_out_d = pk(wo)           # 32 (3 real) output-gradient channels -> block_out_channels[0]
+        # conv_in's input gradient (the image gradient of the guided transfer): block_out_channels[0] -> 3 channels (pad 32)
+        self.conv_in_d = pack_conv_weight(dgrad_weight(m.conv_in.weight.detach().to(device=device, dtype=torch.float32)), tdt, 32)
 
     def refresh(self, m):
         _copy_into(self, TrainWeights(m, self.device, self.tdt))
@@ -94,11 +96,17 @@ class UNetTrainPlan(UNetPlan):
     :func:`training_param_order` prescribes.  ``backward`` ACCUMULATES into ``grads`` (zero them between steps)."""
 
     def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, tw: TrainWeights, B, H, W, device,
-                 params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]):
+                 params: Optional[Dict[str, torch.Tensor]] = None, grads: Optional[Dict[str, torch.Tensor]] = None,
+                 input_grad: bool = False):
+        """``grads`` = None: no parameter gradients (weight / bias / GroupNorm / embedding launches are not emitted);
+        ``input_grad``: also produce d loss / d sample (fp32 NCHW, ``self.dsample``) -- the gradient-guided transfer."""
         self.train = True
         super().__init__(m, w, B, H, W, device)
         self.tw, self.params, self.grads = tw, params, grads
-        self._check_layout()
+        self.param_grads, self.input_grad = grads is not None, input_grad
+        self.dsample = self._f32(B, m.config.in_channels, H, W) if input_grad else None
+        if self.param_grads:
+            self._check_layout()
         c0, tdim = m.config.block_out_channels[0], m.time_embed_dim
         self.t_feat, self.t_z1, self.t_emb = self._f32(B, c0), self._f32(B, tdim), self._f32(B, tdim)
         self.temb_table = self._f32(B, w.proj_dim)
@@ -182,6 +190,8 @@ class UNetTrainPlan(UNetPlan):
     def _G(self, name, span=()):
         """Gradient tensor of a parameter, noting that the NEXT emitted op writes it (and the parameters fused behind it:
         ``span``) -- the schedule the overlapped data-parallel all-reduce follows."""
+        if not self.param_grads:
+            return None
         for n in (name,) + tuple(span):
             self.grad_ready[n] = len(self.bwd_ops)
         return self.grads[name]
@@ -190,6 +200,8 @@ class UNetTrainPlan(UNetPlan):
         return 2 if self.code == L.PD_BF16 else 4
 
     def _bias_grad(self, dy, total, valid=None, per_sample=None, per_stride=None):
+        if not self.param_grads:
+            return
         B, h, w, ch = dy.shape
         out = per_sample if per_sample is not None else self._tmp((B, ch), "chsum", torch.float32)
         fused = self._fused_sums.get(id(dy))
@@ -209,6 +221,8 @@ class UNetTrainPlan(UNetPlan):
         self._b(self.lib.pd_channel_sum, a, "channel_sum", 0.0, dy.numel() * self._esz())
 
     def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0):
+        if not self.param_grads:
+            return
         B, hin, win, c0 = x0.shape
         c1 = x1.shape[3] if x1 is not None else 0
         _, hout, wout, cout = dy.shape
@@ -256,7 +270,7 @@ class UNetTrainPlan(UNetPlan):
                         gamma=s.gamma.data_ptr(), beta=s.beta.data_ptr(), partial=partial.data_ptr(), splits=splits,
                         coef=coef.data_ptr(), dx0=g0[0].data_ptr(), dx1=(g1[0].data_ptr() if g1 else None),
                         accumulate0=int(g0[1]), accumulate1=int(g1[1]) if g1 else 0,
-                        dgamma=self._G(wname + ".weight").data_ptr(), dbeta=self._G(wname + ".bias").data_ptr(),
+                        dgamma=L.ptr(self._G(wname + ".weight")), dbeta=L.ptr(self._G(wname + ".bias")),
                         dz_combined=1 if (combined and c1) else 0, res=L.ptr(res))
         g0[1] = True
         if g1:
@@ -265,7 +279,7 @@ class UNetTrainPlan(UNetPlan):
         # which the producer block's bias / time-embedding gradients read instead of another pass (a later writer of the
         # same buffer re-registers and supersedes these)
         for src, fld, gb in ((x0, "sum0", g0), (x1, "sum1", g1)):
-            if src is None:
+            if src is None or not self.param_grads:
                 continue
             prev = self._sum_owner.pop(id(src), None)
             if prev is not None:
@@ -324,12 +338,24 @@ class UNetTrainPlan(UNetPlan):
                 self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
             elif k == "conv_in":
                 dout = self._g(rec.out)[0]
+                if self.input_grad:
+                    ops, self.ops = self.ops, self.bwd_ops
+                    try:
+                        self._conv(dout, None, tw.conv_in_d, self._zero_bias, c.in_channels, out_mode=L.PD_OUT_NCHW_F32,
+                                   cout_pad=32, y=self.dsample, stats=False)
+                    finally:
+                        self.ops = ops
+                    self.bwd_ops[-1].what = "dgrad3x3"
+                if not self.param_grads:
+                    continue
                 self._bias_grad(dout, G("conv_in.bias"))
                 cols = self._tmp((B, H, W, 32), "im2col")
                 a = L.Im2col3Args(dtype=self.code, B=B, H=H, W=W, C=c.in_channels, x=None, out=cols.data_ptr())
                 self._sample_ptr_args.append(a)
                 self._b(self.lib.pd_im2col3, a, "im2col3", 0.0, cols.numel() * self._esz())
                 self._wgrad(cols, None, None, 0, dout, G("conv_in.weight"), ksize=1, pad=0, cin_valid=c.in_channels * 9)
+        if not self.param_grads:
+            return
         self._temb_bwd()
         # one slab serves every weight-gradient launch (they run back to back on one stream)
         need = max(self.lib.pd_conv_wgrad_workspace(C.byref(a)) for a in self._wgrad_args)
@@ -507,6 +533,7 @@ class _Repacker:
         co, c0 = m.conv_out.weight.shape[0], m.conv_out.weight.shape[1]
         job(w.conv_out_w, m.conv_out.weight, co, c0, 3, cout_pad=w.conv_out_pad)
         job(tw.conv_out_d, m.conv_out.weight, c0, co, 3, dgrad=1, cin_pad=w.conv_out_pad)
+        job(tw.conv_in_d, m.conv_in.weight, ci, m.conv_in.weight.shape[0], 3, dgrad=1, cout_pad=32)
         te = m.time_embedding
         res = [mod for _, mod in m.named_modules() if isinstance(mod, _Resnet)]
         pd_, tdim = w.proj_dim, m.time_embed_dim

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import (CondUNet2DRef, ConditionalDDIMPipelineRef, DDIMInverseSchedulerRef, DDIMSchedulerRef,  # noqa: E402
-                    UNET_CONFIGS, ddib_ref)
+                    UNET_CONFIGS, ddib_ref, linear_interp_custom_guidance_inverted_start_ref)
 
 SCHED_3K = dict(num_train_timesteps=3000, beta_start=1e-4, beta_end=0.02, beta_schedule="scaled_linear",
                 clip_sample=True, clip_sample_range=1.0, prediction_type="v_prediction",
@@ -43,6 +43,10 @@ def main():
         eps = unet(x, 1500, class_labels=labels).sample
     np.savez_compressed(os.path.join(HERE, "ddib_super_small_32_s4.npz"), images=x.numpy(), labels=labels.numpy(),
                         inverted=inverted.numpy(), out_images=out, unet_out_t1500=eps.numpy())
+    # gradient-guided transfer (utils_Img2Img.py:651-760), p = 2, S = 3; loss scale 0.5 so the gradient term is visible
+    guided = linear_interp_custom_guidance_inverted_start_ref(pipe, x[:2], labels[:2], 1 - labels[:2], 2, 0.5, 3)
+    np.savez_compressed(os.path.join(HERE, "guided_super_small_32_s3.npz"), images=x[:2].numpy(), labels=labels[:2].numpy(),
+                        p=np.float32(2), guidance_loss_scale=np.float32(0.5), out=guided.numpy())
     # scheduler tables (int64 grids are bit-exact requirements)
     sched.set_timesteps(50)
     inv = DDIMInverseSchedulerRef.from_config(sched.config)

@@ -178,3 +178,85 @@ def test_overlapped_gradient_allreduce_path_single_rank():
         assert torch.equal(tr.opt.grad, want)
     finally:
         dist.destroy_process_group()
+
+
+def _pipes(mode, size=32):
+    import phendiff_amd as P
+    from oracle import ConditionalDDIMPipelineRef, DDIMSchedulerRef
+    r, m = make_pair("super_small", size, mode)
+    cfg = P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]
+    return (ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**cfg)), P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**cfg)))
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("p", [2, 1.5])
+def test_guidance_gradient_through_unet_matches_autograd(mode, tol, p):
+    """d Lp(x0_pred, target) / d image through the UNet and the scheduler's x0 formula (clipped), one step
+    (torch.autograd.grad(losses_seq, images), utils_Img2Img.py:744-745)."""
+    from oracle import lp_loss_ref
+    from test_gpu_unet_ddib import synth_batch
+    rp, pp = _pipes(mode)
+    x, labels = synth_batch(2, 32)
+    g = torch.Generator().manual_seed(3)
+    images = (x + 0.3 * torch.randn(x.shape, generator=g)).requires_grad_(True)
+    target = x.clone()
+    rp.scheduler.set_timesteps(4)
+    t = rp.scheduler.timesteps[1]
+    mo = rp.unet(images, t, labels).sample
+    x0 = rp.scheduler.step(mo, t, images).pred_original_sample
+    losses = lp_loss_ref(x0, target, p)
+    (ref,) = torch.autograd.grad([losses[0], losses[1]], images)
+
+    import ctypes as C
+    import phendiff_amd._lib as L
+    dev = "cuda:0"
+    plan = pp.unet.input_grad_plan(2, 32, 32, torch.device(dev))
+    st = torch.cuda.current_stream().cuda_stream
+    im, tg, lb = images.detach().to(dev).contiguous(), target.to(dev), labels.to(dev)
+    out, d_out, d_dir = (torch.empty_like(im) for _ in range(3))
+    pp.scheduler.set_timesteps(4)
+    plan.forward(im, torch.full((2,), float(t), device=dev), lb, None, out, st)
+    sa, sb, _, _, _ = pp.scheduler.step_coefficients(t)
+    partial = torch.empty(2 * 4, dtype=torch.float64, device=dev)
+    ls = torch.empty(2, device=dev)
+    a = L.LpGuidanceArgs(numel=im.numel(), per_sample=im[0].numel(), pred_type=2, clip=1, clip_range=1.0, sqrt_a=sa, sqrt_b=sb,
+                         p=float(p), sample=im.data_ptr(), model_out=out.data_ptr(), target=tg.data_ptr(),
+                         partial=partial.data_ptr(), splits=4, d_model_out=d_out.data_ptr(), d_sample_direct=d_dir.data_ptr(),
+                         losses=ls.data_ptr())
+    L.check(L.lib().pd_lp_guidance(C.byref(a), st), "pd_lp_guidance")
+    plan.backward(d_out, st)
+    torch.cuda.synchronize()
+    assert rel(ls, losses.detach()) < (1e-5 if mode == "f32" else 2e-2)
+    assert rel(d_dir + plan.dsample, ref) < tol
+
+
+def test_gradient_guided_transfer_matches_oracle_f32():
+    """_linear_interp_custom_guidance_inverted_start end to end (inversion + guided generation), S = 3.  The loss scale is
+    raised from the reference default 1e-3 so that a wrong gradient could not hide inside the tolerance."""
+    import phendiff_amd as P
+    from oracle import linear_interp_custom_guidance_inverted_start_ref
+    from test_gpu_unet_ddib import synth_batch
+    rp, pp = _pipes("f32")
+    x, labels = synth_batch(2, 32)
+    target = 1 - labels
+    ref = linear_interp_custom_guidance_inverted_start_ref(rp, x, labels, target, 2, 0.5, 3)
+    got = P.linear_interp_custom_guidance_inverted_start(pp, x.cuda(), labels.cuda(), target.cuda(), 2, 0.5, 3, output_type="pt")
+    assert rel(got, ref) < 2e-3
+    plain = P.ddib(pp, x.cuda(), labels.cuda(), target.cuda(), 3, output_type="numpy")      # guidance must have had an effect
+    moved = (got / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy()
+    assert float(abs(moved - plain).max()) > 1e-2
+    with pytest.raises(NotImplementedError):
+        P.custom_guided_generation(pp, x.cuda(), target.cuda(), "inf", 0.001, 3)
+
+
+def test_golden_fixture_guided_transfer_f32():
+    """Committed oracle vectors (tests/golden/make_golden.py): weights seed 0, super_small @32, S = 3, p = 2, scale 0.5."""
+    import os
+    import numpy as np
+    import phendiff_amd as P
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_super_small_32_s3.npz"))
+    _, pp = _pipes("f32")
+    x, labels = torch.from_numpy(d["images"]), torch.from_numpy(d["labels"])
+    got = P.linear_interp_custom_guidance_inverted_start(pp, x.cuda(), labels.cuda(), (1 - labels).cuda(), float(d["p"]),
+                                                         float(d["guidance_loss_scale"]), 3, output_type="pt")
+    assert rel(got, d["out"]) < 2e-3
