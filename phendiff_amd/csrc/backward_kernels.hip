@@ -121,18 +121,18 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_ar
       a.coef[(n * a.groups + tid) * 2] = (float)(r * A / M);
       a.coef[(n * a.groups + tid) * 2 + 1] = (float)(r * Bq / M);
     }
-  } else {   // parameter gradients of 32 channels per block: 8 lanes share the (sample, split) terms of a channel, fixed order
-    const int c = (blockIdx.x - a.B) * 32 + (tid >> 3), q = tid & 7;
+  } else {   // parameter gradients of 8 channels per block: 32 lanes share the (sample, split) terms of a channel, fixed order
+    const int c = (blockIdx.x - a.B) * 8 + (tid >> 5), q = tid & 31;
     double d1 = 0.0, d2 = 0.0;
     if (c < C) {
       const int terms = a.B * a.splits;
-      for (int t = q; t < terms; t += 8) {
+      for (int t = q; t < terms; t += 32) {
         const double* in = a.partial + ((size_t)t * C + c) * 2;
         d1 += in[0]; d2 += in[1];
       }
     }
 #pragma unroll
-    for (int msk = 1; msk < 8; msk <<= 1) { d1 += __shfl_xor(d1, msk); d2 += __shfl_xor(d2, msk); }
+    for (int msk = 1; msk < 32; msk <<= 1) { d1 += __shfl_xor(d1, msk); d2 += __shfl_xor(d2, msk); }
     if (c < C && q == 0) {
       if (a.dbeta) a.dbeta[c] += (float)d1;
       if (a.dgamma) a.dgamma[c] += (float)d2;
@@ -411,11 +411,11 @@ extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
   const unsigned agrid = (unsigned)(a->B * a->splits);
   if (a->dtype == PD_F32) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 31) / 32), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 7) / 8), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(agrid), dim3(256), 0, st, *a);
   } else if (a->dtype == PD_BF16) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 31) / 32), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 7) / 8), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(agrid), dim3(256), 0, st, *a);
   } else { set_error("pd_gn_silu_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();

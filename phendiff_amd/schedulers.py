@@ -137,11 +137,15 @@ class _SchedulerBase:
         return prev, x0
 
     def _per_sample_coefs(self, timesteps, device):
-        acp = self.alphas_cumprod
-        t = timesteps.detach().cpu().long().reshape(-1)
-        sa = (acp[t] ** 0.5).to(device)
-        sb = ((1 - acp[t]) ** 0.5).to(device)
-        return sa.contiguous(), sb.contiguous()
+        """sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t) per sample.  The tables are computed once on the host in fp32 (the
+        reference's arithmetic, bit for bit) and gathered on the device: no host sync when ``timesteps`` live there."""
+        tabs = getattr(self, "_coef_tables", None)
+        if tabs is None or tabs[0].device != torch.device(device):
+            acp = self.alphas_cumprod
+            tabs = ((acp ** 0.5).to(device), ((1 - acp) ** 0.5).to(device))
+            self._coef_tables = tabs
+        t = timesteps.detach().to(device=device, dtype=torch.long).reshape(-1)
+        return tabs[0][t].contiguous(), tabs[1][t].contiguous()
 
     def _mix(self, x, noise, timesteps, velocity):
         if not x.is_cuda:

@@ -75,6 +75,9 @@ class DiffusionLoss:
     def __init__(self, scheduler, device):
         self.scheduler = scheduler
         self.partial = torch.empty(1024, dtype=torch.float64, device=device)
+        acp = scheduler.alphas_cumprod.float()
+        # host-computed fp32 tables (the reference's arithmetic), gathered on the device: no host sync per step
+        self.tables = tuple(t.to(device) for t in (acp / (1 - acp), acp ** 0.5, (1 - acp) ** 0.5))
 
     def __call__(self, model_out, clean, noise, timesteps, want_grad=True, grad_scale=1.0):
         if not model_out.is_cuda:
@@ -82,12 +85,14 @@ class DiffusionLoss:
         pt = self.scheduler.config.prediction_type
         dev = model_out.device
         mo, cl, nz = model_out.contiguous().float(), clean.contiguous().float(), noise.contiguous().float()
-        acp = self.scheduler.alphas_cumprod[timesteps.detach().cpu().long()]
+        if self.tables[0].device != dev:
+            self.tables = tuple(t.to(dev) for t in self.tables)
+        idx = timesteps.detach().to(device=dev, dtype=torch.long)
         w = sa = sb = None
         if pt == "sample":
-            w = (acp / (1 - acp)).to(dev).contiguous()          # SNR weights (extract_into_tensor, utils_misc.py:33-48)
+            w = self.tables[0][idx].contiguous()                # SNR weights (extract_into_tensor, utils_misc.py:33-48)
         elif pt == "v_prediction":
-            sa, sb = (acp ** 0.5).to(dev).contiguous(), ((1 - acp) ** 0.5).to(dev).contiguous()
+            sa, sb = self.tables[1][idx].contiguous(), self.tables[2][idx].contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         grad = torch.empty_like(mo) if want_grad else None
         a = L.LossArgs(numel=mo.numel(), per_sample=mo[0].numel(), pred_type=L.PD_PRED[pt], model_out=mo.data_ptr(),
