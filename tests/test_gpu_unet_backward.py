@@ -260,3 +260,26 @@ def test_golden_fixture_guided_transfer_f32():
     got = P.linear_interp_custom_guidance_inverted_start(pp, x.cuda(), labels.cuda(), (1 - labels).cuda(), float(d["p"]),
                                                          float(d["guidance_loss_scale"]), 3, output_type="pt")
     assert rel(got, d["out"]) < 2e-3
+
+
+def test_unet_backward_small_denoiser_and_non_square_f32():
+    """Wider model (128/256/512 channels, concat inputs up to 1024) and a non-square sample (32 x 64)."""
+    from phendiff_amd.unet_train import UNetTrainer
+    import phendiff_amd as P
+    for name, hw in (("small_denoiser_config", (32, 32)), ("super_small", (32, 64))):
+        r, m = make_pair(name, 32, "f32")
+        sched = P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+        g = torch.Generator().manual_seed(9)
+        B = 2
+        clean = torch.rand(B, 3, *hw, generator=g) * 2 - 1
+        noise = torch.randn(B, 3, *hw, generator=g)
+        ts = torch.tensor([2100, 333])
+        labels = torch.tensor([1, 0])
+        acp = sched.alphas_cumprod[ts]
+        sa, sb = (acp ** 0.5).view(-1, 1, 1, 1), ((1 - acp) ** 0.5).view(-1, 1, 1, 1)
+        noisy, target = sa * clean + sb * noise, sa * noise - sb * clean
+        _, ref = oracle_grads(r, noisy, ts, target, labels=labels)
+        tr = UNetTrainer(m, sched, lr=1e-4, use_ema=False)
+        tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+        torch.cuda.synchronize()
+        compare(ref, tr.grads, 3e-4, 3e-5)
