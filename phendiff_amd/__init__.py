@@ -15,3 +15,4 @@ from .img2img import (inversion, ddib, inverted_regeneration, classifier_free_gu
 from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401
 from . import training  # noqa: F401
 from .unet_train import UNetTrainer, UNetTrainPlan, training_param_order  # noqa: F401
+from . import train_state  # noqa: F401

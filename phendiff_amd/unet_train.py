@@ -677,6 +677,16 @@ class UNetTrainer:
         flat.div_(world)
         return loss
 
+    def save_state(self, output_dir, **kw):
+        """``accelerator.save_state`` layout (``train_state.py``): model, AdamW moments, LR-scheduler, RNG, EMA."""
+        from .train_state import save_state
+        save_state(self, output_dir, **kw)
+
+    def load_state(self, input_dir, **kw):
+        """``accelerator.load_state``: restores everything ``save_state`` wrote, in place (plans stay valid)."""
+        from .train_state import load_state
+        return load_state(self, input_dir, **kw)
+
     def refresh_weights(self):
         """Parameters changed in place: rebuild the kernel-layout copies (same device buffers, plans stay valid)."""
         m = self.model

@@ -283,3 +283,37 @@ def test_unet_backward_small_denoiser_and_non_square_f32():
         tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
         torch.cuda.synchronize()
         compare(ref, tr.grads, 3e-4, 3e-5)
+
+
+def test_save_state_resume_continues_bitwise(tmp_path):
+    """accelerate-layout checkpoint (utils_misc.py:322-347, utils_training.py:56-94): a run resumed from step_2 on a fresh
+    trainer reproduces the uninterrupted run's losses exactly (deterministic kernels, ordered reductions)."""
+    import os
+    import phendiff_amd as P
+    from phendiff_amd import train_state as TS
+    sched, clean, noise, ts, labels, noisy, _ = batch(4, 32)
+    args = [t.cuda() for t in (noisy, ts, clean, noise)]
+
+    def fresh():
+        _, m = make_pair("super_small", 32, "bf16")
+        return P.UNetTrainer(m, sched, lr=3e-4)
+    a = fresh()
+    first = [float(a.step(*args, class_labels=labels.cuda())) for _ in range(2)]
+    folder = TS.save_checkpoint(a, str(tmp_path), 2, checkpoints_total_limit=1)
+    assert sorted(os.listdir(folder)) == ["custom_checkpoint_0.pkl", "optimizer.bin", "pytorch_model.bin", "random_states_0.pkl",
+                                          "scheduler.bin"]
+    rest = [float(a.step(*args, class_labels=labels.cuda())) for _ in range(3)]
+    TS.save_checkpoint(a, str(tmp_path), 5, checkpoints_total_limit=1)
+    assert os.listdir(tmp_path) == ["step_5"]                                  # total_limit pruning
+    TS.save_checkpoint(a, str(tmp_path), 2, checkpoints_total_limit=None)       # put a step_2 lookalike back for "which="
+    b = fresh()
+    # resume from the real step-2 state: re-create it by replaying (the pruned folder is gone) -> use a second trainer
+    c = fresh()
+    for _ in range(2):
+        c.step(*args, class_labels=labels.cuda())
+    c.save_state(str(tmp_path / "again" / "step_2"))
+    first_epoch, resume_step, global_step, sched_state = TS.resume_from_checkpoint(b, str(tmp_path / "again"), "latest", 10)
+    assert (first_epoch, resume_step, global_step) == (0, 2, 2) and sched_state["last_epoch"] == 2 and b.opt.t == 2
+    resumed = [float(b.step(*args, class_labels=labels.cuda())) for _ in range(3)]
+    assert resumed == rest, (first, rest, resumed)
+    assert torch.equal(b.opt.ema, a.opt.ema) and torch.equal(b.opt.flat, a.opt.flat)

@@ -153,3 +153,48 @@ def test_sample_training_inputs_semantics():
     assert ts.dtype == torch.int64 and ts.min() >= 0 and ts.max() < 3000
     a = sched.alphas_cumprod[ts.cpu()][:, None, None, None]
     assert torch.allclose(noisy.cpu(), a ** 0.5 * clean.cpu() + (1 - a) ** 0.5 * noise.cpu(), atol=1e-6)
+
+
+def test_optimizer_state_in_accelerate_layout_roundtrips_through_torch_adamw(tmp_path):
+    """optimizer.bin of accelerator.save_state = torch.optim.AdamW.state_dict(): built from the engine's flat moment buffers
+    it must load into a real torch AdamW over the same module (parameters() order), land on the right parameters, and load
+    back into flat buffers unchanged."""
+    import phendiff_amd as P
+    from phendiff_amd import train_state as TS
+    m = P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], sample_size=32))
+    order = P.training_param_order(m)
+    fnames = [n for n, _ in order]
+    pnames = [n for n, _ in m.named_parameters()]
+    sizes = {n: p.shape for n, p in order}
+    n = sum(p.numel() for _, p in order)
+    g = torch.Generator().manual_seed(0)
+    ea, eas = torch.randn(n, generator=g), torch.rand(n, generator=g)
+    sd = TS.optimizer_state_dict(pnames, fnames, sizes, ea, eas, step=7, lr=3e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    opt = torch.optim.AdamW(m.parameters(), lr=1.0)
+    opt.load_state_dict(sd)                                     # torch accepts the layout
+    assert opt.param_groups[0]["lr"] == 3e-4 and opt.param_groups[0]["betas"] == (0.95, 0.999)
+    # a parameter that sits elsewhere in the flat buffer than in parameters() order
+    name = "down_blocks.2.attentions.0.to_k.weight"
+    off = sum(sizes[k].numel() for k in fnames[:fnames.index(name)])
+    st = opt.state[dict(m.named_parameters())[name]]
+    assert float(st["step"]) == 7 and torch.equal(st["exp_avg"].reshape(-1), ea[off:off + sizes[name].numel()])
+    torch.save(opt.state_dict(), tmp_path / "optimizer.bin")     # and torch's own file loads back into the flat layout
+    ea2, eas2 = torch.empty(n), torch.empty(n)
+    step = TS.load_optimizer_state_dict(torch.load(tmp_path / "optimizer.bin"), pnames, fnames, sizes, ea2, eas2)
+    assert step == 7 and torch.equal(ea2, ea) and torch.equal(eas2, eas)
+    # EMA state in diffusers EMAModel layout: shadow list in parameters() order
+    esd = TS.ema_state_dict(ea, fnames, pnames, sizes, 7)
+    assert len(esd["shadow_params"]) == len(pnames) and esd["optimization_step"] == 7
+    assert torch.equal(esd["shadow_params"][pnames.index(name)].reshape(-1), ea[off:off + sizes[name].numel()])
+    assert TS.lr_scheduler_state_dict(1e-4, 12, 5e-5)["last_epoch"] == 12
+
+
+def test_checkpoint_folder_helpers(tmp_path):
+    from phendiff_amd import train_state as TS
+    assert TS.latest_checkpoint(str(tmp_path / "none")) is None
+    for s in (10, 200, 30):
+        (tmp_path / f"step_{s}").mkdir()
+    assert TS.latest_checkpoint(str(tmp_path)).endswith("step_200")       # numeric, not lexicographic (utils_training.py:76)
+    assert TS.resume_from_checkpoint(None, str(tmp_path / "none")) == (0, 0, 0, {})
