@@ -21,6 +21,8 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 
 from .schedulers_ref import DDIMSchedulerRef, DDIMInverseSchedulerRef  # noqa: F401
 from .unet_ref import CondUNet2DRef, UNET_CONFIGS  # noqa: F401
+from .sd_unet_ref import (  # noqa: F401
+    UNet2DConditionRef, CustomEmbeddingRef, SD21_UNET_CONFIG, class_emb_to_encoder_hidden_states)
 from .pipeline_ref import (  # noqa: F401
     ConditionalDDIMPipelineRef,
     inversion_ref,
