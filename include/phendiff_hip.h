@@ -383,6 +383,33 @@ typedef struct {
 int pd_adamw_ema(const pd_adamw_ema_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stable-Diffusion tier (diffusers UNet2DConditionModel as driven by custom_pipeline_stable_diffusion_img2img.py:680-686 and
+ * _SD_prediction_wrapper, utils_training.py:459-496).  ResnetBlock2D / GroupNorm / every nn.Linear (as a 1x1 conv over NHWC
+ * tokens) / sampling convs reuse pd_conv; the blocks below are what Transformer2DModel adds.
+ *
+ * pd_attn_d64: softmax(q k^T / sqrt(64)) v, head_dim 64 (BasicTransformerBlock.attn1: self attention; .attn2: cross
+ *   attention over the 77 encoder_hidden_states tokens).  Token-major operands with explicit strides, so q/k/v may be
+ *   slices of one fused projection output:  q[(b*Nq+i)*q_stride + head*64 + d],  k|v[(b*Nkv+j)*kv_stride + head*64 + d],
+ *   out[(b*Nq+i)*out_stride + head*64 + d].
+ */
+typedef struct {
+  int dtype;
+  int B, heads, Nq, Nkv;
+  const void* q; int q_stride;
+  const void* k; const void* v; int kv_stride;
+  void* out; int out_stride;
+} pd_attn_d64_args;
+int pd_attn_d64(const pd_attn_d64_args* a, void* stream);
+
+/* pd_layernorm: y[r][c] = (x[r][c] - mean_r) * rstd_r * gamma[c] + beta[c]  (nn.LayerNorm(C), biased variance) */
+typedef struct { int dtype; long long rows; int C; float eps; const void* x; const float* gamma; const float* beta; void* y; } pd_layernorm_args;
+int pd_layernorm(const pd_layernorm_args* a, void* stream);
+
+/* pd_geglu: y[r][i] = x[r][i] * gelu(x[r][inner + i])   (diffusers GEGLU after its Linear(C, 2*inner); exact erf GELU) */
+typedef struct { int dtype; long long rows; int inner; const void* x; void* y; } pd_geglu_args;
+int pd_geglu(const pd_geglu_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Gradient-guided transfer (_custom_guided_generation, utils_Img2Img.py:699-760).
  * pd_lp_guidance: losses[n] = || x0_n - target_n ||_p (Lp_loss, :245-270) with x0 = DDIMScheduler.step(...).pred_original_sample
  * (prediction type, clipping as pd_ddim_step), and its gradient split the way the chain rule needs it:

@@ -112,6 +112,20 @@ class AttnArgs(C.Structure):
                 ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp)]
 
 
+class AttnD64Args(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int), ("q", vp),
+                ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp), ("out_stride", C.c_int)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("C", C.c_int), ("eps", C.c_float), ("x", vp), ("gamma", vp),
+                ("beta", vp), ("y", vp)]
+
+
+class GegluArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("inner", C.c_int), ("x", vp), ("y", vp)]
+
+
 class LpGuidanceArgs(C.Structure):
     _fields_ = [("numel", C.c_int64), ("per_sample", C.c_int64), ("pred_type", C.c_int), ("clip", C.c_int),
                 ("clip_range", C.c_float), ("sqrt_a", C.c_float), ("sqrt_b", C.c_float), ("p", C.c_float), ("sample", vp),
@@ -184,6 +198,9 @@ SYMBOLS = {
     "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
+    "pd_attn_d64": (C.c_int, [C.POINTER(AttnD64Args), vp]),
+    "pd_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), vp]),
+    "pd_geglu": (C.c_int, [C.POINTER(GegluArgs), vp]),
     "pd_lp_guidance": (C.c_int, [C.POINTER(LpGuidanceArgs), vp]),
     "pd_guidance_apply": (C.c_int, [C.POINTER(GuidanceApplyArgs), vp]),
     "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),

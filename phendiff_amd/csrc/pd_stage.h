@@ -57,4 +57,39 @@ template <> struct Stage<float> {
 };
 
 
+// ---- MFMA operand fragments whose 8 elements are 8 consecutive ROWS of an LDS image at one column (a transposed read):
+// bf16 via ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3; lane i receives column i),
+// fp32 (validation) via eight ds_read_b32.  Used by the weight-gradient GEMM (K = pixels) and the d = 64 attention (V^T).
+template <typename T> struct FragLd;
+template <> struct FragLd<bf16_t> {
+  // lane base address: pixel 8h+q, channels 16*cg + 4*pp (see file header); second read 4 pixels further
+  static __device__ __forceinline__ unsigned lane_off(int lane, int pitch) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    return (unsigned)((8 * (g >> 1) + q) * pitch + (16 * (g & 1) + 4 * pp) * 2);
+  }
+  template <int PITCH>
+  static __device__ __forceinline__ Elem<bf16_t>::Frag load(const unsigned char* base) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lp;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + 4 * PITCH));
+    Elem<bf16_t>::Frag f;
+    f.v = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+  }
+};
+template <> struct FragLd<float> {
+  static __device__ __forceinline__ unsigned lane_off(int lane, int pitch) {
+    return (unsigned)(8 * (lane >> 5) * pitch + (lane & 31) * 4);
+  }
+  template <int PITCH>
+  static __device__ __forceinline__ Elem<float>::Frag load(const unsigned char* base) {
+    Elem<float>::Frag f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.lo[j] = *(const float*)(base + j * PITCH); f.hi[j] = *(const float*)(base + (4 + j) * PITCH); }
+    return f;
+  }
+};
+
+
 }  // namespace pd

@@ -1,0 +1,304 @@
+// Kernels of the Stable-Diffusion tier (diffusers UNet2DConditionModel / Transformer2DModel blocks):
+//   pd_attn_d64  : softmax(q k^T / 8) v for head_dim 64 -- BasicTransformerBlock.attn1 (self, N up to 4096) and .attn2 (cross,
+//                  77 context tokens); the contraction is genuinely dense here, so both products run as full MFMA tiles
+//   pd_layernorm : nn.LayerNorm(C) over the channels of each token (norm1/2/3 of BasicTransformerBlock)
+//   pd_geglu     : GEGLU gate  h * gelu(g)  of FeedForward (exact erf form, F.gelu default)
+// Everything else of the SD UNet (ResnetBlock2D, GroupNorm, every Linear as a 1x1 conv on NHWC tokens, down/up-sampling)
+// reuses pd_conv / pd_gn_finalize / pd_temb.
+#include "pd_common.h"
+#include "pd_stage.h"
+
+namespace pd {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention, head_dim 64.  Workgroup = 4 waves = 128 queries of one (batch, head); keys/values stream through LDS in
+// double-buffered tiles of 64.  Per wave and 32-key sub-tile:
+//   S^T[key][query] = K[32 x 64] . Q^T[64 x 32]        4 MFMA k-steps (Q fragments live in registers, pre-scaled by
+//                                                      64^-1/2 * log2 e); D layout: query on the lane, 16 keys in registers
+//   online softmax, lane-local (one cross-half exchange for the row max); P stays in registers ...
+//   O^T[d][query]  += V^T[64 x 32 keys] . P^T          ... as the B operand: 2 row tiles x 2 k-steps.  V sits row-major
+//                                                      [key][d] in LDS; the A operand V^T is a TRANSPOSED read
+//                                                      (ds_read_b64_tr_b16, rows chosen per lane to match P's key order).
+template <typename T> struct D64;
+template <> struct D64<bf16_t> {
+  static constexpr int KP = 128 + 16, VP = 128 + 64;      // row pitches: conflict-free ds_read_b128 rows / 4-row transposed blocks
+  typedef Elem<bf16_t>::Frag Frag;
+  static __device__ __forceinline__ int vt_lane_off(int lane) {      // block row q <-> key 4h + q, columns 16*cg + 4*pp of a 32-d row tile
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    return (4 * (g >> 1) + q) * VP + (16 * (g & 1) + 4 * pp) * 2;
+  }
+  // A fragment of V^T for k-step s (16 keys) of a 32-key sub-tile: element j <-> key 16s + 8(j>>2) + 4h + (j&3) (P's register order)
+  static __device__ __forceinline__ Frag load_vt(const unsigned char* base) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lp;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + 8 * VP));
+    Frag f; f.v = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+  }
+  static __device__ __forceinline__ Frag pack_p(const f32x16& p, int s) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+    Frag f; f.v = __builtin_bit_cast(s16x8, (u32x4){w[0], w[1], w[2], w[3]});
+    return f;
+  }
+};
+template <> struct D64<float> {
+  static constexpr int KP = 256 + 16, VP = 256 + 16;
+  typedef Elem<float>::Frag Frag;
+  static __device__ __forceinline__ int vt_lane_off(int lane) { return (4 * (lane >> 5)) * VP + (lane & 31) * 4; }   // key 4h, d = r
+  static __device__ __forceinline__ Frag load_vt(const unsigned char* base) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.lo[j] = *(const float*)(base + j * VP); f.hi[j] = *(const float*)(base + (8 + j) * VP); }
+    return f;
+  }
+  static __device__ __forceinline__ Frag pack_p(const f32x16& p, int s) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.lo[j] = p[8 * s + j]; f.hi[j] = p[8 * s + 4 + j]; }
+    return f;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_d64_kernel(const pd_attn_d64_args a) {
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  using X = D64<T>;
+  constexpr int KT = 64, KP = X::KP, VP = X::VP, ES = E::BYTES;
+  constexpr int KBYTES = KT * KP, VBYTES = KT * VP;
+  constexpr int PIECES = KT * 64 / 8 / 256;            // 8-element pieces per thread per tensor (2)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][K tile | V tile]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nqb = (a.Nq + 127) / 128;
+  const int total = nqb * a.heads * a.B;
+  int item = blockIdx.x;
+  if ((total & 7) == 0) item = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);     // query blocks of one head share an XCD / L2
+  const int qb = item % nqb, head = (item / nqb) % a.heads, b = item / (nqb * a.heads);
+  const T* qp = (const T*)a.q + (size_t)b * a.Nq * a.q_stride + head * 64;
+  const T* kp = (const T*)a.k + (size_t)b * a.Nkv * a.kv_stride + head * 64;
+  const T* vp = (const T*)a.v + (size_t)b * a.Nkv * a.kv_stride + head * 64;
+
+  // Q^T fragments (B operand): lane (query, h), k-step ks: d = 16 ks + 8 h + j, pre-scaled
+  const int query = qb * 128 + wave * 32 + r, qc = min(query, a.Nq - 1);
+  const float qscale = 0.125f * 1.4426950408889634f;
+  Frag qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    float v[8];
+    E::unpack(E::load(qp + (size_t)qc * a.q_stride + 16 * ks + 8 * h), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= qscale;
+    qf[ks] = E::pack(v);
+  }
+  f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);      // O^T row tiles d 0..31, 32..63
+  float m = -INFINITY, l = 0.f;                      // l: this lane half's share of the row sum
+
+  Frag stk[PIECES], stv[PIECES];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + 256 * i, key = k0 + (pc >> 3), sub = pc & 7;
+      if (key < a.Nkv) {
+        stk[i] = E::load(kp + (size_t)key * a.kv_stride + sub * 8);
+        stv[i] = E::load(vp + (size_t)key * a.kv_stride + sub * 8);
+      } else { stk[i] = E::zero(); stv[i] = E::zero(); }
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* kb = lds + buf * (KBYTES + VBYTES);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + 256 * i, row = pc >> 3, sub = pc & 7;
+      E::store(kb + row * KP + sub * 8 * ES, stk[i]);
+      E::store(kb + KBYTES + row * VP + sub * 8 * ES, stv[i]);
+    }
+  };
+  const int k_lane = r * KP + 8 * h * ES;             // K row fragment: key r, d = 16 ks + 8 h + (0..7)
+  const int v_lane = X::vt_lane_off(lane);
+
+  issue(0);
+  commit(0);
+  if (KT < a.Nkv) issue(KT);
+  __syncthreads();
+  for (int k0 = 0, cur = 0; k0 < a.Nkv; k0 += KT, cur ^= 1) {
+    const unsigned char* kb = lds + cur * (KBYTES + VBYTES);
+    const unsigned char* vb = kb + KBYTES;
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      if (k0 + sub * 32 < a.Nkv) {                    // workgroup-uniform
+        f32x16 s = (f32x16)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          s = E::mma(E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES), qf[ks], s);
+        if (k0 + sub * 32 + 32 > a.Nkv) {              // keys beyond the context length
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Nkv) s[i] = -INFINITY;
+        }
+        float tmax = s[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every sub-tile visited holds at least one real key
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i] - mn); ps += s[i]; }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const Frag pf = X::pack_p(s, st);
+          const unsigned char* vs = vb + v_lane + (sub * 32 + 16 * st) * VP;
+          o0 = E::mma(X::load_vt(vs), pf, o0);
+          o1 = E::mma(X::load_vt(vs + 32 * ES), pf, o1);
+        }
+      }
+    }
+    if (k0 + KT < a.Nkv) {
+      commit(cur ^ 1);
+      if (k0 + 2 * KT < a.Nkv) issue(k0 + 2 * KT);
+    }
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 32);
+  if (query < a.Nq) {
+    const float inv = 1.0f / l;
+    T* dst = (T*)a.out + ((size_t)b * a.Nq + query) * a.out_stride + head * 64 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                      // register 4g + i <-> d = 8g + 4h + i (+32 for the second row tile)
+      store4(dst + 8 * g, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      store4(dst + 32 + 8 * g, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over C per token: one wave per token, 8-element pieces
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const pd_layernorm_args a) {
+  using E = Elem<T>;
+  constexpr int MAXP = 4;                             // C <= 64 lanes * 8 * 4 = 2048
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int pieces = a.C / 8;
+  const T* x = (const T*)a.x + row * a.C;
+  float v[MAXP][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int pc = lane + 64 * i;
+    if (pc < pieces) {
+      E::unpack(E::load(x + pc * 8), v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk);
+  const float mean = s / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int pc = lane + 64 * i;
+    if (pc < pieces) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) q += __shfl_xor(q, msk);
+  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+  T* y = (T*)a.y + row * a.C;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int pc = lane + 64 * i;
+    if (pc < pieces) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * a.gamma[pc * 8 + j] + a.beta[pc * 8 + j];
+      E::store(y + pc * 8, E::pack(o));
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const pd_geglu_args a) {
+  using E = Elem<T>;
+  const int pieces = a.inner / 8;
+  const size_t total = (size_t)a.rows * pieces;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / pieces;
+    const int pc = (int)(idx - row * pieces);
+    float hv[8], gv[8], o[8];
+    E::unpack(E::load((const T*)a.x + row * 2 * a.inner + pc * 8), hv);
+    E::unpack(E::load((const T*)a.x + row * 2 * a.inner + a.inner + pc * 8), gv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = hv[j] * (0.5f * gv[j] * (1.0f + erff(gv[j] * 0.7071067811865476f)));
+    E::store((T*)a.y + row * a.inner + pc * 8, E::pack(o));
+  }
+}
+
+template <typename T>
+static int launch_attn_d64(const pd_attn_d64_args* a, hipStream_t st) {
+  constexpr int LDS = 2 * 64 * (D64<T>::KP + D64<T>::VP);
+  auto kern = attn_d64_kernel<T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("pd_attn_d64: cannot reserve %d bytes of LDS", LDS);
+      return PD_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(((a->Nq + 127) / 128) * a->heads * a->B), dim3(256), LDS, st, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+}  // namespace pd
+
+using namespace pd;
+
+extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_attn_d64: null args");
+  PD_CHECK(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nkv > 0, PD_ERR_SHAPE, "pd_attn_d64: bad shape");
+  PD_CHECK(a->q && a->k && a->v && a->out, PD_ERR_ARG, "pd_attn_d64: null pointer");
+  PD_CHECK(a->q_stride >= a->heads * 64 && a->kv_stride >= a->heads * 64 && a->out_stride >= a->heads * 64 && a->q_stride % 8 == 0 &&
+               a->kv_stride % 8 == 0 && a->out_stride % 8 == 0, PD_ERR_SHAPE, "pd_attn_d64: strides must cover heads*64 channels and be multiples of 8");
+  PD_CHECK((long long)((a->Nq + 127) / 128) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d64: grid too large");
+  if (a->dtype == PD_F32) return launch_attn_d64<float>(a, (hipStream_t)stream);
+  if (a->dtype == PD_BF16) return launch_attn_d64<bf16_t>(a, (hipStream_t)stream);
+  set_error("pd_attn_d64: bad dtype");
+  return PD_ERR_ARG;
+}
+
+extern "C" int pd_layernorm(const pd_layernorm_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 2048 && a->x && a->y && a->gamma && a->beta, PD_ERR_ARG,
+           "pd_layernorm: bad args (C must be a multiple of 8, <= 2048)");
+  const unsigned grid = (unsigned)((a->rows + 3) / 4);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_layernorm: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_geglu(const pd_geglu_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->inner > 0 && a->inner % 8 == 0 && a->x && a->y, PD_ERR_ARG, "pd_geglu: bad args");
+  const size_t total = (size_t)a->rows * (a->inner / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(geglu_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(geglu_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_geglu: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}

@@ -5,8 +5,8 @@ set -e
 HERE="$(cd "$(dirname "$0")/.." && pwd)"
 DEFS="$1"; shift
 cd "$HERE/phendiff_amd/csrc"
-for f in conv_igemm attn_d8 small_kernels train_kernels backward_kernels; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEFS -c $f.hip -o /tmp/ab_$f.o & done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libpd_abl.so /tmp/ab_conv_igemm.o /tmp/ab_attn_d8.o /tmp/ab_small_kernels.o /tmp/ab_train_kernels.o /tmp/ab_backward_kernels.o
+for f in conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEFS -c $f.hip -o /tmp/ab_$f.o & done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libpd_abl.so /tmp/ab_conv_igemm.o /tmp/ab_attn_d8.o /tmp/ab_small_kernels.o /tmp/ab_train_kernels.o /tmp/ab_backward_kernels.o /tmp/ab_wgrad.o /tmp/ab_sd_kernels.o
 cd "$HERE"
 python - "$@" <<'PY'
 import os, sys, runpy

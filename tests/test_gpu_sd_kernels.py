@@ -1,0 +1,72 @@
+"""SD-tier kernels on MI355X against plain PyTorch fp32 of the same ops (what the oracle's Transformer2D blocks dispatch to)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_kernels import DT, bf16_round, env, rel, stream  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 2, 256, 256), (1, 5, 1024, 1024), (2, 3, 200, 77), (1, 1, 16, 16), (2, 2, 130, 4), (1, 20, 64, 64)])
+def test_attention_d64(env, mode, cfg):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, Nq, Nkv = cfg
+    Cc = heads * 64
+    g = torch.Generator().manual_seed(41)
+    self_attn = Nq == Nkv
+    if self_attn:       # q, k, v are slices of one fused projection output [B][N][3C]
+        qkv = bf16_round(torch.randn(B, Nq, 3 * Cc, generator=g), mode)
+        q, k, v = qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:]
+        QKV = qkv.to(tdt).to(dev).contiguous()
+        esz = QKV.element_size()
+        qptr, kptr, vptr, qs, kvs = QKV.data_ptr(), QKV.data_ptr() + Cc * esz, QKV.data_ptr() + 2 * Cc * esz, 3 * Cc, 3 * Cc
+    else:               # cross attention: q [B][Nq][C], kv = fused [B][Nkv][2C]
+        q = bf16_round(torch.randn(B, Nq, Cc, generator=g), mode)
+        kv = bf16_round(torch.randn(B, Nkv, 2 * Cc, generator=g), mode)
+        k, v = kv[..., :Cc], kv[..., Cc:]
+        Q, KV = q.to(tdt).to(dev).contiguous(), kv.to(tdt).to(dev).contiguous()
+        qptr, kptr, vptr, qs, kvs = Q.data_ptr(), KV.data_ptr(), KV.data_ptr() + Cc * KV.element_size(), Cc, 2 * Cc
+    out = torch.full((B, Nq, Cc), float("nan"), dtype=tdt, device=dev)
+    a = L.AttnD64Args(dtype=code, B=B, heads=heads, Nq=Nq, Nkv=Nkv, q=qptr, q_stride=qs, k=kptr, v=vptr, kv_stride=kvs,
+                      out=out.data_ptr(), out_stride=Cc)
+    L.check(lib.pd_attn_d64(C.byref(a), stream()), "pd_attn_d64")
+    torch.cuda.synchronize()
+    sp = lambda t, n: t.reshape(B, n, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, Nq), sp(k, Nkv), sp(v, Nkv)).transpose(1, 2).reshape(B, Nq, Cc)
+    assert rel(out.float(), ref) < (2e-5 if mode == "f32" else 1.5e-2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(37, 64), (1000, 320), (513, 1280), (4, 2048)])
+def test_layernorm(env, mode, cfg):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    rows, Cc = cfg
+    g = torch.Generator().manual_seed(42)
+    x = bf16_round(torch.randn(rows, Cc, generator=g) * 2 + 0.5, mode)
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    X, y = x.to(tdt).to(dev), torch.empty((rows, Cc), dtype=tdt, device=dev)
+    gm, bt = gamma.to(dev), beta.to(dev)
+    a = L.LayerNormArgs(dtype=code, rows=rows, C=Cc, eps=1e-5, x=X.data_ptr(), gamma=gm.data_ptr(), beta=bt.data_ptr(), y=y.data_ptr())
+    L.check(lib.pd_layernorm(C.byref(a), stream()), "pd_layernorm")
+    torch.cuda.synchronize()
+    assert rel(y.float(), F.layer_norm(x, (Cc,), gamma, beta, 1e-5)) < (2e-6 if mode == "f32" else 4e-3)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_geglu(env, mode):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    g = torch.Generator().manual_seed(43)
+    x = bf16_round(torch.randn(301, 2 * 256, generator=g) * 2, mode)
+    X, y = x.to(tdt).to(dev), torch.empty((301, 256), dtype=tdt, device=dev)
+    a = L.GegluArgs(dtype=code, rows=301, inner=256, x=X.data_ptr(), y=y.data_ptr())
+    L.check(lib.pd_geglu(C.byref(a), stream()), "pd_geglu")
+    torch.cuda.synchronize()
+    h, gate = x.chunk(2, -1)
+    assert rel(y.float(), h * F.gelu(gate)) < (2e-6 if mode == "f32" else 4e-3)
