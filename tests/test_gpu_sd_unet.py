@@ -1,0 +1,69 @@
+"""SD-tier UNet2DConditionModel forward on MI355X against the CPU oracle on identical seeded weights / inputs, with the
+reference's class conditioning (CustomEmbedding token + 76 zero tokens as encoder_hidden_states)."""
+import pytest
+import torch
+
+from test_gpu_unet_ddib import rel
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(in_channels=4, out_channels=4, block_out_channels=(64, 128), layers_per_block=1,
+            down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+            attention_head_dim=(1, 2), cross_attention_dim=96, norm_num_groups=32)
+SMALL = dict(in_channels=4, out_channels=4, block_out_channels=(64, 128, 192), layers_per_block=2,
+             down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+             up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+             attention_head_dim=(1, 2, 3), cross_attention_dim=128, norm_num_groups=32)
+
+
+def make_pair(cfg, mode, seed=0):
+    import phendiff_amd as P
+    from oracle import CustomEmbeddingRef, UNet2DConditionRef
+    torch.manual_seed(seed)
+    r = UNet2DConditionRef(**cfg).eval()
+    emb = CustomEmbeddingRef(2, cfg["cross_attention_dim"])
+    m = P.SDUNet2DConditionModel(compute_dtype=mode, **cfg)
+    m.load_state_dict(r.state_dict())
+    e2 = P.CustomEmbedding(2, cfg["cross_attention_dim"])
+    e2.load_state_dict(emb.state_dict())
+    return r, emb, m.to("cuda:0"), e2.to("cuda:0")
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 5e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32)])
+def test_sd_unet_forward(mode, tol, cfg, size):
+    import phendiff_amd as P
+    from oracle import class_emb_to_encoder_hidden_states as ehs_ref
+    r, emb, m, e2 = make_pair(cfg, mode)
+    g = torch.Generator().manual_seed(2)
+    B = 2
+    x = torch.randn(B, 4, size, size, generator=g)
+    labels = torch.tensor([0, 1])
+    ts = torch.tensor([980, 37])
+    with torch.no_grad():
+        ref = r(x, ts, ehs_ref(emb(labels))).sample
+        ref_uncond = r(x, ts, torch.zeros(B, 77, cfg["cross_attention_dim"])).sample
+    ehs = P.class_emb_to_encoder_hidden_states(e2(labels.cuda()))
+    assert ehs.shape == (B, 77, cfg["cross_attention_dim"])
+    got = m(x.cuda(), ts.cuda(), ehs).sample
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert rel(got, ref) < tol, rel(got, ref)
+    # the call form of the pipeline: unet(sample, t, encoder_hidden_states=..., cross_attention_kwargs=None, return_dict=False)[0],
+    # scalar timestep, unconditional (all-zero) context
+    got_u = m(x.cuda(), ts.cuda(), encoder_hidden_states=torch.zeros_like(ehs), cross_attention_kwargs=None, return_dict=False)[0]
+    assert rel(got_u, ref_uncond) < tol
+    with torch.no_grad():
+        ref_s = r(x, 500, ehs_ref(emb(labels))).sample
+    assert rel(m(x.cuda(), 500, ehs).sample, ref_s) < tol
+
+
+def test_sd_unet_rejects_bad_calls():
+    import phendiff_amd as P
+    _, _, m, _ = make_pair(TINY, "f32")
+    x = torch.randn(2, 4, 16, 16)
+    with pytest.raises(P.PhenDiffHipError):
+        m(x, 1, torch.zeros(2, 77, 96))
+    with pytest.raises(ValueError):
+        m(x.cuda(), 1, torch.zeros(2, 77, 64, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        P.SDUNet2DConditionModel(**dict(TINY, attention_head_dim=(2, 2)))       # head_dim 32
