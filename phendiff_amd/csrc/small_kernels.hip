@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
 // pd_temb: one block per (timestep, class) row.  All weights are passed TRANSPOSED ([in][out]) so that
 // thread `o` streams column o with coalesced loads.
 // ================================================================================================
-__global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a) {
+__global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a, int skip_proj) {
   extern __shared__ float sm[];          // [c0] sincos | [tdim] h1 | [tdim] act
   float* se = sm;
   float* h1 = sm + a.c0;
@@ -53,11 +53,26 @@ __global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a) {
     act[o] = silu_f(acc);
   }
   __syncthreads();
+  if (skip_proj) return;                 // the projections run in temb_proj_kernel (wide models: one block per 256 outputs)
   for (int o = tid; o < a.proj_dim; o += 256) {
     float acc = a.bp[o];
     for (int i = 0; i < a.tdim; ++i) acc += a.wp[(size_t)i * a.proj_dim + o] * act[i];
     a.proj[(size_t)row * a.proj_dim + o] = acc;
   }
+}
+
+// proj[r][o] = bp[o] + sum_i wp[i][o] * silu(emb[r][i]);  grid (rows, proj_dim / 256).  Same summation order as the tail of
+// temb_kernel, so both paths give identical bits.
+__global__ __launch_bounds__(256) void temb_proj_kernel(const pd_temb_args a) {
+  extern __shared__ float act[];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < a.tdim; i += 256) act[i] = silu_f(a.emb[(size_t)row * a.tdim + i]);
+  __syncthreads();
+  const int o = blockIdx.y * 256 + tid;
+  if (o >= a.proj_dim) return;
+  float acc = a.bp[o];
+  for (int i = 0; i < a.tdim; ++i) acc += a.wp[(size_t)i * a.proj_dim + o] * act[i];
+  a.proj[(size_t)row * a.proj_dim + o] = acc;
 }
 
 // ================================================================================================
@@ -318,8 +333,16 @@ extern "C" int pd_temb(const pd_temb_args* a, void* stream) {
   PD_CHECK(!(a->labels && !a->class_table), PD_ERR_ARG, "pd_temb: labels without class table");
   const size_t sm = (size_t)(a->c0 + 2 * a->tdim) * sizeof(float);
   PD_CHECK(sm <= 64 * 1024, PD_ERR_SHAPE, "pd_temb: tdim too large");
-  hipLaunchKernelGGL(temb_kernel, dim3(a->rows), dim3(256), sm, (hipStream_t)stream, *a);
+  // wide projection stacks (the SD UNet: 22 720 outputs of 1280 inputs per row) on few rows: spread the projections over
+  // proj_dim / 256 blocks per row; needs the emb buffer as the hand-over
+  const int split = a->emb != nullptr && (long long)a->proj_dim * a->tdim >= (1 << 22) && a->rows < 1024;
+  hipLaunchKernelGGL(temb_kernel, dim3(a->rows), dim3(256), sm, (hipStream_t)stream, *a, split);
   PD_LAUNCH_CHECK();
+  if (split) {
+    hipLaunchKernelGGL(temb_proj_kernel, dim3(a->rows, (a->proj_dim + 255) / 256), dim3(256), (size_t)a->tdim * sizeof(float),
+                       (hipStream_t)stream, *a);
+    PD_LAUNCH_CHECK();
+  }
   return PD_OK;
 }
 
@@ -358,13 +381,14 @@ extern "C" int pd_gn_stats(const pd_gn_stats_args* a, void* stream) {
 extern "C" int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_gn_finalize: null args");
   const int C = a->C0 + a->C1;
-  PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C1 >= 0 && C <= 1024 && a->T0 > 0, PD_ERR_SHAPE, "pd_gn_finalize: bad shape (C=%d)", C);
+  PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C1 >= 0 && C <= 16384 && a->T0 > 0, PD_ERR_SHAPE, "pd_gn_finalize: bad shape (C=%d)", C);
   PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0, PD_ERR_SHAPE, "pd_gn_finalize: groups=%d C=%d", a->groups, C);
   PD_CHECK(a->stats0 && a->gamma && a->beta && a->scale && a->shift, PD_ERR_ARG, "pd_gn_finalize: null pointer");
   PD_CHECK((a->C1 == 0) == (a->stats1 == nullptr) && (a->C1 == 0 || a->T1 > 0), PD_ERR_ARG, "pd_gn_finalize: stats1/C1 mismatch");
   PD_CHECK((a->mean == nullptr) == (a->rstd == nullptr), PD_ERR_ARG, "pd_gn_finalize: mean/rstd must be given together");
   const int gs = C / a->groups;
-  const int CB = (96 % gs == 0) ? 96 : C;          // channel block of whole groups
+  PD_CHECK(gs <= 1024, PD_ERR_SHAPE, "pd_gn_finalize: %d channels per group", gs);
+  const int CB = gs * (gs <= 96 ? 96 / gs : 1);     // channel block of whole groups (<= 1024 channels, <= 64 groups)
   hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->B, (C + CB - 1) / CB), dim3(1024), 0, (hipStream_t)stream, *a, CB);
   PD_LAUNCH_CHECK();
   return PD_OK;

@@ -349,6 +349,7 @@ class SDUNetPlan(UNetPlan):
                                     w1=w.w1T.data_ptr(), b1=w.b1.data_ptr(), w2=w.w2T.data_ptr(), b2=w.b2.data_ptr(),
                                     class_table=None, wp=w.wpT.data_ptr(), bp=w.bp.data_ptr())
         self.temb_table = self._f32(B, w.proj_dim)
+        self.temb_emb = self._f32(B, m.time_embed_dim)
         self.ehs = torch.empty((B, 1, self.tokens, c.cross_attention_dim), dtype=self.tdt, device=self.device)
         self.bufs.append(self.ehs)
         # latents NCHW fp32 -> NHWC (32 channels, zero padded), then a plain 3x3 conv
@@ -389,7 +390,11 @@ class SDUNetPlan(UNetPlan):
     def forward(self, sample, ts, ehs, out, stream):
         """fp32 NCHW latents + (B,) timesteps + (B, tokens, D) encoder_hidden_states -> fp32 NCHW prediction."""
         self.ehs.view(self.B, self.tokens, -1).copy_(ehs)             # dtype cast (plumbing); stays on the device
-        self.temb_rows(ts, None, None, stream, out=self.temb_table)
+        a = self.temb_args
+        a.rows = self.B
+        a.timesteps, a.labels, a.class_emb = ts.data_ptr(), None, None
+        a.emb, a.proj = self.temb_emb.data_ptr(), self.temb_table.data_ptr()     # emb given: wide projections run split
+        L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
         self.run(sample.data_ptr(), self.temb_table.data_ptr(), out.data_ptr(), stream)
         self.keepalive = (sample, ts, ehs, out)
 
