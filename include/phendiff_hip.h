@@ -401,6 +401,26 @@ typedef struct {
 } pd_attn_d64_args;
 int pd_attn_d64(const pd_attn_d64_args* a, void* stream);
 
+/* pd_attn_wide: softmax(q k^T * scale) v with ONE wide head per D channels, D in {128, 256, 512} -- the mid-block attention of
+ * the SD VAE (diffusers AutoencoderKL: Encoder/Decoder.mid_block.attentions[0], a single head over all 512 channels;
+ * vae.encode / vae.decode at custom_pipeline_stable_diffusion_img2img.py:431,709-711).  Operand addressing as pd_attn_d64
+ * (token-major with strides; channel = head*D + d).  scale = D^-1/2 for diffusers' Attention. */
+typedef struct {
+  int dtype;
+  int B, heads, D, Nq, Nkv;
+  float scale;
+  const void* q; int q_stride;
+  const void* k; const void* v; int kv_stride;
+  void* out; int out_stride;
+} pd_attn_wide_args;
+int pd_attn_wide(const pd_attn_wide_args* a, void* stream);
+
+/* pd_latent_sample: AutoencoderKL.encode(x).latent_dist.sample(generator) (or .mode() when noise = NULL) times the
+ * pipeline's scaling_factor (custom_pipeline_stable_diffusion_img2img.py:431-433, utils_Img2Img.py:833-836):
+ *   out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise),  moments = [B][2C][HW] fp32 = [mean | logvar]. */
+typedef struct { int B, C, HW; float scale; const float* moments; const float* noise; float* out; } pd_latent_sample_args;
+int pd_latent_sample(const pd_latent_sample_args* a, void* stream);
+
 /* pd_layernorm: y[r][c] = (x[r][c] - mean_r) * rstd_r * gamma[c] + beta[c]  (nn.LayerNorm(C), biased variance) */
 typedef struct { int dtype; long long rows; int C; float eps; const void* x; const float* gamma; const float* beta; void* y; } pd_layernorm_args;
 int pd_layernorm(const pd_layernorm_args* a, void* stream);

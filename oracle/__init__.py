@@ -23,6 +23,7 @@ from .schedulers_ref import DDIMSchedulerRef, DDIMInverseSchedulerRef  # noqa: F
 from .unet_ref import CondUNet2DRef, UNET_CONFIGS  # noqa: F401
 from .sd_unet_ref import (  # noqa: F401
     UNet2DConditionRef, CustomEmbeddingRef, SD21_UNET_CONFIG, class_emb_to_encoder_hidden_states)
+from .vae_ref import AutoencoderKLRef, SD_VAE_CONFIG, vae_preprocess_ref, vae_postprocess_ref  # noqa: F401
 from .pipeline_ref import (  # noqa: F401
     ConditionalDDIMPipelineRef,
     inversion_ref,

@@ -117,6 +117,16 @@ class AttnD64Args(C.Structure):
                 ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp), ("out_stride", C.c_int)]
 
 
+class AttnWideArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int),
+                ("scale", C.c_float), ("q", vp), ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp),
+                ("out_stride", C.c_int)]
+
+
+class LatentSampleArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("scale", C.c_float), ("moments", vp), ("noise", vp), ("out", vp)]
+
+
 class LayerNormArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("C", C.c_int), ("eps", C.c_float), ("x", vp), ("gamma", vp),
                 ("beta", vp), ("y", vp)]
@@ -199,6 +209,8 @@ SYMBOLS = {
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
     "pd_attn_d64": (C.c_int, [C.POINTER(AttnD64Args), vp]),
+    "pd_attn_wide": (C.c_int, [C.POINTER(AttnWideArgs), vp]),
+    "pd_latent_sample": (C.c_int, [C.POINTER(LatentSampleArgs), vp]),
     "pd_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), vp]),
     "pd_geglu": (C.c_int, [C.POINTER(GegluArgs), vp]),
     "pd_lp_guidance": (C.c_int, [C.POINTER(LpGuidanceArgs), vp]),

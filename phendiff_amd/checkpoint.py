@@ -38,6 +38,20 @@ def _load_weights(folder: str) -> dict:
     return torch.load(os.path.join(folder, "diffusion_pytorch_model.bin"), map_location="cpu", weights_only=True)
 
 
+def load_weights_file(folder: str) -> dict:
+    """``diffusion_pytorch_model.{safetensors,bin}`` of a diffusers model folder, attention keys in their in-memory names."""
+    return remap_deprecated_attention_keys(_load_weights(folder))
+
+
+def save_weights_file(state_dict: dict, folder: str, safe_serialization: bool = True) -> None:
+    sd = {k: v.detach().cpu().contiguous() for k, v in state_dict.items()}
+    if safe_serialization:
+        from safetensors.torch import save_file
+        save_file(sd, os.path.join(folder, "diffusion_pytorch_model.safetensors"))
+    else:
+        torch.save(sd, os.path.join(folder, "diffusion_pytorch_model.bin"))
+
+
 def save_unet(unet, folder: str, safe_serialization: bool = True) -> None:
     os.makedirs(folder, exist_ok=True)
     cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(unet.config).items()}

@@ -7,7 +7,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p "$HERE/build"
 pids=()
-for f in conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels; do
+SRCS="conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels vae_kernels"
+for f in $SRCS; do
   if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_stage.h" -nt "$HERE/build/$f.o" ] \
      || [ "$HERE/../../include/phendiff_hip.h" -nt "$HERE/build/$f.o" ]; then
     X=""
@@ -18,5 +19,7 @@ for f in conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad s
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/build/conv_igemm.o" "$HERE/build/attn_d8.o" "$HERE/build/small_kernels.o" "$HERE/build/train_kernels.o" "$HERE/build/backward_kernels.o" "$HERE/build/wgrad.o" "$HERE/build/sd_kernels.o"
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS $HERE/build/$f.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
 echo "built $OUT"
