@@ -24,6 +24,8 @@ from .unet_ref import CondUNet2DRef, UNET_CONFIGS  # noqa: F401
 from .sd_unet_ref import (  # noqa: F401
     UNet2DConditionRef, CustomEmbeddingRef, SD21_UNET_CONFIG, class_emb_to_encoder_hidden_states)
 from .vae_ref import AutoencoderKLRef, SD_VAE_CONFIG, vae_preprocess_ref, vae_postprocess_ref  # noqa: F401
+from .sd_pipeline_ref import (  # noqa: F401
+    SDImg2ImgPipelineRef, hack_class_embedding_ref, encode_to_latents_ref, sd_inversion_ref, sd_ddib_ref, sd_cfg_forward_start_ref)
 from .pipeline_ref import (  # noqa: F401
     ConditionalDDIMPipelineRef,
     inversion_ref,

@@ -35,15 +35,50 @@ def inversion(pipe, input_images: torch.Tensor, class_labels: torch.Tensor, num_
 
 
 @torch.no_grad()
+def encode_to_latents(pipe, images: torch.Tensor, generator=None) -> torch.Tensor:
+    """``_encode_to_latents`` (utils_Img2Img.py:827-836): ``vae.encode(x).latent_dist.sample() * scaling_factor`` (the scale
+    is folded into the sampling kernel)."""
+    return pipe.vae.encode(images).latent_dist.sample(generator, scale=float(pipe.vae.config.scaling_factor))
+
+
+@torch.no_grad()
+def decode_to_images(pipe, latents: torch.Tensor) -> torch.Tensor:
+    """``_decode_to_images`` (utils_Img2Img.py:839-847)."""
+    return pipe.vae.decode(latents / pipe.vae.config.scaling_factor, return_dict=False)[0]
+
+
+@torch.no_grad()
+def LDM_preprocess(pipe, images: torch.Tensor, class_labels_seq=None, generator=None):
+    """``_LDM_preprocess`` (utils_Img2Img.py:803-824): images -> scaled latents, each label tensor -> (B, 77, D) embedding."""
+    from .sd_pipeline import hack_class_embedding
+    latents = encode_to_latents(pipe, images, generator)
+    if class_labels_seq is None:
+        return latents, None
+    embeds = [hack_class_embedding(pipe._encode_class(class_labels=cl, device=latents.device, do_classifier_free_guidance=False))
+              for cl in class_labels_seq]
+    return latents, embeds
+
+
+@torch.no_grad()
 def ddib(pipe, clean_images, orig_class_labels, target_class_labels, num_inference_steps: int,
-         process_idx: Optional[int] = None, variant: str = "0.18.2", output_type: str = "numpy"):
-    """``_ddib`` for :class:`ConditionalDDIMPipeline` (utils_Img2Img.py:566-599)."""
-    if not isinstance(pipe, ConditionalDDIMPipeline):
-        raise NotImplementedError("only the ConditionalDDIMPipeline branch is implemented")
-    inverted_gauss = inversion(pipe, clean_images, orig_class_labels, num_inference_steps, process_idx, variant)
-    return pipe(class_labels=target_class_labels, w=0, num_inference_steps=num_inference_steps,
-                start_image=inverted_gauss, add_forward_noise_to_image=False, frac_diffusion_skipped=0,
-                output_type=output_type).images
+         process_idx: Optional[int] = None, variant: str = "0.18.2", output_type: str = "numpy", generator=None):
+    """``_ddib`` (utils_Img2Img.py:566-612), both pipeline branches.  ``generator`` seeds the VAE posterior draw of the
+    latent-diffusion branch (the reference draws it unseeded)."""
+    from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline
+    if isinstance(pipe, CustomStableDiffusionImg2ImgPipeline):
+        clean_images, [orig_class_cond] = LDM_preprocess(pipe, clean_images, [orig_class_labels], generator)
+    elif isinstance(pipe, ConditionalDDIMPipeline):
+        orig_class_cond = orig_class_labels
+    else:
+        raise NotImplementedError(type(pipe))
+    inverted_gauss = inversion(pipe, clean_images, orig_class_cond, num_inference_steps, process_idx, variant)
+    if isinstance(pipe, ConditionalDDIMPipeline):
+        return pipe(class_labels=target_class_labels, w=0, num_inference_steps=num_inference_steps,
+                    start_image=inverted_gauss, add_forward_noise_to_image=False, frac_diffusion_skipped=0,
+                    output_type=output_type).images
+    return pipe(image=inverted_gauss, class_labels=target_class_labels, strength=1, add_forward_noise_to_image=False,
+                num_inference_steps=num_inference_steps, guidance_scale=0,     # guidance_scale <= 1.0 disables guidance
+                output_type={"numpy": "np"}.get(output_type, output_type))
 
 
 @torch.no_grad()
@@ -56,9 +91,14 @@ def inverted_regeneration(pipe, clean_images, orig_class_labels, num_inference_s
 def classifier_free_guidance_forward_start(pipe, clean_images, target_class_labels, guidance_scale: float,
                                            frac_diffusion_skipped: float, num_inference_steps: int, generator=None,
                                            output_type: str = "numpy"):
-    """``_classifier_free_guidance_forward_start`` (utils_Img2Img.py:615-648), ConditionalDDIMPipeline branch: noise
+    """``_classifier_free_guidance_forward_start`` (utils_Img2Img.py:615-648), both pipeline branches: noise
     the image up to ``(1 - frac_diffusion_skipped)`` of the trajectory, then denoise under the target class with
     classifier-free guidance."""
+    from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline
+    if isinstance(pipe, CustomStableDiffusionImg2ImgPipeline):       # :638-645: strength = frac_diffusion_skipped
+        return pipe(image=clean_images, class_labels=target_class_labels, strength=frac_diffusion_skipped,
+                    num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, generator=generator,
+                    output_type={"numpy": "np"}.get(output_type, output_type))
     return pipe(class_labels=target_class_labels, w=guidance_scale, num_inference_steps=num_inference_steps,
                 start_image=clean_images, frac_diffusion_skipped=frac_diffusion_skipped, generator=generator,
                 output_type=output_type).images

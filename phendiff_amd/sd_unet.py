@@ -169,6 +169,36 @@ class SDUNet2DConditionModel(nn.Module):
         self._plans, self._weights = {}, None
         self.requires_grad_(False)
 
+    @classmethod
+    def from_config(cls, config, compute_dtype="bf16", **overrides):
+        d = dict(config) if isinstance(config, dict) else dict(vars(config))
+        d = {k: v for k, v in d.items() if k in _SD_DEFAULTS}
+        d.update(overrides)
+        return cls(compute_dtype=compute_dtype, **d)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, compute_dtype="bf16", **overrides):
+        """diffusers folder layout (``config.json`` + ``diffusion_pytorch_model.{safetensors,bin}``)."""
+        import json
+        import os
+        from .checkpoint import load_weights_file
+        folder = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(folder, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        m = cls.from_config(cfg, compute_dtype=compute_dtype, **overrides)
+        m.load_state_dict(load_weights_file(folder))
+        return m
+
+    def save_pretrained(self, path, safe_serialization=True):
+        import json
+        import os
+        from .checkpoint import save_weights_file
+        os.makedirs(path, exist_ok=True)
+        cfg = dict(vars(self.config), _class_name="UNet2DConditionModel", _diffusers_version="0.18.2")
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2)
+        save_weights_file(self.state_dict(), path, safe_serialization)
+
     @property
     def dtype(self):
         return self.conv_in.weight.dtype

@@ -32,6 +32,39 @@ def synth_batch(B, size, seed=1234):
     return x, labels
 
 
+SD_TINY_UNET = dict(in_channels=4, out_channels=4, block_out_channels=(64, 128), layers_per_block=1,
+                    down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+                    attention_head_dim=(1, 2), cross_attention_dim=96, norm_num_groups=32)
+SD_TINY_VAE = dict(block_out_channels=(32, 64), layers_per_block=1)
+SD_SCHED = dict(beta_end=0.012, beta_schedule="scaled_linear", beta_start=0.00085, clip_sample=False, clip_sample_range=1.0,
+                num_train_timesteps=1000, prediction_type="v_prediction", rescale_betas_zero_snr=False,
+                set_alpha_to_one=False, steps_offset=1, thresholding=False, timestep_spacing="leading")
+
+
+def sd_tiny_pipe():
+    """Tiny latent-diffusion stack (same block types as SD-2.1; construction order fixes the seeded weights)."""
+    from oracle import AutoencoderKLRef, CustomEmbeddingRef, SDImg2ImgPipelineRef, UNet2DConditionRef
+    torch.manual_seed(0)
+    unet = UNet2DConditionRef(**SD_TINY_UNET).eval()
+    vae = AutoencoderKLRef(**SD_TINY_VAE).eval()
+    emb = CustomEmbeddingRef(2, SD_TINY_UNET["cross_attention_dim"])
+    return SDImg2ImgPipelineRef(vae, unet, DDIMSchedulerRef(**SD_SCHED), emb)
+
+
+def main_sd():
+    """custom_pipeline_stable_diffusion_img2img: DDIB (VAE encode -> invert -> class swap -> denoise -> decode) and the
+    CFG forward-start transfer, 32x32 images (16x16 latents), S = 4."""
+    from oracle import sd_cfg_forward_start_ref, sd_ddib_ref
+    pipe = sd_tiny_pipe()
+    x, labels = synth_batch(4, 32)
+    out, inverted, latents = sd_ddib_ref(pipe, x, labels, 1 - labels, 4, generator=torch.Generator().manual_seed(11))
+    cfg_out, cfg_lat = sd_cfg_forward_start_ref(pipe, x, 1 - labels, 3.0, 0.5, 4, generator=torch.Generator().manual_seed(12),
+                                                output_type="np+latent")
+    np.savez_compressed(os.path.join(HERE, "sd_tiny_32_s4.npz"), images=x.numpy(), labels=labels.numpy(), latents=latents.numpy(),
+                        inverted=inverted.numpy(), ddib_out=out, cfg_out=cfg_out, cfg_latents=cfg_lat.numpy())
+    print("wrote sd_tiny_32_s4.npz")
+
+
 def main():
     torch.manual_seed(0)
     unet = CondUNet2DRef(**dict(UNET_CONFIGS["super_small"], sample_size=32)).eval()
@@ -58,4 +91,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--sd" in sys.argv:
+        main_sd()
+    else:
+        main()
+        main_sd()

@@ -1,0 +1,112 @@
+"""CustomStableDiffusionImg2ImgPipeline on MI355X (SD UNet + VAE + DDIM on the HIP engine) against the CPU oracle and the
+committed golden vectors: DDIB through the latent space, CFG forward-start transfer, call-surface options."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_unet_ddib import rel
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLDEN)
+from make_golden import SD_SCHED, SD_TINY_UNET, SD_TINY_VAE, sd_tiny_pipe  # noqa: E402
+
+
+def make_pipe(mode):
+    import phendiff_amd as P
+    ref = sd_tiny_pipe()
+    unet = P.SDUNet2DConditionModel(compute_dtype=mode, **SD_TINY_UNET)
+    unet.load_state_dict(ref.unet.state_dict())
+    vae = P.AutoencoderKL(compute_dtype=mode, **SD_TINY_VAE)
+    vae.load_state_dict(ref.vae.state_dict())
+    emb = P.CustomEmbedding(2, SD_TINY_UNET["cross_attention_dim"])
+    emb.load_state_dict(ref.class_embedding.state_dict())
+    pipe = P.CustomStableDiffusionImg2ImgPipeline(vae.to("cuda:0"), unet.to("cuda:0"), P.DDIMScheduler(**SD_SCHED), emb.to("cuda:0"))
+    return ref, pipe
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+def test_sd_ddib_matches_golden(mode, tol):
+    import phendiff_amd as P
+    d = np.load(os.path.join(GOLDEN, "sd_tiny_32_s4.npz"))
+    _, pipe = make_pipe(mode)
+    x, labels = torch.from_numpy(d["images"]).cuda(), torch.from_numpy(d["labels"]).cuda()
+    # the pieces, as _ddib strings them together (utils_Img2Img.py:575-607)
+    lat, [cond] = P.LDM_preprocess(pipe, x, [labels], generator=torch.Generator().manual_seed(11))
+    assert cond.shape == (4, 77, 96)
+    assert rel(lat, torch.from_numpy(d["latents"])) < tol
+    inv = P.inversion(pipe, lat, cond, 4)
+    assert rel(inv, torch.from_numpy(d["inverted"])) < tol
+    out = P.ddib(pipe, x, labels, 1 - labels, 4, generator=torch.Generator().manual_seed(11))
+    assert isinstance(out, np.ndarray) and out.shape == (4, 32, 32, 3)
+    assert np.linalg.norm(out - d["ddib_out"]) / np.linalg.norm(d["ddib_out"]) < tol
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+def test_sd_cfg_forward_start_matches_golden(mode, tol):
+    import phendiff_amd as P
+    d = np.load(os.path.join(GOLDEN, "sd_tiny_32_s4.npz"))
+    _, pipe = make_pipe(mode)
+    x, labels = torch.from_numpy(d["images"]).cuda(), torch.from_numpy(d["labels"]).cuda()
+    out, lat = pipe(image=x, class_labels=1 - labels, strength=0.5, num_inference_steps=4, guidance_scale=3.0,
+                    generator=torch.Generator().manual_seed(12), output_type="np+latent")
+    assert rel(lat, torch.from_numpy(d["cfg_latents"])) < tol
+    assert np.linalg.norm(out - d["cfg_out"]) / np.linalg.norm(d["cfg_out"]) < tol
+    out2 = P.classifier_free_guidance_forward_start(pipe, x, 1 - labels, 3.0, 0.5, 4, generator=torch.Generator().manual_seed(12))
+    assert np.array_equal(out2, out)
+
+
+def test_sd_pipeline_call_surface():
+    import phendiff_amd as P
+    ref, pipe = make_pipe("f32")
+    assert pipe.vae_scale_factor == 2 and set(pipe.components) == {"vae", "unet", "scheduler", "class_embedding"}
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(2, 4, 8, 8, generator=g)
+    kw = dict(strength=1, add_forward_noise_to_image=False, num_inference_steps=3)
+    want = ref(image=lat, class_labels=[1, 0], guidance_scale=None, output_type="latent", **kw)
+    a = pipe(image=lat.cuda(), class_labels=[1, 0], guidance_scale=None, output_type="latent", **kw)
+    assert rel(a, want) < 2e-4
+    b = pipe(image=lat.cuda(), class_labels=torch.tensor([1, 0]).cuda(), guidance_scale=1.0, output_type="latent", **kw)
+    assert torch.equal(a, b)
+    # per-sample guidance weights (1-D tensor), pre-computed embeddings, pt / pil outputs
+    w = torch.tensor([1.5, 4.0])
+    emb = ref.class_embedding(torch.tensor([1, 0])).detach()
+    want = ref(image=lat, class_labels_embeds=emb, guidance_scale=w, output_type="pt", **kw)
+    got = pipe(image=lat.cuda(), class_labels_embeds=emb.cuda(), guidance_scale=w.cuda(), output_type="pt", **kw)
+    assert got.shape == (2, 3, 16, 16) and rel(got, want) < 2e-4
+    pil = pipe(image=lat.cuda(), class_labels=[1, 0], output_type="pil", **kw)
+    assert len(pil) == 2 and pil[0].size == (16, 16)
+    # int label, generation from noise (image=None, latent_shape), strength 0 returns the latents untouched
+    one = pipe(latent_shape=(1, 4, 8, 8), class_labels=1, strength=1, num_inference_steps=2, output_type="latent")
+    assert one.shape == (1, 4, 8, 8) and bool(torch.isfinite(one).all())
+    z = pipe(image=lat.cuda(), class_labels=[1, 0], strength=0, add_forward_noise_to_image=False, num_inference_steps=4, output_type="latent")
+    assert torch.equal(z.cpu(), lat)
+    # callback protocol
+    seen = []
+    pipe(image=lat.cuda(), class_labels=[1, 0], output_type="latent", callback=lambda i, t, l: seen.append((i, int(t))), **kw)
+    assert [s[0] for s in seen] == [0, 1, 2]
+    # input checks of the reference
+    with pytest.raises(ValueError):
+        pipe(class_labels=[1])
+    with pytest.raises(ValueError):
+        pipe(image=lat.cuda(), class_labels=[1, 0], strength=1.5)
+    with pytest.raises(ValueError):
+        pipe(image=lat.cuda(), class_labels=[1, 0], class_labels_embeds=emb.cuda())
+    with pytest.raises(ValueError):
+        pipe(image=lat.cuda())
+
+
+def test_sd_pipeline_save_and_reload(tmp_path):
+    import phendiff_amd as P
+    _, pipe = make_pipe("f32")
+    pipe.save_pretrained(str(tmp_path / "sd"))
+    for sub in ("vae", "unet", "scheduler", "class_embedding"):
+        assert (tmp_path / "sd" / sub).is_dir()
+    p2 = P.CustomStableDiffusionImg2ImgPipeline.from_pretrained(str(tmp_path / "sd"), compute_dtype="f32").to("cuda:0")
+    lat = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(2)).cuda()
+    kw = dict(image=lat, class_labels=[0, 1], strength=1, add_forward_noise_to_image=False, num_inference_steps=2, output_type="np")
+    assert np.array_equal(pipe(**kw), p2(**kw))
