@@ -398,6 +398,7 @@ typedef struct {
   const void* q; int q_stride;
   const void* k; const void* v; int kv_stride;
   void* out; int out_stride;
+  float* lse;   /* optional out [B][heads][Nq]: log2-domain log-sum-exp of the scaled scores (kept for pd_attn_d64_bwd), or NULL */
 } pd_attn_d64_args;
 int pd_attn_d64(const pd_attn_d64_args* a, void* stream);
 
@@ -428,6 +429,41 @@ int pd_layernorm(const pd_layernorm_args* a, void* stream);
 /* pd_geglu: y[r][i] = x[r][i] * gelu(x[r][inner + i])   (diffusers GEGLU after its Linear(C, 2*inner); exact erf GELU) */
 typedef struct { int dtype; long long rows; int inner; const void* x; void* y; } pd_geglu_args;
 int pd_geglu(const pd_geglu_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the Transformer2DModel blocks: what autograd runs under accelerator.backward(loss) (utils_training.py:436)
+ * when _SD_prediction_wrapper (utils_training.py:459-496) trains the SD UNet.  Linear layers reuse pd_conv (input gradient,
+ * transposed weights) and pd_conv_wgrad (ksize 1).
+ *
+ * pd_attn_d64_bwd: gradient of pd_attn_d64; P is recomputed from the forward's lse.  o / dout: the forward's output and the
+ * gradient w.r.t. it, [B][Nq][o_stride]; delta: workspace [B][heads][Nq]; dq: [B][Nq][dq_stride], dk / dv: [B][Nkv][dkv_stride]
+ * (channel = head*64 + d, so they may be slices of one fused projection's output gradient). */
+typedef struct {
+  int dtype;
+  int B, heads, Nq, Nkv;
+  const void* q; int q_stride;
+  const void* k; const void* v; int kv_stride;
+  const void* o; const void* dout; int o_stride;
+  const float* lse; float* delta;
+  void* dq; int dq_stride;
+  void* dk; void* dv; int dkv_stride;
+} pd_attn_d64_bwd_args;
+int pd_attn_d64_bwd(const pd_attn_d64_bwd_args* a, void* stream);
+
+/* pd_layernorm_bwd: dx = LayerNorm'(x; gamma)(dy) [+ res: the gradient arriving over the skip connection around the
+ * normalised branch]; dgamma += sum_rows dy*xhat, dbeta += sum_rows dy (both or neither; `partial` is a workspace of
+ * pd_layernorm_bwd_blocks(rows) * 2 * C floats, summed in a fixed order). */
+typedef struct {
+  int dtype; long long rows; int C; float eps;
+  const void* x; const void* dy; const float* gamma; const void* res;
+  void* dx; float* dgamma; float* dbeta; float* partial;
+} pd_layernorm_bwd_args;
+int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream);
+int pd_layernorm_bwd_blocks(long long rows);
+
+/* pd_geglu_bwd: x = [h | g] (the forward's input, [rows][2*inner]), dy [rows][inner] -> dx = [dy*gelu(g) | dy*h*gelu'(g)] */
+typedef struct { int dtype; long long rows; int inner; const void* x; const void* dy; void* dx; } pd_geglu_bwd_args;
+int pd_geglu_bwd(const pd_geglu_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient-guided transfer (_custom_guided_generation, utils_Img2Img.py:699-760).

@@ -114,13 +114,28 @@ class AttnArgs(C.Structure):
 
 class AttnD64Args(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int), ("q", vp),
-                ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp), ("out_stride", C.c_int)]
+                ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp), ("out_stride", C.c_int), ("lse", vp)]
 
 
 class AttnWideArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int),
                 ("scale", C.c_float), ("q", vp), ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp),
                 ("out_stride", C.c_int)]
+
+
+class AttnD64BwdArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int), ("q", vp),
+                ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("o", vp), ("dout", vp), ("o_stride", C.c_int),
+                ("lse", vp), ("delta", vp), ("dq", vp), ("dq_stride", C.c_int), ("dk", vp), ("dv", vp), ("dkv_stride", C.c_int)]
+
+
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("C", C.c_int), ("eps", C.c_float), ("x", vp), ("dy", vp), ("gamma", vp),
+                ("res", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp), ("partial", vp)]
+
+
+class GegluBwdArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("inner", C.c_int), ("x", vp), ("dy", vp), ("dx", vp)]
 
 
 class LatentSampleArgs(C.Structure):
@@ -211,6 +226,10 @@ SYMBOLS = {
     "pd_attn_d64": (C.c_int, [C.POINTER(AttnD64Args), vp]),
     "pd_attn_wide": (C.c_int, [C.POINTER(AttnWideArgs), vp]),
     "pd_latent_sample": (C.c_int, [C.POINTER(LatentSampleArgs), vp]),
+    "pd_attn_d64_bwd": (C.c_int, [C.POINTER(AttnD64BwdArgs), vp]),
+    "pd_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdArgs), vp]),
+    "pd_layernorm_bwd_blocks": (C.c_int, [C.c_longlong]),
+    "pd_geglu_bwd": (C.c_int, [C.POINTER(GegluBwdArgs), vp]),
     "pd_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), vp]),
     "pd_geglu": (C.c_int, [C.POINTER(GegluArgs), vp]),
     "pd_lp_guidance": (C.c_int, [C.POINTER(LpGuidanceArgs), vp]),

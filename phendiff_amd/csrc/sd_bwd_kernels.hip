@@ -1,0 +1,492 @@
+// Backward kernels of the Stable-Diffusion tier (what autograd runs under `accelerator.backward(loss)`, utils_training.py:436,
+// over diffusers' Transformer2DModel blocks when _SD_prediction_wrapper trains the SD UNet, utils_training.py:459-496):
+//   pd_attn_d64_bwd  : gradient of softmax(q k^T / 8) v, head_dim 64 (self attention and the 77-token cross attention)
+//   pd_layernorm_bwd : gradient of nn.LayerNorm(C) (+ the skip-connection gradient folded into dx)
+//   pd_geglu_bwd     : gradient of the GEGLU gate h * gelu(g)
+#include "pd_common.h"
+#include "pd_stage.h"
+#include "pd_d64.h"
+
+namespace pd {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention backward, head_dim 64.  P is recomputed from the forward's log-sum-exp (log2 domain); two kernels so that every
+// reduction is lane-local and no atomics are needed (same split as pd_attn_d8_bwd):
+//   dQ kernel    : query on the lane.  Per 32-key sub-tile  S^T = K.Q^T,  dP^T = V.dO^T  (K / V rows from LDS, Q^T / dO^T
+//                  fragments in registers),  dS^T = P^T o (dP^T - delta)  lane-local,  dQ^T += K^T . dS^T  with K^T a
+//                  transposed LDS read of the same K tile and dS^T packed straight from the accumulator registers.
+//   dK/dV kernel : key on the lane.  Per 32-query sub-tile  S = Q.K^T,  dP = dO.V^T  (Q / dO rows from LDS, K^T / V^T
+//                  fragments in registers),  dV^T += dO^T . P,  dK^T += Q^T . dS  (transposed reads of the dO / Q tiles).
+// delta[i] = sum_d o[i][d] * do[i][d] comes from a small pre-pass.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_d64_delta_kernel(const pd_attn_d64_bwd_args a) {
+  using E = Elem<T>;
+  const size_t total = (size_t)a.B * a.Nq * a.heads * 8;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  size_t row = 0; int head = 0;
+  if (idx < total) {
+    const int sub = (int)(idx & 7);
+    head = (int)((idx >> 3) % a.heads);
+    row = idx / ((size_t)a.heads * 8);                 // b * Nq + i
+    float o[8], d[8];
+    E::unpack(E::load((const T*)a.o + row * a.o_stride + head * 64 + sub * 8), o);
+    E::unpack(E::load((const T*)a.dout + row * a.o_stride + head * 64 + sub * 8), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += o[j] * d[j];
+  }
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  if (idx < total && (idx & 7) == 0) {
+    const size_t b = row / a.Nq, i = row - b * a.Nq;
+    a.delta[(b * a.heads + head) * a.Nq + i] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_args a) {
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  using X = D64<T>;
+  constexpr int KT = 64, VP = X::VP, ES = E::BYTES;
+  constexpr int TB = KT * VP;                          // bytes of one [64][64] tile
+  constexpr int PIECES = KT * 64 / 8 / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][K tile | V tile]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nqb = (a.Nq + 127) / 128;
+  const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.heads, b = blockIdx.x / (nqb * a.heads);
+  const T* qp = (const T*)a.q + (size_t)b * a.Nq * a.q_stride + head * 64;
+  const T* kp = (const T*)a.k + (size_t)b * a.Nkv * a.kv_stride + head * 64;
+  const T* vp = (const T*)a.v + (size_t)b * a.Nkv * a.kv_stride + head * 64;
+  const T* dop = (const T*)a.dout + (size_t)b * a.Nq * a.o_stride + head * 64;
+
+  const int query = qb * 128 + wave * 32 + r, qc = min(query, a.Nq - 1);
+  const float qscale = 0.125f * 1.4426950408889634f;
+  Frag qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    float v[8];
+    E::unpack(E::load(qp + (size_t)qc * a.q_stride + 16 * ks + 8 * h), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= qscale;
+    qf[ks] = E::pack(v);
+    dof[ks] = E::load(dop + (size_t)qc * a.o_stride + 16 * ks + 8 * h);
+  }
+  const size_t stat = ((size_t)b * a.heads + head) * a.Nq + qc;
+  const float lse = a.lse[stat], delta = a.delta[stat];
+  f32x16 dq0 = (f32x16)(0.f), dq1 = (f32x16)(0.f);
+
+  Frag stk[PIECES], stv[PIECES];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + 256 * i, key = k0 + (pc >> 3), sub = pc & 7;
+      if (key < a.Nkv) {
+        stk[i] = E::load(kp + (size_t)key * a.kv_stride + sub * 8);
+        stv[i] = E::load(vp + (size_t)key * a.kv_stride + sub * 8);
+      } else { stk[i] = E::zero(); stv[i] = E::zero(); }
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* kb = lds + buf * 2 * TB;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + 256 * i, row = pc >> 3, sub = pc & 7;
+      E::store(kb + row * VP + sub * 8 * ES, stk[i]);
+      E::store(kb + TB + row * VP + sub * 8 * ES, stv[i]);
+    }
+  };
+  const int row_lane = r * VP + 8 * h * ES;            // row fragment: row r, d = 16 ks + 8 h + (0..7)
+  const int t_lane = X::vt_lane_off(lane);
+
+  issue(0);
+  commit(0);
+  if (KT < a.Nkv) issue(KT);
+  __syncthreads();
+  for (int k0 = 0, cur = 0; k0 < a.Nkv; k0 += KT, cur ^= 1) {
+    const unsigned char* kb = lds + cur * 2 * TB;
+    const unsigned char* vb = kb + TB;
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      if (k0 + sub * 32 < a.Nkv) {                     // workgroup-uniform
+        f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = E::mma(E::load(kb + row_lane + sub * 32 * VP + ks * 16 * ES), qf[ks], s);
+          dp = E::mma(E::load(vb + row_lane + sub * 32 * VP + ks * 16 * ES), dof[ks], dp);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool valid = k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < a.Nkv;
+          const float p = valid ? __builtin_amdgcn_exp2f(s[i] - lse) : 0.f;
+          s[i] = p * (dp[i] - delta);                  // dS^T
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const Frag df = X::pack_p(s, st);
+          const unsigned char* ks_ = kb + t_lane + (sub * 32 + 16 * st) * VP;
+          dq0 = E::mma(X::load_vt(ks_), df, dq0);
+          dq1 = E::mma(X::load_vt(ks_ + 32 * ES), df, dq1);
+        }
+      }
+    }
+    if (k0 + KT < a.Nkv) {
+      commit(cur ^ 1);
+      if (k0 + 2 * KT < a.Nkv) issue(k0 + 2 * KT);
+    }
+    __syncthreads();
+  }
+  if (query < a.Nq) {
+    T* dst = (T*)a.dq + ((size_t)b * a.Nq + query) * a.dq_stride + head * 64 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      store4(dst + 8 * g, dq0[4 * g] * 0.125f, dq0[4 * g + 1] * 0.125f, dq0[4 * g + 2] * 0.125f, dq0[4 * g + 3] * 0.125f);
+      store4(dst + 32 + 8 * g, dq1[4 * g] * 0.125f, dq1[4 * g + 1] * 0.125f, dq1[4 * g + 2] * 0.125f, dq1[4 * g + 3] * 0.125f);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd_args a) {
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  using X = D64<T>;
+  constexpr int QT = 64, VP = X::VP, ES = E::BYTES;
+  constexpr int TB = QT * VP;
+  constexpr int BUF = 2 * TB + 2 * QT * 4;             // Q tile | dO tile | lse[64] | delta[64]
+  constexpr int PIECES = QT * 64 / 8 / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][BUF]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nkb = (a.Nkv + 127) / 128;
+  const int kblk = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.heads, b = blockIdx.x / (nkb * a.heads);
+  const T* qp = (const T*)a.q + (size_t)b * a.Nq * a.q_stride + head * 64;
+  const T* kp = (const T*)a.k + (size_t)b * a.Nkv * a.kv_stride + head * 64;
+  const T* vp = (const T*)a.v + (size_t)b * a.Nkv * a.kv_stride + head * 64;
+  const T* dop = (const T*)a.dout + (size_t)b * a.Nq * a.o_stride + head * 64;
+  const float* lsep = a.lse + ((size_t)b * a.heads + head) * a.Nq;
+  const float* delp = a.delta + ((size_t)b * a.heads + head) * a.Nq;
+
+  // K^T / V^T fragments (B operands): lane (key r, h), k-step ks: d = 16 ks + 8 h + j
+  const int key = kblk * 128 + wave * 32 + r;
+  const bool kvalid = key < a.Nkv;
+  const float kscale = 0.125f * 1.4426950408889634f;
+  Frag kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (kvalid) {
+      float v[8];
+      E::unpack(E::load(kp + (size_t)key * a.kv_stride + 16 * ks + 8 * h), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= kscale;
+      kf[ks] = E::pack(v);
+      vf[ks] = E::load(vp + (size_t)key * a.kv_stride + 16 * ks + 8 * h);
+    } else { kf[ks] = E::zero(); vf[ks] = E::zero(); }
+  }
+  f32x16 dk0 = (f32x16)(0.f), dk1 = (f32x16)(0.f), dv0 = (f32x16)(0.f), dv1 = (f32x16)(0.f);
+
+  Frag stq[PIECES], std_[PIECES];
+  float st_stat = 0.f;                                 // thread t < 64: lse of query t; 64 <= t < 128: delta of query t - 64
+  auto issue = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + 256 * i, qi = q0 + (pc >> 3), sub = pc & 7;
+      if (qi < a.Nq) {
+        stq[i] = E::load(qp + (size_t)qi * a.q_stride + sub * 8);
+        std_[i] = E::load(dop + (size_t)qi * a.o_stride + sub * 8);
+      } else { stq[i] = E::zero(); std_[i] = E::zero(); }
+    }
+    if (tid < 128) {
+      const int qi = q0 + (tid & 63);
+      st_stat = tid < 64 ? (qi < a.Nq ? lsep[qi] : INFINITY) : (qi < a.Nq ? delp[qi] : 0.f);   // lse = +inf: P = 0 on the padding
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* qb_ = lds + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + 256 * i, row = pc >> 3, sub = pc & 7;
+      E::store(qb_ + row * VP + sub * 8 * ES, stq[i]);
+      E::store(qb_ + TB + row * VP + sub * 8 * ES, std_[i]);
+    }
+    if (tid < 128) ((float*)(qb_ + 2 * TB))[tid] = st_stat;
+  };
+  const int row_lane = r * VP + 8 * h * ES;
+  const int t_lane = X::vt_lane_off(lane);
+
+  issue(0);
+  commit(0);
+  if (QT < a.Nq) issue(QT);
+  __syncthreads();
+  for (int q0 = 0, cur = 0; q0 < a.Nq; q0 += QT, cur ^= 1) {
+    const unsigned char* qb_ = lds + cur * BUF;
+    const unsigned char* db = qb_ + TB;
+    const float* lse_t = (const float*)(qb_ + 2 * TB);
+    const float* del_t = lse_t + QT;
+#pragma unroll
+    for (int sub = 0; sub < QT / 32; ++sub) {
+      if (q0 + sub * 32 < a.Nq) {                      // workgroup-uniform
+        f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = E::mma(E::load(qb_ + row_lane + sub * 32 * VP + ks * 16 * ES), kf[ks], s);     // S[query][key]
+          dp = E::mma(E::load(db + row_lane + sub * 32 * VP + ks * 16 * ES), vf[ks], dp);    // dP[query][key]
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                  // register i <-> query sub*32 + 8(i>>2) + 4h + (i&3)
+          const int qi = sub * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+          const float p = __builtin_amdgcn_exp2f(s[i] - lse_t[qi]);
+          s[i] = p;
+          dp[i] = p * (dp[i] - del_t[qi]);              // dS
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const Frag pf = X::pack_p(s, st), df = X::pack_p(dp, st);
+          const unsigned char* dro = db + t_lane + (sub * 32 + 16 * st) * VP;
+          const unsigned char* qro = qb_ + t_lane + (sub * 32 + 16 * st) * VP;
+          dv0 = E::mma(X::load_vt(dro), pf, dv0);
+          dv1 = E::mma(X::load_vt(dro + 32 * ES), pf, dv1);
+          dk0 = E::mma(X::load_vt(qro), df, dk0);
+          dk1 = E::mma(X::load_vt(qro + 32 * ES), df, dk1);
+        }
+      }
+    }
+    if (q0 + QT < a.Nq) {
+      commit(cur ^ 1);
+      if (q0 + 2 * QT < a.Nq) issue(q0 + 2 * QT);
+    }
+    __syncthreads();
+  }
+  if (kvalid) {
+    T* dkd = (T*)a.dk + ((size_t)b * a.Nkv + key) * a.dkv_stride + head * 64 + 4 * h;
+    T* dvd = (T*)a.dv + ((size_t)b * a.Nkv + key) * a.dkv_stride + head * 64 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      store4(dkd + 8 * g, dk0[4 * g] * 0.125f, dk0[4 * g + 1] * 0.125f, dk0[4 * g + 2] * 0.125f, dk0[4 * g + 3] * 0.125f);
+      store4(dkd + 32 + 8 * g, dk1[4 * g] * 0.125f, dk1[4 * g + 1] * 0.125f, dk1[4 * g + 2] * 0.125f, dk1[4 * g + 3] * 0.125f);
+      store4(dvd + 8 * g, dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]);
+      store4(dvd + 32 + 8 * g, dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  One wave per token (statistics recomputed from x, as cheap as loading them):
+//   xhat = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ res]
+// The grid is fixed-size; every wave walks a strided set of tokens and keeps its share of dgamma = sum dy xhat and
+// dbeta = sum dy in registers; per-workgroup partials go to a workspace and are summed in a fixed order by a second kernel.
+constexpr int LN_MAXP = 4;                             // C <= 64 lanes * 8 * 4 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_bwd_args a) {
+  using E = Elem<T>;
+  __shared__ float red[3][2][LN_MAXP][8][64];          // waves 1..3: [dgamma | dbeta] shares
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pieces = a.C / 8;
+  float gam[LN_MAXP][8], dg[LN_MAXP][8], db[LN_MAXP][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAXP; ++i) {
+    const int pc = lane + 64 * i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gam[i][j] = pc < pieces ? a.gamma[pc * 8 + j] : 0.f; dg[i][j] = 0.f; db[i][j] = 0.f; }
+  }
+  const float invC = 1.0f / (float)a.C;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < a.rows; row += (long long)gridDim.x * 4) {
+    const T* x = (const T*)a.x + row * a.C;
+    const T* dy = (const T*)a.dy + row * a.C;
+    float v[LN_MAXP][8], g[LN_MAXP][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i) {
+      const int pc = lane + 64 * i;
+      if (pc < pieces) {
+        E::unpack(E::load(x + pc * 8), v[i]);
+        E::unpack(E::load(dy + pc * 8), g[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+      }
+    }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk);
+    const float mean = s * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i)
+      if (lane + 64 * i < pieces) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+      }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) q += __shfl_xor(q, msk);
+    const float rstd = 1.0f / sqrtf(q * invC + a.eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i)
+      if (lane + 64 * i < pieces) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (v[i][j] - mean) * rstd, dyv = g[i][j];
+          dg[i][j] += dyv * xh;
+          db[i][j] += dyv;
+          const float gg = dyv * gam[i][j];
+          v[i][j] = xh; g[i][j] = gg;
+          sg += gg; sgx += gg * xh;
+        }
+      }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) { sg += __shfl_xor(sg, msk); sgx += __shfl_xor(sgx, msk); }
+    const float mg = sg * invC, mgx = sgx * invC;
+    T* dx = (T*)a.dx + row * a.C;
+    const T* res = a.res ? (const T*)a.res + row * a.C : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i) {
+      const int pc = lane + 64 * i;
+      if (pc < pieces) {
+        float o[8], rv[8];
+        if (res) E::unpack(E::load(res + pc * 8), rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - mg - v[i][j] * mgx) + (res ? rv[j] : 0.f);
+        E::store(dx + pc * 8, E::pack(o));
+      }
+    }
+  }
+  if (!a.partial) return;
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[wave - 1][0][i][j][lane] = dg[i][j]; red[wave - 1][1][i][j][lane] = db[i][j]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* pg = a.partial + (size_t)blockIdx.x * 2 * a.C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i) {
+      const int pc = lane + 64 * i;
+      if (pc < pieces) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pg[pc * 8 + j] = ((dg[i][j] + red[0][0][i][j][lane]) + red[1][0][i][j][lane]) + red[2][0][i][j][lane];
+          pg[a.C + pc * 8 + j] = ((db[i][j] + red[0][1][i][j][lane]) + red[1][1][i][j][lane]) + red[2][1][i][j][lane];
+        }
+      }
+    }
+  }
+}
+
+// dgamma[c] += sum over workgroups of partial[wg][0][c], dbeta likewise (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* partial, int nblocks, int C, float* dgamma, float* dbeta) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 2 * C + idx];
+  float* dst = idx < C ? dgamma + idx : dbeta + (idx - C);
+  *dst += s;
+}
+
+// GEGLU backward: y = h * gelu(g)  ->  dh = dy * gelu(g),  dg = dy * h * (Phi(g) + g * phi(g));  dx = [dh | dg]
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const pd_geglu_bwd_args a) {
+  using E = Elem<T>;
+  const int pieces = a.inner / 8;
+  const size_t total = (size_t)a.rows * pieces;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / pieces;
+    const int pc = (int)(idx - row * pieces);
+    float hv[8], gv[8], dyv[8], dh[8], dgv[8];
+    E::unpack(E::load((const T*)a.x + row * 2 * a.inner + pc * 8), hv);
+    E::unpack(E::load((const T*)a.x + row * 2 * a.inner + a.inner + pc * 8), gv);
+    E::unpack(E::load((const T*)a.dy + row * a.inner + pc * 8), dyv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cdf = 0.5f * (1.0f + erff(gv[j] * 0.7071067811865476f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * gv[j] * gv[j]);
+      dh[j] = dyv[j] * gv[j] * cdf;
+      dgv[j] = dyv[j] * hv[j] * (cdf + gv[j] * pdf);
+    }
+    E::store((T*)a.dx + row * 2 * a.inner + pc * 8, E::pack(dh));
+    E::store((T*)a.dx + row * 2 * a.inner + a.inner + pc * 8, E::pack(dgv));
+  }
+}
+
+template <typename T>
+static int launch_attn_d64_bwd(const pd_attn_d64_bwd_args* a, hipStream_t st) {
+  constexpr int TB = 64 * D64<T>::VP;
+  constexpr int LDS_DQ = 2 * 2 * TB, LDS_DKV = 2 * (2 * TB + 2 * 64 * 4);
+  auto kq = attn_d64_dq_kernel<T>;
+  auto kkv = attn_d64_dkv_kernel<T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV) != hipSuccess) {
+      set_error("pd_attn_d64_bwd: cannot reserve %d / %d bytes of LDS", LDS_DQ, LDS_DKV);
+      return PD_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const size_t nd = (size_t)a->B * a->Nq * a->heads * 8;
+  hipLaunchKernelGGL(attn_d64_delta_kernel<T>, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, *a);
+  PD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kq, dim3(((a->Nq + 127) / 128) * a->heads * a->B), dim3(256), LDS_DQ, st, *a);
+  PD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kkv, dim3(((a->Nkv + 127) / 128) * a->heads * a->B), dim3(256), LDS_DKV, st, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+}  // namespace pd
+
+using namespace pd;
+
+extern "C" int pd_attn_d64_bwd(const pd_attn_d64_bwd_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_attn_d64_bwd: null args");
+  PD_CHECK(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nkv > 0, PD_ERR_SHAPE, "pd_attn_d64_bwd: bad shape");
+  PD_CHECK(a->q && a->k && a->v && a->o && a->dout && a->lse && a->delta && a->dq && a->dk && a->dv, PD_ERR_ARG, "pd_attn_d64_bwd: null pointer");
+  const int c = a->heads * 64;
+  PD_CHECK(a->q_stride >= c && a->kv_stride >= c && a->o_stride >= c && a->dq_stride >= c && a->dkv_stride >= c && a->q_stride % 8 == 0 &&
+               a->kv_stride % 8 == 0 && a->o_stride % 8 == 0 && a->dq_stride % 8 == 0 && a->dkv_stride % 8 == 0, PD_ERR_SHAPE,
+           "pd_attn_d64_bwd: strides must cover heads*64 channels and be multiples of 8");
+  PD_CHECK((long long)((a->Nq + 127) / 128) * a->heads * a->B < (1ll << 31) && (long long)a->B * a->Nq * a->heads * 8 / 256 < (1ll << 31),
+           PD_ERR_SHAPE, "pd_attn_d64_bwd: grid too large");
+  if (a->dtype == PD_F32) return launch_attn_d64_bwd<float>(a, (hipStream_t)stream);
+  if (a->dtype == PD_BF16) return launch_attn_d64_bwd<bf16_t>(a, (hipStream_t)stream);
+  set_error("pd_attn_d64_bwd: bad dtype");
+  return PD_ERR_ARG;
+}
+
+extern "C" int pd_layernorm_bwd_blocks(long long rows) {
+  const long long nb = (rows + 3) / 4;
+  return (int)(nb < 1024 ? nb : 1024);
+}
+
+extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 2048 && a->x && a->dy && a->dx && a->gamma, PD_ERR_ARG,
+           "pd_layernorm_bwd: bad args (C must be a multiple of 8, <= 2048)");
+  PD_CHECK((a->dgamma == nullptr) == (a->dbeta == nullptr) && (a->dgamma == nullptr) == (a->partial == nullptr), PD_ERR_ARG,
+           "pd_layernorm_bwd: dgamma, dbeta and partial go together");
+  const int grid = pd_layernorm_bwd_blocks(a->rows);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, *a);
+  else { set_error("pd_layernorm_bwd: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  if (a->partial) {
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * a->C + 255) / 256), dim3(256), 0, st, (const float*)a->partial, grid, a->C,
+                       a->dgamma, a->dbeta);
+    PD_LAUNCH_CHECK();
+  }
+  return PD_OK;
+}
+
+extern "C" int pd_geglu_bwd(const pd_geglu_bwd_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->inner > 0 && a->inner % 8 == 0 && a->x && a->dy && a->dx, PD_ERR_ARG, "pd_geglu_bwd: bad args");
+  const size_t total = (size_t)a->rows * (a->inner / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(geglu_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(geglu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_geglu_bwd: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}

@@ -7,6 +7,7 @@
 // reuses pd_conv / pd_gn_finalize / pd_temb.
 #include "pd_common.h"
 #include "pd_stage.h"
+#include "pd_d64.h"
 
 namespace pd {
 
@@ -19,49 +20,6 @@ namespace pd {
 //   O^T[d][query]  += V^T[64 x 32 keys] . P^T          ... as the B operand: 2 row tiles x 2 k-steps.  V sits row-major
 //                                                      [key][d] in LDS; the A operand V^T is a TRANSPOSED read
 //                                                      (ds_read_b64_tr_b16, rows chosen per lane to match P's key order).
-template <typename T> struct D64;
-template <> struct D64<bf16_t> {
-  static constexpr int KP = 128 + 16, VP = 128 + 64;      // row pitches: conflict-free ds_read_b128 rows / 4-row transposed blocks
-  typedef Elem<bf16_t>::Frag Frag;
-  static __device__ __forceinline__ int vt_lane_off(int lane) {      // block row q <-> key 4h + q, columns 16*cg + 4*pp of a 32-d row tile
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    return (4 * (g >> 1) + q) * VP + (16 * (g & 1) + 4 * pp) * 2;
-  }
-  // A fragment of V^T for k-step s (16 keys) of a 32-key sub-tile: element j <-> key 16s + 8(j>>2) + 4h + (j&3) (P's register order)
-  static __device__ __forceinline__ Frag load_vt(const unsigned char* base) {
-    typedef short v4s __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) v4s* lp;
-    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base));
-    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + 8 * VP));
-    Frag f; f.v = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return f;
-  }
-  static __device__ __forceinline__ Frag pack_p(const f32x16& p, int s) {
-    uint32_t w[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
-    Frag f; f.v = __builtin_bit_cast(s16x8, (u32x4){w[0], w[1], w[2], w[3]});
-    return f;
-  }
-};
-template <> struct D64<float> {
-  static constexpr int KP = 256 + 16, VP = 256 + 16;
-  typedef Elem<float>::Frag Frag;
-  static __device__ __forceinline__ int vt_lane_off(int lane) { return (4 * (lane >> 5)) * VP + (lane & 31) * 4; }   // key 4h, d = r
-  static __device__ __forceinline__ Frag load_vt(const unsigned char* base) {
-    Frag f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { f.lo[j] = *(const float*)(base + j * VP); f.hi[j] = *(const float*)(base + (8 + j) * VP); }
-    return f;
-  }
-  static __device__ __forceinline__ Frag pack_p(const f32x16& p, int s) {
-    Frag f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { f.lo[j] = p[8 * s + j]; f.hi[j] = p[8 * s + 4 + j]; }
-    return f;
-  }
-};
-
 template <typename T>
 __global__ __launch_bounds__(256) void attn_d64_kernel(const pd_attn_d64_args a) {
   using E = Elem<T>;
@@ -171,6 +129,7 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const pd_attn_d64_args a)
   l += __shfl_xor(l, 32);
   if (query < a.Nq) {
     const float inv = 1.0f / l;
+    if (a.lse && h == 0) a.lse[((size_t)b * a.heads + head) * a.Nq + query] = m + __log2f(l);     // log2 domain, scale included
     T* dst = (T*)a.out + ((size_t)b * a.Nq + query) * a.out_stride + head * 64 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {                      // register 4g + i <-> d = 8g + 4h + i (+32 for the second row tile)

@@ -70,3 +70,98 @@ def test_geglu(env, mode):
     torch.cuda.synchronize()
     h, gate = x.chunk(2, -1)
     assert rel(y.float(), h * F.gelu(gate)) < (2e-6 if mode == "f32" else 4e-3)
+
+
+# ---- backward kernels of the Transformer2D blocks: against autograd over plain PyTorch fp32 ---------------------------------
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 2, 256, 256), (1, 5, 1024, 1024), (2, 3, 200, 77), (1, 1, 16, 16), (2, 2, 130, 4), (1, 2, 70, 200)])
+def test_attention_d64_backward(env, mode, cfg):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, Nq, Nkv = cfg
+    Cc = heads * 64
+    g = torch.Generator().manual_seed(51)
+    q = bf16_round(torch.randn(B, Nq, Cc, generator=g), mode).requires_grad_()
+    kv = bf16_round(torch.randn(B, Nkv, 2 * Cc, generator=g), mode).requires_grad_()
+    do = bf16_round(torch.randn(B, Nq, Cc, generator=g), mode)
+    sp = lambda t, n: t.reshape(B, n, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, Nq), sp(kv[..., :Cc], Nkv), sp(kv[..., Cc:], Nkv)).transpose(1, 2).reshape(B, Nq, Cc)
+    ref.backward(do)
+    Q, KV, DO = q.detach().to(tdt).to(dev), kv.detach().to(tdt).to(dev), do.to(tdt).to(dev)
+    esz = Q.element_size()
+    out = torch.empty((B, Nq, Cc), dtype=tdt, device=dev)
+    lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=dev)
+    a = L.AttnD64Args(dtype=code, B=B, heads=heads, Nq=Nq, Nkv=Nkv, q=Q.data_ptr(), q_stride=Cc, k=KV.data_ptr(),
+                      v=KV.data_ptr() + Cc * esz, kv_stride=2 * Cc, out=out.data_ptr(), out_stride=Cc, lse=lse.data_ptr())
+    L.check(lib.pd_attn_d64(C.byref(a), stream()), "pd_attn_d64")
+    # lse: log2-domain log-sum-exp of the scaled scores
+    s = torch.einsum("bhid,bhjd->bhij", sp(q.detach(), Nq), sp(kv.detach()[..., :Cc], Nkv)) / 8
+    assert rel(lse.cpu(), torch.logsumexp(s, -1) * 1.4426950408889634) < (1e-5 if mode == "f32" else 2e-3)
+    dq = torch.full((B, Nq, Cc), float("nan"), dtype=tdt, device=dev)
+    dkv = torch.full((B, Nkv, 2 * Cc), float("nan"), dtype=tdt, device=dev)
+    delta = torch.empty((B, heads, Nq), dtype=torch.float32, device=dev)
+    b = L.AttnD64BwdArgs(dtype=code, B=B, heads=heads, Nq=Nq, Nkv=Nkv, q=Q.data_ptr(), q_stride=Cc, k=KV.data_ptr(),
+                         v=KV.data_ptr() + Cc * esz, kv_stride=2 * Cc, o=out.data_ptr(), dout=DO.data_ptr(), o_stride=Cc,
+                         lse=lse.data_ptr(), delta=delta.data_ptr(), dq=dq.data_ptr(), dq_stride=Cc, dk=dkv.data_ptr(),
+                         dv=dkv.data_ptr() + Cc * esz, dkv_stride=2 * Cc)
+    L.check(lib.pd_attn_d64_bwd(C.byref(b), stream()), "pd_attn_d64_bwd")
+    torch.cuda.synchronize()
+    tol = 3e-5 if mode == "f32" else 2.5e-2
+    assert rel(dq.float(), q.grad) < tol, rel(dq.float(), q.grad)
+    assert rel(dkv.float()[..., :Cc], kv.grad[..., :Cc]) < tol
+    assert rel(dkv.float()[..., Cc:], kv.grad[..., Cc:]) < tol
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(37, 64), (5000, 320), (513, 1280), (4, 2048)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_backward(env, mode, cfg, with_res):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    rows, Cc = cfg
+    g = torch.Generator().manual_seed(52)
+    x = bf16_round(torch.randn(rows, Cc, generator=g) * 2 + 0.5, mode).requires_grad_()
+    gamma = torch.randn(Cc, generator=g).requires_grad_()
+    beta = torch.randn(Cc, generator=g).requires_grad_()
+    dy = bf16_round(torch.randn(rows, Cc, generator=g), mode)
+    res = bf16_round(torch.randn(rows, Cc, generator=g), mode) if with_res else None
+    F.layer_norm(x, (Cc,), gamma, beta, 1e-5).backward(dy)
+    X, DY = x.detach().to(tdt).to(dev), dy.to(tdt).to(dev)
+    R = res.to(tdt).to(dev) if with_res else None
+    dx = torch.empty((rows, Cc), dtype=tdt, device=dev)
+    dgm = torch.full((Cc,), 1.0, dtype=torch.float32, device=dev)        # accumulates (+=)
+    dbt = torch.full((Cc,), -2.0, dtype=torch.float32, device=dev)
+    nb = lib.pd_layernorm_bwd_blocks(rows)
+    part = torch.empty(nb * 2 * Cc, dtype=torch.float32, device=dev)
+    gm = gamma.detach().to(dev)
+    a = L.LayerNormBwdArgs(dtype=code, rows=rows, C=Cc, eps=1e-5, x=X.data_ptr(), dy=DY.data_ptr(), gamma=gm.data_ptr(),
+                           res=L.ptr(R), dx=dx.data_ptr(), dgamma=dgm.data_ptr(), dbeta=dbt.data_ptr(), partial=part.data_ptr())
+    L.check(lib.pd_layernorm_bwd(C.byref(a), stream()), "pd_layernorm_bwd")
+    torch.cuda.synchronize()
+    want = x.grad + (res if with_res else 0)
+    assert rel(dx.float(), want) < (3e-6 if mode == "f32" else 5e-3)
+    assert rel(dgm - 1.0, gamma.grad) < 2e-5 and rel(dbt + 2.0, beta.grad) < 2e-5
+    # input-gradient-only form
+    a.dgamma, a.dbeta, a.partial = None, None, None
+    dx2 = torch.empty_like(dx)
+    a.dx = dx2.data_ptr()
+    L.check(lib.pd_layernorm_bwd(C.byref(a), stream()), "pd_layernorm_bwd")
+    assert torch.equal(dx2, dx)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_geglu_backward(env, mode):
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    rows, inner = 333, 1280
+    g = torch.Generator().manual_seed(53)
+    x = bf16_round(torch.randn(rows, 2 * inner, generator=g) * 1.5, mode).requires_grad_()
+    dy = bf16_round(torch.randn(rows, inner, generator=g), mode)
+    h, gate = x.chunk(2, dim=-1)
+    (h * F.gelu(gate)).backward(dy)
+    X, DY = x.detach().to(tdt).to(dev), dy.to(tdt).to(dev)
+    dx = torch.empty((rows, 2 * inner), dtype=tdt, device=dev)
+    a = L.GegluBwdArgs(dtype=code, rows=rows, inner=inner, x=X.data_ptr(), dy=DY.data_ptr(), dx=dx.data_ptr())
+    L.check(lib.pd_geglu_bwd(C.byref(a), stream()), "pd_geglu_bwd")
+    torch.cuda.synchronize()
+    assert rel(dx.float(), x.grad) < (2e-6 if mode == "f32" else 4e-3)
