@@ -379,6 +379,8 @@ typedef struct {
   const float* clip_coef;         /* device scalar from pd_grad_norm, or NULL */
   float* param; float* grad; float* exp_avg; float* exp_avg_sq;
   float* ema;                     /* EMA shadow parameters or NULL */
+  int ema_only;                   /* 1: no AdamW update (torch skips parameters whose .grad is None, e.g. the CustomEmbedding on an
+                                     unconditional step, utils_training.py:465-471); EMA and grad zeroing still run */
 } pd_adamw_ema_args;
 int pd_adamw_ema(const pd_adamw_ema_args* a, void* stream);
 
@@ -460,6 +462,12 @@ typedef struct {
 } pd_layernorm_bwd_args;
 int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream);
 int pd_layernorm_bwd_blocks(long long rows);
+
+/* pd_token_embedding_grad: gradient of CustomEmbedding (custom_embedding.py:36-47) from the encoder_hidden_states gradient:
+ * dtable[labels[n]][c] += d[n*row_stride + c] (row n = token 0 of sample n; the 76 padding tokens are constants).
+ * labels = NULL (unconditional step, utils_training.py:465-471): no-op. */
+typedef struct { int dtype; int rows, dim, num_classes; long long row_stride; const int64_t* labels; const void* d; float* dtable; } pd_token_embedding_grad_args;
+int pd_token_embedding_grad(const pd_token_embedding_grad_args* a, void* stream);
 
 /* pd_geglu_bwd: x = [h | g] (the forward's input, [rows][2*inner]), dy [rows][inner] -> dx = [dy*gelu(g) | dy*h*gelu'(g)] */
 typedef struct { int dtype; long long rows; int inner; const void* x; const void* dy; void* dx; } pd_geglu_bwd_args;

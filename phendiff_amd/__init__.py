@@ -19,3 +19,4 @@ from . import train_state  # noqa: F401
 from .sd_unet import SDUNet2DConditionModel, CustomEmbedding, class_emb_to_encoder_hidden_states, SD21_UNET_CONFIG  # noqa: F401
 from .vae import AutoencoderKL, VaeImageProcessor, DiagonalGaussianDistribution, SD_VAE_CONFIG  # noqa: F401
 from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline, hack_class_embedding  # noqa: F401
+from .sd_unet_train import SDUNetTrainer, SDUNetTrainPlan, sd_training_param_order  # noqa: F401

@@ -134,6 +134,11 @@ class LayerNormBwdArgs(C.Structure):
                 ("res", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp), ("partial", vp)]
 
 
+class TokenEmbeddingGradArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_int), ("dim", C.c_int), ("num_classes", C.c_int), ("row_stride", C.c_longlong),
+                ("labels", vp), ("d", vp), ("dtable", vp)]
+
+
 class GegluBwdArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("inner", C.c_int), ("x", vp), ("dy", vp), ("dx", vp)]
 
@@ -190,7 +195,7 @@ class AdamWEmaArgs(C.Structure):
     _fields_ = [("numel", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("step_size", C.c_float), ("bias_correction2_sqrt", C.c_float),
                 ("one_minus_decay", C.c_float), ("zero_grad", C.c_int), ("clip_coef", vp), ("param", vp), ("grad", vp),
-                ("exp_avg", vp), ("exp_avg_sq", vp), ("ema", vp)]
+                ("exp_avg", vp), ("exp_avg_sq", vp), ("ema", vp), ("ema_only", C.c_int)]
 
 
 class PostprocArgs(C.Structure):
@@ -230,6 +235,7 @@ SYMBOLS = {
     "pd_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdArgs), vp]),
     "pd_layernorm_bwd_blocks": (C.c_int, [C.c_longlong]),
     "pd_geglu_bwd": (C.c_int, [C.POINTER(GegluBwdArgs), vp]),
+    "pd_token_embedding_grad": (C.c_int, [C.POINTER(TokenEmbeddingGradArgs), vp]),
     "pd_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), vp]),
     "pd_geglu": (C.c_int, [C.POINTER(GegluArgs), vp]),
     "pd_lp_guidance": (C.c_int, [C.POINTER(LpGuidanceArgs), vp]),

@@ -411,6 +411,19 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const pd_geglu_bwd_args 
   }
 }
 
+// CustomEmbedding gradient from the encoder_hidden_states gradient: only token 0 of the 77 carries the class embedding
+// (utils_training.py:479-484), so dtable[labels[n]][c] += d[n][token 0][c].  One thread per column, samples in order.
+template <typename T>
+__global__ __launch_bounds__(256) void token_embedding_grad_kernel(const pd_token_embedding_grad_args a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.dim) return;
+  for (int n = 0; n < a.rows; ++n) {
+    const long long k = a.labels[n];
+    if (k < 0 || k >= a.num_classes) continue;
+    a.dtable[(size_t)k * a.dim + c] += Elem<T>::to_f(((const T*)a.d)[(size_t)n * a.row_stride + c]);
+  }
+}
+
 template <typename T>
 static int launch_attn_d64_bwd(const pd_attn_d64_bwd_args* a, hipStream_t st) {
   constexpr int TB = 64 * D64<T>::VP;
@@ -477,6 +490,18 @@ extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
                        a->dgamma, a->dbeta);
     PD_LAUNCH_CHECK();
   }
+  return PD_OK;
+}
+
+extern "C" int pd_token_embedding_grad(const pd_token_embedding_grad_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->rows > 0 && a->dim > 0 && a->num_classes > 0 && a->d && a->dtable && a->row_stride >= a->dim, PD_ERR_ARG,
+           "pd_token_embedding_grad: bad args");
+  if (!a->labels) return PD_OK;                        // unconditional step (all-zero context): no class-embedding gradient
+  const unsigned grid = (unsigned)((a->dim + 255) / 256);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(token_embedding_grad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(token_embedding_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_token_embedding_grad: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
   return PD_OK;
 }
 

@@ -72,8 +72,13 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(const pd_adamw_ema_args 
 #pragma clang fp contract(off)
   const float coef = a.clip_coef ? a.clip_coef[0] : 1.0f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.numel; i += (int64_t)gridDim.x * 256) {
-    const float g = a.grad[i] * coef;
     float p = a.param[i];
+    if (a.ema_only) {                                                // a parameter whose .grad is None: torch skips its update
+      if (a.ema) { const float s = a.ema[i]; a.ema[i] = s - a.one_minus_decay * (s - p); }
+      if (a.zero_grad) a.grad[i] = 0.0f;
+      continue;
+    }
+    const float g = a.grad[i] * coef;
     p = p * (1.0f - a.lr * a.weight_decay);                          // param.mul_(1 - lr * wd)
     const float m = a.exp_avg[i] + (g - a.exp_avg[i]) * (1.0f - a.beta1);   // exp_avg.lerp_(grad, 1 - beta1)
     const float v = a.exp_avg_sq[i] * a.beta2 + (g * g) * (1.0f - a.beta2);

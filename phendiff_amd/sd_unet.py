@@ -338,11 +338,12 @@ class SDUNetPlan(UNetPlan):
 
     def _attention(self, q, qs, k, v, kvs, heads, nq, nkv):
         out = self._act(1, nq, heads * 64).view(self.B, 1, nq, heads * 64)
+        lse = self._f32(self.B, heads, nq) if self.train else None
         a = L.AttnD64Args(dtype=self.code, B=self.B, heads=heads, Nq=nq, Nkv=nkv, q=q, q_stride=qs, k=k, v=v, kv_stride=kvs,
-                          out=out.data_ptr(), out_stride=heads * 64)
+                          out=out.data_ptr(), out_stride=heads * 64, lse=L.ptr(lse))
         self.ops.append(_Op(self.lib.pd_attn_d64, a, "attn_d64", 4.0 * self.B * heads * nq * nkv * 64,
                             (2.0 * self.B * nq + 2.0 * self.B * nkv) * heads * 64 * self._esz()))
-        return out
+        return out, lse
 
     def _transformer(self, name, x):
         e, zb = self.w.transformers[name], self.w.zero_bias
@@ -352,22 +353,29 @@ class SDUNetPlan(UNetPlan):
         gn = self._gn(x, None, e.g, e.be, e.eps)
         h0 = lin(x, e.w_in, e.b_in, ch, gn=gn)
         # self attention
-        qkv = lin(self._layernorm(h0, e.ln1), e.wqkv1, zb, 3 * ch)
+        y1 = self._layernorm(h0, e.ln1)
+        qkv = lin(y1, e.wqkv1, zb, 3 * ch)
         p = qkv.data_ptr()
-        a1 = self._attention(p, 3 * ch, p + ch * esz, p + 2 * ch * esz, 3 * ch, e.heads, N, N).view(B, h, w, ch)
+        a1, lse1 = self._attention(p, 3 * ch, p + ch * esz, p + 2 * ch * esz, 3 * ch, e.heads, N, N)
+        a1 = a1.view(B, h, w, ch)
         h1 = lin(a1, e.wo1, e.bo1, ch, residual=h0)
         # cross attention over the encoder_hidden_states tokens
-        q2 = lin(self._layernorm(h1, e.ln2), e.wq2, zb, ch)
+        y2 = self._layernorm(h1, e.ln2)
+        q2 = lin(y2, e.wq2, zb, ch)
         kv = lin(self.ehs, e.wkv2, zb, 2 * ch)
-        a2 = self._attention(q2.data_ptr(), ch, kv.data_ptr(), kv.data_ptr() + ch * esz, 2 * ch, e.heads, N, self.tokens)
-        h2 = lin(a2.view(B, h, w, ch), e.wo2, e.bo2, ch, residual=h1)
+        a2, lse2 = self._attention(q2.data_ptr(), ch, kv.data_ptr(), kv.data_ptr() + ch * esz, 2 * ch, e.heads, N, self.tokens)
+        a2 = a2.view(B, h, w, ch)
+        h2 = lin(a2, e.wo2, e.bo2, ch, residual=h1)
         # GEGLU feed-forward
-        ff = lin(self._layernorm(h2, e.ln3), e.wff1, e.bff1, 8 * ch)
+        y3 = self._layernorm(h2, e.ln3)
+        ff = lin(y3, e.wff1, e.bff1, 8 * ch)
         gg = self._act(h, w, 4 * ch)
         ga = L.GegluArgs(dtype=self.code, rows=B * N, inner=4 * ch, x=ff.data_ptr(), y=gg.data_ptr())
         self.ops.append(_Op(self.lib.pd_geglu, ga, "geglu", 0.0, 3.0 * gg.numel() * esz))
         h3 = lin(gg, e.wff2, e.bff2, ch, residual=h2)
         out, _ = self._conv(h3, None, e.w_out, e.b_out, ch, ksize=1, pad=0, residual=x)       # statistics for the next GroupNorm
+        self.tape.append(SimpleNamespace(kind="transformer", name=name, e=e, x=x, gn=gn, h0=h0, y1=y1, qkv=qkv, a1=a1, lse1=lse1,
+                                         h1=h1, y2=y2, q2=q2, kv=kv, a2=a2, lse2=lse2, h2=h2, y3=y3, ff=ff, gg=gg, h3=h3, out=out))
         return out
 
     def _build(self):
@@ -387,6 +395,7 @@ class SDUNetPlan(UNetPlan):
         self._in_args = L.NchwToNhwcArgs(dtype=self.code, B=B, C=c.in_channels, HW=H * W, Cpad=32, x=None, out=lat.data_ptr())
         self.ops.append(_Op(self.lib.pd_nchw_to_nhwc, self._in_args, "nchw_to_nhwc", 0.0, B * H * W * c.in_channels * 4.0))
         h, _ = self._conv(lat, None, w.conv_in_w, w.conv_in_b, boc[0])
+        self.tape.append(SimpleNamespace(kind="sd_conv_in", x=lat, out=h))
         skips = [h]
         for i, blk in enumerate(m.down_blocks):
             has_attn = hasattr(blk, "attentions")
@@ -397,7 +406,9 @@ class SDUNetPlan(UNetPlan):
                 skips.append(h)
             if blk.downsamplers is not None:
                 s = w.samplers[f"down_blocks.{i}.downsamplers.0"]
-                h, _ = self._conv(h, None, s.w, s.b, h.shape[3], stride=2, pad=s.padding)
+                hd, _ = self._conv(h, None, s.w, s.b, h.shape[3], stride=2, pad=s.padding)
+                self.tape.append(SimpleNamespace(kind="down", name=f"down_blocks.{i}.downsamplers.0", x=h, out=hd, e=s))
+                h = hd
                 skips.append(h)
         h = self._resnet("mid_block.resnets.0", h)
         h = self._transformer("mid_block.attentions.0", h)
@@ -410,11 +421,14 @@ class SDUNetPlan(UNetPlan):
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h)
             if blk.upsamplers is not None:
                 s = w.samplers[f"up_blocks.{i}.upsamplers.0"]
-                h, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+                hu, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+                self.tape.append(SimpleNamespace(kind="up", name=f"up_blocks.{i}.upsamplers.0", x=h, out=hu, e=s))
+                h = hu
         g, be, eps = w.gn_out
         gn = self._gn(h, None, g, be, eps)
         _, self._out_args = self._conv(h, None, w.conv_out_w, w.conv_out_b, c.out_channels, silu=1, gn=gn,
                                        out_mode=L.PD_OUT_NCHW_F32, cout_pad=w.conv_out_pad, y=None)
+        self.tape.append(SimpleNamespace(kind="conv_out", x=h, gn=gn))
         self._cur = (None, None, None)
 
     def forward(self, sample, ts, ehs, out, stream):

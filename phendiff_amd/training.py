@@ -130,11 +130,19 @@ class FlatAdamWEMA:
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.ema_kwargs = ema_kwargs or {}
         self.t = 0
+        self.tail = None            # (offset, numel): a trailing segment with its own AdamW step count (see set_tail)
+        self.t_tail = 0
         self.partial = torch.empty(1024, dtype=torch.float64, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.clip_coef = torch.ones(1, dtype=torch.float32, device=dev)
 
-    def step(self, lr: Optional[float] = None, zero_grad: bool = True):
+    def set_tail(self, numel: int):
+        """The last ``numel`` elements are a parameter that does not receive a gradient on every step (the ``CustomEmbedding``
+        on unconditional steps): torch's AdamW skips a parameter whose ``.grad`` is None and counts its steps separately, so
+        that segment keeps its own step count and ``step(tail_active=False)`` leaves it (and its moments) untouched."""
+        self.tail = (self.flat.numel() - numel, numel)
+
+    def step(self, lr: Optional[float] = None, zero_grad: bool = True, tail_active: bool = True):
         """clip_grad_norm_ -> optimizer.step -> zero_grad -> EMA.step (utils_training.py:438-454, 553-556). No host sync:
         the gradient norm stays on the device (``self.grad_norm``)."""
         lib = L.lib()
@@ -146,13 +154,27 @@ class FlatAdamWEMA:
             L.check(lib.pd_grad_norm(self.grad.data_ptr(), self.grad.numel(), self.partial.data_ptr(), float(self.max_grad_norm),
                                      self.grad_norm.data_ptr(), self.clip_coef.data_ptr(), st), "pd_grad_norm")
         d = ema_decay(self.t, **self.ema_kwargs) if self.ema is not None else 0.0
-        a = L.AdamWEmaArgs(numel=self.flat.numel(), lr=lr, beta1=b1, beta2=b2, eps=self.eps, weight_decay=self.wd,
-                           step_size=lr / (1 - b1 ** self.t), bias_correction2_sqrt=math.sqrt(1 - b2 ** self.t),
-                           one_minus_decay=1.0 - d, zero_grad=int(zero_grad),
-                           clip_coef=self.clip_coef.data_ptr() if self.max_grad_norm is not None else None,
-                           param=self.flat.data_ptr(), grad=self.grad.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
-                           exp_avg_sq=self.exp_avg_sq.data_ptr(), ema=L.ptr(self.ema))
-        L.check(lib.pd_adamw_ema(C.byref(a), st), "pd_adamw_ema")
+        clip = self.clip_coef.data_ptr() if self.max_grad_norm is not None else None
+
+        def launch(off, numel, t, ema_only=0):
+            a = L.AdamWEmaArgs(numel=numel, lr=lr, beta1=b1, beta2=b2, eps=self.eps, weight_decay=self.wd,
+                               step_size=lr / (1 - b1 ** t), bias_correction2_sqrt=math.sqrt(1 - b2 ** t),
+                               one_minus_decay=1.0 - d, zero_grad=int(zero_grad), clip_coef=clip,
+                               param=self.flat.data_ptr() + 4 * off, grad=self.grad.data_ptr() + 4 * off,
+                               exp_avg=self.exp_avg.data_ptr() + 4 * off, exp_avg_sq=self.exp_avg_sq.data_ptr() + 4 * off,
+                               ema=(self.ema.data_ptr() + 4 * off) if self.ema is not None else None, ema_only=ema_only)
+            L.check(lib.pd_adamw_ema(C.byref(a), st), "pd_adamw_ema")
+
+        if self.tail is None:
+            launch(0, self.flat.numel(), self.t)
+            return
+        off, n = self.tail
+        launch(0, off, self.t)
+        if tail_active:
+            self.t_tail += 1
+            launch(off, n, self.t_tail)
+        else:
+            launch(off, n, 1, ema_only=1)
 
 
 def allreduce_mean_(flat_grad: torch.Tensor, group=None, bucket_bytes: int = 256 << 20):

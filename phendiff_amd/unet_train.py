@@ -102,6 +102,10 @@ class UNetTrainPlan(UNetPlan):
         ``input_grad``: also produce d loss / d sample (fp32 NCHW, ``self.dsample``) -- the gradient-guided transfer."""
         self.train = True
         super().__init__(m, w, B, H, W, device)
+        self._init_train(tw, params, grads, input_grad)
+
+    def _init_train(self, tw, params, grads, input_grad):
+        m, w, B, H, W = self.m, self.w, self.B, self.H, self.W
         self.tw, self.params, self.grads = tw, params, grads
         self.param_grads, self.input_grad = grads is not None, input_grad
         self.dsample = self._f32(B, m.config.in_channels, H, W) if input_grad else None
@@ -293,67 +297,15 @@ class UNetTrainPlan(UNetPlan):
         self._b(self.lib.pd_gn_silu_bwd, a, "gn_silu_bwd", 0.0, n * self._esz() * (5 + (1 if res is not None else 0)))
 
     # ---- backward plan ---------------------------------------------------------------------------
+    def _zero_bias_len(self):
+        return max(max(self.m.config.block_out_channels) * 3, 64) + 64
+
     def _build_backward(self):
-        m, w, tw, c = self.m, self.w, self.tw, self.m.config
-        G = self._G
-        B, H, W = self.B, self.H, self.W
-        boc0 = c.block_out_channels[0]
-        maxc = max(max(c.block_out_channels) * 3, 64)
-        self._zero_bias = torch.zeros(maxc + 64, dtype=torch.float32, device=self.device)
-        self.dproj = self._f32(B, w.proj_dim)
+        w = self.w
+        self._zero_bias = torch.zeros(self._zero_bias_len(), dtype=torch.float32, device=self.device)
+        self.dproj = self._f32(self.B, w.proj_dim)
         for rec in reversed(self.tape):
-            k = rec.kind
-            if k == "conv_out":
-                dy = self._tmp((B, H, W, w.conv_out_pad), "dy_out")
-                a = L.NchwToNhwcArgs(dtype=self.code, B=B, C=c.out_channels, HW=H * W, Cpad=w.conv_out_pad, x=None,
-                                     out=dy.data_ptr())
-                self._dout_args = a
-                self._b(self.lib.pd_nchw_to_nhwc, a, "nchw_to_nhwc", 0.0, B * H * W * c.out_channels * 4.0)
-                self._bias_grad(dy, G("conv_out.bias"), valid=c.out_channels)
-                self._wgrad(rec.x, None, rec.gn, 1, dy, G("conv_out.weight"), cout_valid=c.out_channels)
-                dz = self._dgrad(dy, tw.conv_out_d, boc0)
-                self._gn_bwd(rec.gn, dz, 1, wname="conv_norm_out")
-            elif k == "resnet":
-                self._resnet_bwd(rec)
-            elif k == "attn":
-                self._attn_bwd(rec)
-            elif k == "down":
-                if rec.e.padding != 1:
-                    raise NotImplementedError("training: Downsample2D with padding != 1")
-                dout = self._g(rec.out)[0]
-                self._bias_grad(dout, G(rec.name + ".conv.bias"))
-                self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), stride=2, pad=1)
-                self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], zero_stuff=True, into=self._g(rec.x))
-            elif k == "up":
-                dout = self._g(rec.out)[0]
-                self._bias_grad(dout, G(rec.name + ".conv.bias"))
-                self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), upsample=1)
-                du = self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], tag="du")
-                gx = self._g(rec.x)
-                _, h, ww, ch = rec.x.shape
-                a = L.Pool2x2Args(dtype=self.code, B=B, H=h, W=ww, C=ch, du=du.data_ptr(), dx=gx[0].data_ptr(),
-                                  accumulate=int(gx[1]))
-                gx[1] = True
-                self._drop_fused_sums(gx[0])
-                self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
-            elif k == "conv_in":
-                dout = self._g(rec.out)[0]
-                if self.input_grad:
-                    ops, self.ops = self.ops, self.bwd_ops
-                    try:
-                        self._conv(dout, None, tw.conv_in_d, self._zero_bias, c.in_channels, out_mode=L.PD_OUT_NCHW_F32,
-                                   cout_pad=32, y=self.dsample, stats=False)
-                    finally:
-                        self.ops = ops
-                    self.bwd_ops[-1].what = "dgrad3x3"
-                if not self.param_grads:
-                    continue
-                self._bias_grad(dout, G("conv_in.bias"))
-                cols = self._tmp((B, H, W, 32), "im2col")
-                a = L.Im2col3Args(dtype=self.code, B=B, H=H, W=W, C=c.in_channels, x=None, out=cols.data_ptr())
-                self._sample_ptr_args.append(a)
-                self._b(self.lib.pd_im2col3, a, "im2col3", 0.0, cols.numel() * self._esz())
-                self._wgrad(cols, None, None, 0, dout, G("conv_in.weight"), ksize=1, pad=0, cin_valid=c.in_channels * 9)
+            self._bwd_record(rec)
         if not self.param_grads:
             return
         self._temb_bwd()
@@ -362,6 +314,67 @@ class UNetTrainPlan(UNetPlan):
         self.slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
         for a in self._wgrad_args:
             a.slab, a.slab_bytes = self.slab.data_ptr(), need
+
+    def _bwd_record(self, rec):
+        """Emit the backward launches of one forward tape record."""
+        m, w, tw, c = self.m, self.w, self.tw, self.m.config
+        G = self._G
+        B, H, W = self.B, self.H, self.W
+        boc0 = c.block_out_channels[0]
+        k = rec.kind
+        if k == "conv_out":
+            dy = self._tmp((B, H, W, w.conv_out_pad), "dy_out")
+            a = L.NchwToNhwcArgs(dtype=self.code, B=B, C=c.out_channels, HW=H * W, Cpad=w.conv_out_pad, x=None,
+                                 out=dy.data_ptr())
+            self._dout_args = a
+            self._b(self.lib.pd_nchw_to_nhwc, a, "nchw_to_nhwc", 0.0, B * H * W * c.out_channels * 4.0)
+            self._bias_grad(dy, G("conv_out.bias"), valid=c.out_channels)
+            self._wgrad(rec.x, None, rec.gn, 1, dy, G("conv_out.weight"), cout_valid=c.out_channels)
+            dz = self._dgrad(dy, tw.conv_out_d, boc0)
+            self._gn_bwd(rec.gn, dz, 1, wname="conv_norm_out")
+        elif k == "resnet":
+            self._resnet_bwd(rec)
+        elif k == "attn":
+            self._attn_bwd(rec)
+        elif k == "down":
+            if rec.e.padding != 1:
+                raise NotImplementedError("training: Downsample2D with padding != 1")
+            dout = self._g(rec.out)[0]
+            self._bias_grad(dout, G(rec.name + ".conv.bias"))
+            self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), stride=2, pad=1)
+            self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], zero_stuff=True, into=self._g(rec.x))
+        elif k == "up":
+            dout = self._g(rec.out)[0]
+            self._bias_grad(dout, G(rec.name + ".conv.bias"))
+            self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), upsample=1)
+            du = self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], tag="du")
+            gx = self._g(rec.x)
+            _, h, ww, ch = rec.x.shape
+            a = L.Pool2x2Args(dtype=self.code, B=B, H=h, W=ww, C=ch, du=du.data_ptr(), dx=gx[0].data_ptr(),
+                              accumulate=int(gx[1]))
+            gx[1] = True
+            self._drop_fused_sums(gx[0])
+            self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
+        elif k == "conv_in":
+            dout = self._g(rec.out)[0]
+            if self.input_grad:
+                ops, self.ops = self.ops, self.bwd_ops
+                try:
+                    self._conv(dout, None, tw.conv_in_d, self._zero_bias, c.in_channels, out_mode=L.PD_OUT_NCHW_F32,
+                               cout_pad=32, y=self.dsample, stats=False)
+                finally:
+                    self.ops = ops
+                self.bwd_ops[-1].what = "dgrad3x3"
+            if not self.param_grads:
+                return
+            self._bias_grad(dout, G("conv_in.bias"))
+            cols = self._tmp((B, H, W, 32), "im2col")
+            a = L.Im2col3Args(dtype=self.code, B=B, H=H, W=W, C=c.in_channels, x=None, out=cols.data_ptr())
+            self._sample_ptr_args.append(a)
+            self._b(self.lib.pd_im2col3, a, "im2col3", 0.0, cols.numel() * self._esz())
+            self._wgrad(cols, None, None, 0, dout, G("conv_in.weight"), ksize=1, pad=0, cin_valid=c.in_channels * 9)
+        else:
+            raise NotImplementedError(f"backward of tape record {k!r}")
 
     def _resnet_bwd(self, rec):
         e, te = rec.e, self.tw.resnets[rec.name]
@@ -422,7 +435,7 @@ class UNetTrainPlan(UNetPlan):
                 db=G(first + ".time_emb_proj.bias", [r + ".time_emb_proj.bias" for r in res[1:]]).data_ptr()), "linear_wgrad")
         self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=pd, dy=self.dproj.data_ptr(),
                 w=P[first + ".time_emb_proj.weight"].data_ptr(), pre=self.t_emb.data_ptr(), dx=demb.data_ptr()), "linear_dgrad")
-        if m.class_embedding is not None:
+        if getattr(m, "class_embedding", None) is not None:
             self._emb_grad_args = L.EmbeddingGradArgs(rows=B, dim=tdim, num_classes=m.class_embedding.weight.shape[0], labels=None,
                                                       d=demb.data_ptr(), dtable=G("class_embedding.weight").data_ptr())
             self._emb_grad_at = len(self.bwd_ops)
@@ -600,8 +613,9 @@ class UNetTrainer:
             self._plans[key] = p
         return p
 
-    def forward_backward(self, noisy, timesteps, clean, noise, class_labels=None, class_emb=None):
-        """Loss of one batch and its parameter gradients (accumulated into the flat gradient buffer)."""
+    def forward_backward(self, noisy, timesteps, clean, noise, class_labels=None, class_emb=None, after_op=None):
+        """Loss of one batch and its parameter gradients (accumulated into the flat gradient buffer).  ``after_op``: hooks the
+        overlapped data-parallel path hangs on backward launches (gradient buckets becoming final)."""
         B, _, H, W = noisy.shape
         plan = self.plan_for(B, H, W)
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -612,7 +626,7 @@ class UNetTrainer:
         out = torch.empty_like(x)
         plan.forward(x, ts, labels, cemb, out, st)
         loss, dout = self.loss_fn(out, clean, noise, timesteps)
-        plan.backward(dout, st)
+        plan.backward(dout, st, after_op=after_op)
         return loss, out
 
     def step(self, noisy, timesteps, clean, noise, class_labels=None, class_emb=None, lr: Optional[float] = None, group=None,
@@ -631,9 +645,12 @@ class UNetTrainer:
         else:
             loss = self._forward_backward_overlapped(noisy, timesteps, clean, noise, class_labels, class_emb, group, world,
                                                      bucket_bytes)
-        self.opt.step(lr)
+        self._optimizer_step(lr)
         self.refresh_weights()
         return loss
+
+    def _optimizer_step(self, lr):
+        self.opt.step(lr)
 
     def _forward_backward_overlapped(self, noisy, timesteps, clean, noise, class_labels, class_emb, group, world, bucket_bytes):
         import torch.distributed as dist
@@ -662,15 +679,7 @@ class UNetTrainer:
         for start, end, rdy in self._buckets:
             prev = hooks.get(rdy)
             hooks[rdy] = (lambda s=start, e=end, p=prev: ((p() if p else None), launch(s, e)))
-        st = cur.cuda_stream
-        x = noisy.contiguous().float()
-        ts = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
-        labels = class_labels.to(device=self.device, dtype=torch.int64).contiguous() if class_labels is not None else None
-        cemb = class_emb.to(device=self.device, dtype=torch.float32).contiguous() if class_emb is not None else None
-        out = torch.empty_like(x)
-        plan.forward(x, ts, labels, cemb, out, st)
-        loss, dout = self.loss_fn(out, clean, noise, timesteps)
-        plan.backward(dout, st, after_op=hooks)
+        loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb, after_op=hooks)
         for wk in works:
             wk.wait()                      # the compute stream waits for the collectives, the host does not
         cur.wait_stream(comm)
