@@ -23,19 +23,23 @@ template <> __device__ __forceinline__ float dsilu_t<bf16_t>(float y) {
 
 // Thread -> (8-channel piece, pixel row) of one (sample, pixel split); the per-channel constants of the piece sit in
 // registers for the whole pixel loop.
+constexpr int GN_CHUNK = 1024;
+constexpr int GN_MAXC = 3072;
+
 template <typename T>
 struct GnPiece {
   int c8, cs, coff, dcs, dcoff;
   bool first, active;
   const T* xs; const T* ds;
   float mu[8], rs[8], sc[8], sh[8];
-  __device__ __forceinline__ void init(const pd_gn_bwd_args& a, int n, int tid, int& prow, int& ppi) {
-    const int C = a.C0 + a.C1, gs = C / a.groups, PP = C / 8;
+  // channels are walked in chunks of GN_CHUNK (blockIdx.y): cb = first channel of this workgroup's chunk, PP = its pieces
+  __device__ __forceinline__ void init(const pd_gn_bwd_args& a, int n, int tid, int cb, int PP, int& prow, int& ppi) {
+    const int C = a.C0 + a.C1, gs = C / a.groups;
     ppi = 256 / PP;
     active = tid < ppi * PP;
     const int piece = tid % PP;
     prow = tid / PP;
-    c8 = piece * 8;
+    c8 = cb + piece * 8;
     first = c8 < a.C0;
     xs = (const T*)(first ? a.x0 : a.x1);
     ds = (const T*)((first || a.dz_combined) ? a.dz0 : a.dz1);
@@ -55,14 +59,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args a) {
   using E = Elem<T>;
   __shared__ float red[256 * 16];
-  const int C = a.C0 + a.C1, PP = C / 8;
+  const int C = a.C0 + a.C1, cb = blockIdx.y * GN_CHUNK, Cc = min(C - cb, GN_CHUNK), PP = Cc / 8;
   const int n = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
   const int per = (a.HW + a.splits - 1) / a.splits;
   const int p0 = split * per, p1 = min(a.HW, p0 + per);
   const int tid = threadIdx.x;
   GnPiece<T> g;
   int prow, ppi;
-  g.init(a, n, tid, prow, ppi);
+  g.init(a, n, tid, cb, PP, prow, ppi);
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -90,18 +94,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const pd_gn_bwd_args
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < Cc; c += 256) {
     const int piece = c >> 3, j = c & 7;
     double d1 = 0.0, d2 = 0.0;
     for (int k = 0; k < ppi; ++k) { d1 += (double)red[(k * PP + piece) * 16 + j]; d2 += (double)red[(k * PP + piece) * 16 + 8 + j]; }
-    double* out = a.partial + (((size_t)n * a.splits + split) * C + c) * 2;
+    double* out = a.partial + (((size_t)n * a.splits + split) * C + cb + c) * 2;
     out[0] = d1; out[1] = d2;
   }
 }
 
 // (2) per-(sample, group) coefficients rstd*A/M, rstd*B/M and the parameter gradients dgamma, dbeta (+=)
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_args a) {
-  __shared__ double s1[1024], s2[1024];
+  __shared__ double s1[GN_MAXC], s2[GN_MAXC];
   const int C = a.C0 + a.C1, gs = C / a.groups, tid = threadIdx.x;
   if (blockIdx.x < (unsigned)a.B) {
     const int n = blockIdx.x;
@@ -149,9 +153,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args 
   const int per = (a.HW + a.splits - 1) / a.splits;
   const int p0 = split * per, p1 = min(a.HW, p0 + per);
   __shared__ float red[256 * 8];
+  const int cb = blockIdx.y * GN_CHUNK, Cc = min(C - cb, GN_CHUNK);
   GnPiece<T> g;
   int prow, ppi;
-  g.init(a, n, threadIdx.x, prow, ppi);
+  g.init(a, n, threadIdx.x, cb, Cc / 8, prow, ppi);
   T* dxp = (T*)(g.first ? a.dx0 : a.dx1);
   float* sump = g.first ? a.sum0 : a.sum1;         // optional per-(sample, split, channel) sums of the dx written here
   float cs_[8];
@@ -203,16 +208,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const pd_gn_bwd_args 
   }
   }
   if (a.sum0 || a.sum1) {              // workgroup-uniform
-    const int PP = C / 8;
+    const int PP = Cc / 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = cs_[j];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int cl = threadIdx.x; cl < Cc; cl += 256) {
+      const int c = cb + cl;
       const bool first = c < a.C0;
       float* sp = first ? a.sum0 : a.sum1;
       if (!sp) continue;
       float t = 0.f;
-      for (int k = 0; k < ppi; ++k) t += red[(k * PP + (c >> 3)) * 8 + (c & 7)];
+      for (int k = 0; k < ppi; ++k) t += red[(k * PP + (cl >> 3)) * 8 + (cl & 7)];
       const int cs = first ? a.C0 : a.C1, cc = first ? c : c - a.C0;
       sp[((size_t)n * a.splits + split) * cs + cc] = t;
     }
@@ -254,7 +260,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_args a) {
   using E = Elem<T>;
   __shared__ float red[256 * 8];
-  const int PP = a.C / 8, ppi = 256 / PP, nthr = ppi * PP;
+  const int c0 = blockIdx.y * 2048, Cc = min(a.C - c0, 2048);        // channels are walked in chunks of 2048 (blockIdx.y)
+  const int PP = Cc / 8, ppi = 256 / PP, nthr = ppi * PP;
   const int nsp = a.workspace ? a.splits : 1;
   const int n = blockIdx.x / nsp, sp = blockIdx.x - n * nsp, tid = threadIdx.x;
   const int per = (a.HW + nsp - 1) / nsp;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_a
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pu = p + u * ppi;
-        f[u] = pu < p_hi ? E::load((const T*)a.x + ((size_t)n * a.HW + pu) * a.C + piece * 8) : E::zero();
+        f[u] = pu < p_hi ? E::load((const T*)a.x + ((size_t)n * a.HW + pu) * a.C + c0 + piece * 8) : E::zero();
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -283,11 +290,11 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const pd_channel_sum_a
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[tid * 8 + j] = s[j];
   __syncthreads();
-  for (int c = tid; c < a.C; c += 256) {
+  for (int c = tid; c < Cc; c += 256) {
     double d = 0.0;
     for (int k = 0; k < ppi; ++k) d += (double)red[(k * PP + (c >> 3)) * 8 + (c & 7)];
-    if (a.workspace) { a.workspace[((size_t)n * nsp + sp) * a.C + c] = (float)d; continue; }
-    float* o = a.out + (size_t)n * a.out_stride + c;
+    if (a.workspace) { a.workspace[((size_t)n * nsp + sp) * a.C + c0 + c] = (float)d; continue; }
+    float* o = a.out + (size_t)n * a.out_stride + c0 + c;
     *o = a.accumulate ? *o + (float)d : (float)d;
   }
 }
@@ -402,21 +409,21 @@ using namespace pd;
 extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_gn_silu_bwd: null args");
   const int C = a->C0 + a->C1;
-  PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0 && C <= 1024, PD_ERR_SHAPE, "pd_gn_silu_bwd: bad shape");
-  PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0 && C / 8 <= 256, PD_ERR_SHAPE, "pd_gn_silu_bwd: groups=%d C=%d", a->groups, C);
+  PD_CHECK(a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0 && C <= GN_MAXC, PD_ERR_SHAPE, "pd_gn_silu_bwd: bad shape (C <= 3072)");
+  PD_CHECK(a->groups > 0 && a->groups <= 64 && C % a->groups == 0, PD_ERR_SHAPE, "pd_gn_silu_bwd: groups=%d C=%d", a->groups, C);
   PD_CHECK(a->x0 && a->dz0 && a->mean && a->rstd && a->gamma && a->beta && a->partial && a->coef && a->splits >= 1, PD_ERR_ARG, "pd_gn_silu_bwd: null pointer");
   PD_CHECK((a->C1 == 0) == (a->x1 == nullptr) && (a->C1 == 0 || a->dz_combined) == (a->dz1 == nullptr), PD_ERR_ARG, "pd_gn_silu_bwd: source 1 mismatch");
   PD_CHECK(a->dx0 || a->dx1, PD_ERR_ARG, "pd_gn_silu_bwd: no output");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned agrid = (unsigned)(a->B * a->splits);
+  const dim3 agrid((unsigned)(a->B * a->splits), (unsigned)((C + GN_CHUNK - 1) / GN_CHUNK));
   if (a->dtype == PD_F32) {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, agrid, dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 7) / 8), dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(agrid), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, agrid, dim3(256), 0, st, *a);
   } else if (a->dtype == PD_BF16) {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, agrid, dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 7) / 8), dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(agrid), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), 0, st, *a);
   } else { set_error("pd_gn_silu_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -434,13 +441,13 @@ extern "C" int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream) {
 }
 
 extern "C" int pd_channel_sum(const pd_channel_sum_args* a, void* stream) {
-  PD_CHECK(a != nullptr && a->B > 0 && a->HW > 0 && a->C > 0 && a->C % 8 == 0 && a->C / 8 <= 256 && a->out, PD_ERR_ARG, "pd_channel_sum: bad args");
+  PD_CHECK(a != nullptr && a->B > 0 && a->HW > 0 && a->C > 0 && a->C % 8 == 0 && a->out, PD_ERR_ARG, "pd_channel_sum: bad args");
   PD_CHECK(a->x || a->workspace, PD_ERR_ARG, "pd_channel_sum: x = NULL needs a pre-filled workspace (pd_gn_silu_bwd sum0/sum1)");
   PD_CHECK(!a->workspace || a->splits >= 1, PD_ERR_ARG, "pd_channel_sum: workspace without splits");
   const int nblk = a->B * (a->workspace ? a->splits : 1);
   if (!a->x) { /* per-split sums already in the workspace */ }
-  else if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a);
-  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, (a->C + 2047) / 2048), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nblk, (a->C + 2047) / 2048), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_channel_sum: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   if (a->total) PD_CHECK(a->total_valid > 0 && a->total_valid <= a->C, PD_ERR_ARG, "pd_channel_sum: total_valid=%d", a->total_valid);

@@ -376,14 +376,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
   }
 }
 
-// dgamma[c] += sum over workgroups of partial[wg][0][c], dbeta likewise (fixed order: bitwise reproducible)
+// dgamma[c] += sum over workgroups of partial[wg][0][c], dbeta likewise (fixed order: bitwise reproducible).
+// Workgroup = 16 columns x 16 row groups: row group r sums workgroups r, r+16, ...; the 16 shares are added in order.
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* partial, int nblocks, int C, float* dgamma, float* dbeta) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 2 * C) return;
+  __shared__ float red[16][17];
+  const int col = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + col;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 2 * C + idx];
-  float* dst = idx < C ? dgamma + idx : dbeta + (idx - C);
-  *dst += s;
+  if (idx < 2 * C)
+    for (int b = rg; b < nblocks; b += 16) s += partial[(size_t)b * 2 * C + idx];
+  red[rg][col] = s;
+  __syncthreads();
+  if (rg == 0 && idx < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][col];
+    float* dst = idx < C ? dgamma + idx : dbeta + (idx - C);
+    *dst += t;
+  }
 }
 
 // GEGLU backward: y = h * gelu(g)  ->  dh = dy * gelu(g),  dg = dy * h * (Phi(g) + g * phi(g));  dx = [dh | dg]
@@ -486,7 +496,7 @@ extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
   else { set_error("pd_layernorm_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   if (a->partial) {
-    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * a->C + 255) / 256), dim3(256), 0, st, (const float*)a->partial, grid, a->C,
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * a->C + 15) / 16), dim3(256), 0, st, (const float*)a->partial, grid, a->C,
                        a->dgamma, a->dbeta);
     PD_LAUNCH_CHECK();
   }
