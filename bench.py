@@ -226,13 +226,141 @@ def main_train(args, P, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
+def _sd_stack(P, args, dev, latent_only=False):
+    """Full-size latent-diffusion stack, random init (seed 0): SD-2.1 UNet (865.9 M), SD VAE (83.7 M), CustomEmbedding(2, 1024)."""
+    torch.manual_seed(0)
+    with torch.device(dev):
+        unet = P.SDUNet2DConditionModel(compute_dtype=args.dtype, **P.SD21_UNET_CONFIG)
+        emb = P.CustomEmbedding(2, 1024)
+        vae = None if latent_only else P.AutoencoderKL(compute_dtype=args.dtype)
+    return unet, vae, emb, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["SD_orig_config"])
+
+
+def _timed_steps(args, dev, dist, step):
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+def _plan_roofline(prof, dtype, method):
+    total_ms = sum(d["ms"] for d in prof.values())
+    kind, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    mfma = d["flops"] > 0
+    if mfma:
+        ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS[dtype], "TFLOP/s"
+    else:
+        ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+    return {"kernel": kind, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak, "unit": unit,
+            "frac": round(ach / peak, 4), "traffic": None, "launches": round(d["launches"]),
+            "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4), "share": round(d["ms"] / total_ms, 3), "method": method,
+            "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+            "per_kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["ms"] > 0 and v["flops"] > 0}}
+
+
+def main_sd_img2img(args, P, world, rank, dev, dist):
+    """configs[4]: custom_pipeline_stable_diffusion_img2img DDIB at 512x512 (64x64 latents): VAE encode -> S-step DDIM inversion
+    under the original class -> class swap -> S-step denoising -> VAE decode.  Images are independent: sharded, no collective."""
+    B, size, S = args.batch or 8, args.size or 512, args.inference_steps
+    unet, vae, emb, sched = _sd_stack(P, args, dev)
+    pipe = P.CustomStableDiffusionImg2ImgPipeline(vae, unet, sched, emb)
+    x, labels = synth_batch(B, size, 1234 + rank)
+    x, labels = x.to(dev), labels.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    P.ddib(pipe, x, labels, 1 - labels, 1, generator=gen)          # builds every launch plan
+    elapsed, out = _timed_steps(args, dev, dist, lambda: P.ddib(pipe, x, labels, 1 - labels, S, generator=gen))
+    assert out.shape == (B, size, size, 3)
+    value = world * B * args.steps / elapsed
+    res = {"metric": "SD img2img images/sec (VAE encode + 50-step DDIM invert + 50-step denoise + VAE decode, 512x512)",
+           "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"configs[4]: custom_pipeline_stable_diffusion_img2img DDIB, {size}x{size} images ({size // 8}x{size // 8} "
+                                  f"latents), {S}+{S} DDIM steps, SD-2.1 UNet (865.9 M) + SD VAE (83.7 M) + CustomEmbedding, random init, "
+                                  f"SD_orig_config / v_prediction, {B} images/GPU/step sharded over {world} GPU(s), no collectives",
+                      "batch_per_gpu": B, "global_batch": B * world, "inference_steps": S, "image_size": size}}
+    if rank == 0 and not args.no_roofline:
+        plan = next(p for k, p in unet._plans.items() if k[0] == B)
+        prof = plan._profile_ops(plan.ops, torch.cuda.current_stream(dev).cuda_stream, reps=2)
+        res["roofline"] = _plan_roofline(prof, args.dtype, "HIP events between consecutive launches of one SD-UNet forward (same plan "
+                                                           "and buffers as the timed region; 2*S of them per step)")
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_sd_train(args, P, world, rank, dev, dist):
+    """configs[3]: SD-2.1 UNet + CustomEmbedding fine-tuning at 64x64 latents (512 px), data-parallel.  One step = sampling
+    (noise, timesteps, add_noise on the latents) + _SD_prediction_wrapper forward + loss + backward + bucketed gradient
+    all-reduce (3.46 GB fp32, N > 1) + clip/AdamW/EMA + weight re-pack; every 10th step is unconditional (proba_uncond = 0.1)."""
+    from phendiff_amd.training import scaled_lr
+    B, size = args.batch or 8, args.size or 64
+    unet, _, emb, sched = _sd_stack(P, args, dev, latent_only=True)
+    tr = P.SDUNetTrainer(unet, emb, sched, lr=scaled_lr(1e-5, world))
+    g = torch.Generator().manual_seed(1234 + rank)
+    clean = (torch.randn(B, 4, size, size, generator=g) * 0.8).to(dev)       # VAE latents * scaling_factor have ~unit scale
+    labels = (torch.arange(B) % 2).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    count = [0]
+
+    def step():
+        noise = torch.randn(clean.shape, device=dev, generator=gen)
+        ts = torch.randint(0, sched.config.num_train_timesteps, (B,), device=dev, generator=gen)
+        noisy = sched.add_noise(clean, noise, ts)
+        count[0] += 1
+        return tr.step(noisy, ts, clean, noise, labels, unconditional=(count[0] % 10 == 0))
+
+    elapsed, loss = _timed_steps(args, dev, dist, step)
+    assert torch.isfinite(loss).all()
+    value = world * B * args.steps / elapsed
+    res = {"metric": "SD-2.1 UNet fine-tuning samples/sec (64x64 latents = 512x512, bf16)", "value": round(value, 3), "unit": "samples/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"configs[3]: SD-2.1 UNet (865.9 M, random init) + CustomEmbedding fine-tune, {size}x{size} latents, "
+                                  f"batch {B}/GPU on {world} GPU(s), SD_orig_config / v_prediction, AdamW(.95,.999) + clip 1.0 + EMA, "
+                                  "data-parallel gradient all-reduce (64 MB buckets) overlapped with the backward",
+                      "batch_per_gpu": B, "global_batch": B * world, "latent_size": size, "final_loss": round(float(loss), 5)}}
+    if rank == 0 and not args.no_roofline:
+        plan = tr.plan_for(B, size, size)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        prof = {}
+        for title, ops in (("fwd", plan.ops), ("bwd", plan.bwd_ops)):
+            for k, d in plan._profile_ops(ops, st, reps=1).items():
+                prof[f"{title}.{k}"] = d
+        torch.cuda.synchronize(dev)
+        res["roofline"] = _plan_roofline(prof, args.dtype, "HIP events between consecutive launches of one forward + backward (same plan and buffers)")
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="img2img", choices=["img2img", "train"],
-                    help="img2img = BASELINE.json's metric (default); train = configs[1], one optimisation step per 'step'")
+    ap.add_argument("--workload", default="img2img", choices=["img2img", "train", "sd_img2img", "sd_train"],
+                    help="img2img = BASELINE.json's metric (default); train = configs[1], one optimisation step per 'step'; "
+                         "sd_img2img = configs[4] (latent-diffusion DDIB at 512x512); sd_train = configs[3] (SD-2.1 UNet fine-tuning step)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; train: 112 = launch_script_DDIM.sh:52)")
     ap.add_argument("--size", type=int, default=None, help="image size (default 256; train: 128)")
     ap.add_argument("--inference-steps", type=int, default=50)
@@ -263,6 +391,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if args.workload == "train":
         return main_train(args, P, world, rank, dev, dist)
+    if args.workload == "sd_img2img":
+        return main_sd_img2img(args, P, world, rank, dev, dist)
+    if args.workload == "sd_train":
+        return main_sd_train(args, P, world, rank, dev, dist)
     args.batch, args.size = args.batch or 32, args.size or 256
 
     B, S, size = args.batch, args.inference_steps, args.size

@@ -34,4 +34,5 @@ from .pipeline_ref import (  # noqa: F401
     lp_loss_ref,
     custom_guided_generation_ref,
     linear_interp_custom_guidance_inverted_start_ref,
+    tensor_to_uint8_ref,
 )

@@ -124,3 +124,17 @@ def linear_interp_custom_guidance_inverted_start_ref(pipe, clean_images, orig_cl
 def numpy_to_uint8(images: np.ndarray) -> np.ndarray:
     """``DiffusionPipeline.numpy_to_pil`` quantisation: ``(images * 255).round().astype("uint8")``."""
     return (images * 255).round().astype("uint8")
+
+
+def tensor_to_uint8_ref(tensor: torch.Tensor, channel="mean") -> np.ndarray:
+    """``tensor_to_PIL`` (utils_Img2Img.py:96-150) up to the uint8 NHWC array it hands to ``Image.fromarray``."""
+    img = tensor.clone().detach()
+    if tensor.shape[1] == 4:
+        img -= img.min()
+        img /= img.max()
+        img = img.clamp(0, 1)
+        img = img[:, channel].view(tensor.shape[0], 1, tensor.shape[2], tensor.shape[3]) if isinstance(channel, int) \
+            else img.mean(dim=1, keepdim=True)
+    elif tensor.shape[1] == 3:
+        img = (img / 2 + 0.5).clamp(0, 1)
+    return (img.cpu().permute(0, 2, 3, 1).numpy() * 255).round().astype("uint8")

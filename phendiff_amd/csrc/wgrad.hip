@@ -223,10 +223,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
   }
 }
 
-// dw[co][ci][tap] (+)= sum over splits of slab[split][tap][co][ci].  Block = 64 consecutive slab elements (ci fastest:
-// coalesced) x 4 split groups; the groups are combined in a fixed order (bitwise reproducible).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int taps,
+// dw[co][ci][tap] (+)= sum over splits of slab[split][tap][co][ci], splits added in a fixed order (bitwise reproducible).
+// Workgroup = one co x 64 consecutive ci x all taps: the slab rows are read coalesced (ci fastest), transposed through LDS
+// and written as one contiguous run of 64*taps floats of dw (for a 3x3 conv the taps are the fastest dw index).
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
                                                             int COP, int CIP, int cout_valid, int cin_valid, int accumulate) {
+  __shared__ float tile[64 * TAPS];
+  const int tid = threadIdx.x;
+  const int ci_blocks = CIP / 64;
+  const int co = blockIdx.x / ci_blocks, ci0 = (blockIdx.x - co * ci_blocks) * 64;
+  if (co >= cout_valid) return;                        // workgroup-uniform
+  const size_t per = (size_t)TAPS * COP * CIP;
+  for (int e = tid; e < 64 * TAPS; e += 256) {
+    const int k = e >> 6, ci = e & 63;
+    const float* src = slab + ((size_t)k * COP + co) * CIP + ci0 + ci;
+    float s0 = 0.f, s1 = 0.f;                          // two chains: the loads of consecutive splits overlap
+    int sp = 0;
+    for (; sp + 2 <= splits; sp += 2) { s0 += src[(size_t)sp * per]; s1 += src[(size_t)(sp + 1) * per]; }
+    if (sp < splits) s0 += src[(size_t)sp * per];
+    tile[ci * TAPS + k] = s0 + s1;
+  }
+  __syncthreads();
+  const int nci = min(64, cin_valid - ci0);            // may be <= 0 for padded input channels
+  float* out = dw + ((size_t)co * cin_valid + ci0) * TAPS;
+  for (int e = tid; e < nci * TAPS; e += 256) out[e] = accumulate ? out[e] + tile[e] : tile[e];
+}
+
+// Many splits (small weights, many pixels): block = 64 consecutive slab elements x 4 split groups, combined in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_split_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int taps,
+                                                                  int COP, int CIP, int cout_valid, int cin_valid, int accumulate) {
   __shared__ float red[256];
   const int tid = threadIdx.x, sg = tid >> 6;
   const size_t per = (size_t)taps * COP * CIP;
@@ -271,34 +297,37 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ 
 // input-gradient weights W'[ci][co][K-1-ky][K-1-kx]; thread = one 8-element lane fragment
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const pd_pack_weight_args a) {
+  // workgroup = one (32-co tile, 32-ci chunk) of the packed matrix, all taps: the 32 x 32 x taps source block is read as 32
+  // contiguous runs (coalesced), staged in LDS, and every lane fragment is gathered from there
+  extern __shared__ float tile[];                      // [row o][col i * taps + t], row pitch 32*taps + 1
   const int taps = a.ksize * a.ksize;
-  const int chunks = a.cin_pad / 32, cts = a.cout_pad / 32;
-  const size_t total = (size_t)cts * chunks * taps * 2 * 64;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int lane = (int)(idx & 63);
-  size_t rest = idx >> 6;
-  const int sidx = (int)(rest & 1); rest >>= 1;
-  const int tap = (int)(rest % taps); rest /= taps;
-  const int chunk = (int)(rest % chunks);
-  const int ct = (int)(rest / chunks);
-  const int r = lane & 31, h = lane >> 5;
-  const int co = ct * 32 + r;
-  float v[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int ci = chunk * 32 + sidx * 16 + h * 8 + j;
+  const int chunks = a.cin_pad / 32;
+  const int ct = blockIdx.x / chunks, chunk = blockIdx.x - ct * chunks;
+  const int tid = threadIdx.x;
+  const int run = 32 * taps, pitch = run + 1;
+  // source block: forward rows o = co (ct), cols i = ci (chunk); input-gradient rows o = ci (chunk), cols i = co (ct)
+  const int o0 = a.dgrad ? chunk * 32 : ct * 32, i0 = a.dgrad ? ct * 32 : chunk * 32;
+  const int n_o = a.dgrad ? a.cin : a.cout, n_i = a.dgrad ? a.cout : a.cin;       // valid source rows / cols
+  for (int e = tid; e < 32 * run; e += 256) {
+    const int ro = e / run, c = e - ro * run;          // c = i_local * taps + t
+    const int i = i0 + c / taps;
     float x = 0.f;
-    if (co < a.cout && ci < a.cin) {
-      // packed (co, ci, tap) reads src[o][i][t]: forward o=co,i=ci,t=tap; input-gradient o=ci,i=co,t=taps-1-tap
-      const size_t o = a.dgrad ? ci : co, i = a.dgrad ? co : ci;
-      const int t = a.dgrad ? taps - 1 - tap : tap;
-      x = a.src[(o * a.src_in + i) * taps + t];
-    }
-    v[j] = x;
+    if (o0 + ro < n_o && i < n_i) x = a.src[((size_t)(o0 + ro) * a.src_in + i0) * taps + c];
+    tile[ro * pitch + c] = x;
   }
-  T* dst = (T*)a.dst + (size_t)ct * a.dst_ct_stride + ((((size_t)chunk * taps + tap) * 2 + sidx) * 64 + lane) * 8;
-  Elem<T>::store(dst, Elem<T>::pack(v));
+  __syncthreads();
+  for (int f = tid; f < taps * 2 * 64; f += 256) {
+    const int lane = f & 63, sidx = (f >> 6) & 1, tap = f >> 7;
+    const int r = lane & 31, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cl = sidx * 16 + h * 8 + j;            // ci within the chunk; co within the tile = r
+      v[j] = a.dgrad ? tile[cl * pitch + r * taps + (taps - 1 - tap)] : tile[r * pitch + cl * taps + tap];
+    }
+    T* dst = (T*)a.dst + (size_t)ct * a.dst_ct_stride + ((((size_t)chunk * taps + tap) * 2 + sidx) * 64 + lane) * 8;
+    Elem<T>::store(dst, Elem<T>::pack(v));
+  }
 }
 
 static int pick_splits(int ntiles, int ncombo) {
@@ -347,8 +376,12 @@ static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cf::LDS_BYTES, st, p);
   PD_LAUNCH_CHECK();
   const int cout_v = a->Cout_valid > 0 ? a->Cout_valid : a->Cout, cin_v = a->Cin_valid > 0 ? a->Cin_valid : cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((size_t)Cf::TAPS * p.COP * p.CIP / 64)), dim3(256), 0, st, (const float*)a->slab,
-                     a->dw, splits, Cf::TAPS, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
+  if (splits > 8)     // small weights spread over many pixel splits: parallelise over the splits
+    hipLaunchKernelGGL(wgrad_reduce_split_kernel, dim3((unsigned)((size_t)Cf::TAPS * p.COP * p.CIP / 64)), dim3(256), 0, st,
+                       (const float*)a->slab, a->dw, splits, Cf::TAPS, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
+  else                // large weights (few splits): coalesced transposing copy
+    hipLaunchKernelGGL(wgrad_reduce_kernel<Cf::TAPS>, dim3((unsigned)((size_t)p.COP * (p.CIP / 64))), dim3(256), 0, st, (const float*)a->slab,
+                       a->dw, splits, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
@@ -414,10 +447,10 @@ extern "C" int pd_pack_weight(const pd_pack_weight_args* a, void* stream) {
            "pd_pack_weight: padded sizes must be multiples of 32 (cout %d/%d, cin %d/%d)", a->cout, a->cout_pad, a->cin, a->cin_pad);
   const size_t per_ct = (size_t)(a->cin_pad / 32) * a->ksize * a->ksize * 2 * 64 * 8;
   PD_CHECK((size_t)a->dst_ct_stride >= per_ct, PD_ERR_ARG, "pd_pack_weight: dst_ct_stride too small");
-  const size_t total = (size_t)(a->cout_pad / 32) * (a->cin_pad / 32) * a->ksize * a->ksize * 2 * 64;
-  const unsigned grid = (unsigned)((total + 255) / 256);
-  if (a->dtype == PD_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
-  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  const unsigned grid = (unsigned)((a->cout_pad / 32) * (a->cin_pad / 32));
+  const size_t lds = (size_t)32 * (32 * a->ksize * a->ksize + 1) * sizeof(float);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);
   else { set_error("pd_pack_weight: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

@@ -170,6 +170,39 @@ def linear_interp_custom_guidance_inverted_start(pipe, clean_images, orig_class_
     return pipe.numpy_to_pil(arr) if output_type == "pil" else arr
 
 
+@torch.no_grad()
+def tensor_to_PIL(tensor: torch.Tensor, channel="mean"):
+    """``tensor_to_PIL`` (utils_Img2Img.py:96-150): (N, 3, H, W) images in [-1, 1] -> RGB PIL images through ``pd_postproc``
+    (``uint8 = round(255 * clamp(x/2 + 1/2, 0, 1))`` on the device); (N, 4, h, w) latents -> global min-max normalisation, then
+    one channel or the channel mean as a greyscale image (visualisation only).  One image is returned bare, like the reference."""
+    from PIL import Image
+    assert tensor.ndim == 4, "Expecting a tensor of shape (N, C, H, W)"
+    assert channel in ["mean"] + list(range(tensor.shape[1])), \
+        f"Expecting a channel in {list(range(tensor.shape[1]))} or 'mean', got {channel}"
+    if tensor.shape[1] == 4:
+        img = tensor.detach().float().clone()
+        img -= img.min()
+        img /= img.max()
+        img = img.clamp(0, 1)
+        img = img[:, channel:channel + 1] if isinstance(channel, int) else img.mean(dim=1, keepdim=True)
+        arr = (img.cpu().permute(0, 2, 3, 1).numpy() * 255).round().astype("uint8")
+    else:
+        assert float(tensor.min()) >= -1 and float(tensor.max()) <= 1, "Expecting values in [-1, 1]"
+        x = tensor.detach().contiguous().float()
+        if not x.is_cuda:
+            raise L.PhenDiffHipError("phendiff_amd runs on MI355X only (no CPU fallback): move the tensor to 'cuda'")
+        B, Cc, H, W = x.shape
+        out = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device)
+        a = L.PostprocArgs(B=B, C=Cc, H=H, W=W, x=x.data_ptr(), out_f32=None, out_u8=out.data_ptr())
+        L.check(L.lib().pd_postproc(C.byref(a), torch.cuda.current_stream(x.device).cuda_stream), "pd_postproc")
+        arr = out.cpu().numpy()
+    if arr.shape[-1] == 1:
+        pil = [Image.fromarray(im.squeeze(-1), mode="L") for im in arr]
+    else:
+        pil = [Image.fromarray(im) for im in arr]
+    return pil[0] if len(pil) == 1 else pil
+
+
 def swap_binary_labels(orig_class_labels: torch.Tensor) -> torch.Tensor:
     """``target = 1 - orig`` (utils_Img2Img.py:343-344): strictly binary datasets."""
     return 1 - orig_class_labels

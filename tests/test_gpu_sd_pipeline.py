@@ -110,3 +110,20 @@ def test_sd_pipeline_save_and_reload(tmp_path):
     lat = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(2)).cuda()
     kw = dict(image=lat, class_labels=[0, 1], strength=1, add_forward_noise_to_image=False, num_inference_steps=2, output_type="np")
     assert np.array_equal(pipe(**kw), p2(**kw))
+
+
+def test_tensor_to_pil():
+    import phendiff_amd as P
+    from oracle import tensor_to_uint8_ref
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(3, 3, 8, 10, generator=g) * 2 - 1
+    pil = P.tensor_to_PIL(x.cuda())
+    got = np.stack([np.asarray(im) for im in pil])
+    want = tensor_to_uint8_ref(x)
+    assert got.shape == want.shape == (3, 8, 10, 3) and int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1     # <= 1 LSB (A20)
+    lat = torch.randn(2, 4, 6, 6, generator=g)
+    for ch in ("mean", 2):
+        pil = P.tensor_to_PIL(lat.cuda(), ch)
+        got = np.stack([np.asarray(im) for im in pil])
+        assert pil[0].mode == "L" and np.array_equal(got, tensor_to_uint8_ref(lat, ch)[..., 0])
+    assert P.tensor_to_PIL(x[:1].cuda()).size == (10, 8)        # a single image is returned bare
