@@ -404,6 +404,25 @@ typedef struct {
 } pd_attn_d64_args;
 int pd_attn_d64(const pd_attn_d64_args* a, void* stream);
 
+/* pd_linear: y[m][n] = sum_k x[m][k] * W[n][k] + bias[n] (+ residual[m][n]) -- nn.Linear over M tokens as a dedicated MFMA GEMM
+ * (128 x 128 workgroup tiles, 64-channel K chunks).  Replaces the Linear layers of BasicTransformerBlock (attn1/attn2 to_q/k/v,
+ * to_out.0, FeedForward; reached from custom_pipeline_stable_diffusion_img2img.py:680-686 and utils_training.py:486-494) and,
+ * with the transposed weights (pd_pack_weight dgrad = 1), their input gradients.  w_packed: pd_conv's layout for a 1x1 kernel,
+ * [N_pad/32][K/32][1][2][64 lanes][8].  x rows may be strided (x_stride elements, >= K); y / residual are dense [M][N]. */
+typedef struct {
+  int dtype;
+  long long M;              /* rows (tokens) */
+  int K;                    /* input features, % 32 == 0 */
+  int N;                    /* output features, % 8 == 0 */
+  int N_pad;                /* packed output features, % 32 == 0 */
+  const void* x; int x_stride;
+  const void* w_packed;
+  const float* bias;        /* [N_pad] */
+  const void* residual;     /* [M][N] or NULL */
+  void* y;                  /* [M][N] */
+} pd_linear_args;
+int pd_linear(const pd_linear_args* a, void* stream);
+
 /* pd_attn_wide: softmax(q k^T * scale) v with ONE wide head per D channels, D in {128, 256, 512} -- the mid-block attention of
  * the SD VAE (diffusers AutoencoderKL: Encoder/Decoder.mid_block.attentions[0], a single head over all 512 channels;
  * vae.encode / vae.decode at custom_pipeline_stable_diffusion_img2img.py:431,709-711).  Operand addressing as pd_attn_d64

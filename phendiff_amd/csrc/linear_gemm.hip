@@ -1,0 +1,282 @@
+// pd_linear: Y[m][n] = sum_k X[m][k] W[n][k] + bias[n] (+ R[m][n]) -- nn.Linear over NHWC tokens as a dedicated MFMA GEMM.
+// Replaces the Linear layers of diffusers' BasicTransformerBlock inside UNet2DConditionModel (attn1 / attn2 projections and
+// to_out, FeedForward; custom_pipeline_stable_diffusion_img2img.py:680-686, utils_training.py:486-494) and, with the transposed
+// weights, their input gradients.  pd_conv runs a 1x1 convolution with its 3x3 machinery (32-channel chunks, one barrier per
+// 8 MFMAs and a 64-channel output tile per staged activation tile); here the tile is shaped for a plain GEMM:
+//   workgroup = 4 waves = 128 tokens x 128 output channels, wave = 64 x 64 (2 x 2 MFMA tiles: every A and every B fragment
+//   feeds two MFMAs), K in chunks of 64 channels staged global -> registers -> LDS (double-buffered, one barrier per 16
+//   MFMAs per wave), weights in pd_conv's packed fragment order straight from L2 (1 KiB coalesced per fragment).
+// Operand conventions are pd_conv's: B fragment = lane (token r, half h) holds channels 16 s + 8 h + (0..7) of a k-step,
+// D: lane owns a token, register i <-> channel 8 (i>>2) + 4 h + (i&3) of a 32-channel tile.
+#include "pd_common.h"
+#include <type_traits>
+#include "pd_stage.h"
+
+namespace pd {
+
+struct LinP {
+  long long M;
+  int K, N, N_pad, x_stride;
+  int t_tiles, c_tiles;
+  unsigned xbytes;
+  const void* x; const void* w; const float* bias; const void* residual; void* y;
+};
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  using SR = typename Stage<T>::R;
+  constexpr int ES = E::BYTES;
+  constexpr int TM = 128, TN = 64 * NC, CK = 64;
+  constexpr int PITCH = CK * ES + 16;                  // odd number of 16-B slots: conflict-free ds_read_b128 over 32 tokens
+  constexpr int XTILE = TM * PITCH;
+  constexpr int NIT = TM * CK / 8 / 256;               // 8-channel pieces per thread per chunk (4)
+  constexpr int EP_PITCH = TN * ES + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][XTILE] | epilogue [TM][EP_PITCH]
+
+  // block -> (token tile, channel tile): the channel tiles of one token tile are 8 blocks apart in dispatch order, i.e. on
+  // the same XCD / L2 (the X tile is fetched from HBM once) whenever the number of token tiles is a multiple of 8
+  int tt, ct;
+  {
+    const int b = blockIdx.x;
+    if ((p.t_tiles & 7) == 0) { tt = (b & 7) + 8 * (b / (8 * p.c_tiles)); ct = (b >> 3) % p.c_tiles; }
+    else { ct = b % p.c_tiles; tt = b / p.c_tiles; }
+  }
+  const long long m0 = (long long)tt * TM;
+  const int n0 = ct * TN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int ksteps = p.K / 16;
+  const int last_ct32 = p.N_pad / 32 - 1;
+  // channel tiles beyond N_pad do not exist in w_packed: clamp (the garbage is never stored)
+  int ct32[NC];
+  const T* wb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ct32[c] = min(n0 / 32 + wc * NC + c, last_ct32);
+    wb[c] = (const T*)p.w + (size_t)ct32[c] * ksteps * 512 + lane * 8;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  unsigned soff[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int pc = tid + 256 * i, tok = pc >> 3, sub = pc & 7;
+    const long long m = m0 + tok;
+    soff[i] = m < p.M ? (unsigned)(((size_t)m * p.x_stride + sub * 8) * ES) : OOB_OFF;
+  }
+  SR stage[NIT];
+  auto issue = [&](int chunk) {
+    const unsigned cb = (unsigned)(chunk * CK * ES);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) stage[i] = Stage<T>::load(rsx, soff[i] == OOB_OFF ? OOB_OFF : soff[i] + cb);
+  };
+  auto commit = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int pc = tid + 256 * i, tok = pc >> 3, sub = pc & 7;
+      if constexpr (ES == 2) *(u32x4*)(buf + tok * PITCH + sub * 16) = stage[i].v;
+      else { *(u32x4*)(buf + tok * PITCH + sub * 32) = stage[i].a; *(u32x4*)(buf + tok * PITCH + sub * 32 + 16) = stage[i].b; }
+    }
+  };
+
+  // accumulators start at the bias: acc[c][f] = channel tile c (0/1) x token fragment f (0/1)
+  f32x16 acc[NC][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    f32x16 init;
+    const int cob = ct32[c] * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(p.bias + cob + 8 * g + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) init[4 * g + i] = bv[i];
+    }
+    acc[c][0] = init; acc[c][1] = init;
+  }
+
+  const int nchunks = p.K / CK, tail_ksteps = (p.K % CK) / 16;     // K % 32 == 0: a trailing half chunk of 2 k-steps is possible
+  const int total_chunks = nchunks + (tail_ksteps ? 1 : 0);
+  const int b_lane = (wp * 64 + r) * PITCH + 8 * h * ES;
+
+  if constexpr (NC == 2) {
+    // wide tiles (big grids): weight fragments one k-step ahead in registers, activation fragments read at the top of the
+    // k-step; deeper rings / unrolled k-steps cost a wave of occupancy, which pays more here (measured) -- the other
+    // resident waves cover both latencies
+    Frag a[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a[c] = E::load(wb[c]);
+    issue(0);
+    commit(lds);
+    if (total_chunks > 1) issue(1);
+    __syncthreads();
+    for (int chunk = 0; chunk < total_chunks; ++chunk) {
+      const unsigned char* buf = lds + (chunk & 1) * XTILE;
+      const int nks = (chunk < nchunks) ? CK / 16 : tail_ksteps;
+      const int g0 = chunk * (CK / 16);
+      for (int ks = 0; ks < nks; ++ks) {
+        const int gn = min(g0 + ks + 1, ksteps - 1);   // next k-step's weight fragments (clamped at the end)
+        Frag an[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) an[c] = E::load(wb[c] + (size_t)gn * 512);
+        const Frag b0 = E::load(buf + b_lane + ks * 16 * ES), b1 = E::load(buf + b_lane + 32 * PITCH + ks * 16 * ES);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          acc[c][0] = E::mma(a[c], b0, acc[c][0]);
+          acc[c][1] = E::mma(a[c], b1, acc[c][1]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a[c] = an[c];
+      }
+      if (chunk + 1 < total_chunks) {
+        commit(lds + ((chunk + 1) & 1) * XTILE);
+        if (chunk + 2 < total_chunks) issue(chunk + 2);
+      }
+      __syncthreads();
+    }
+  } else {
+    // narrow tiles (small grids, long K per workgroup): the per-workgroup latency chain matters -- weight fragments in a
+    // register ring AD k-steps ahead, continuously across chunk boundaries, activation fragments one k-step ahead
+    constexpr int AD = 2, AR = 4;                      // AR divides the 4 k-steps of a chunk: static ring indices
+    Frag aring[AR][NC];
+    const int last_kstep = ksteps - 1;
+    auto compute = [&](int chunk, const unsigned char* buf, auto nks_c) {
+      constexpr int NKS = decltype(nks_c)::value;
+      const int g0 = chunk * (CK / 16);
+      Frag bc[2], bn[2];
+      bc[0] = E::load(buf + b_lane); bc[1] = E::load(buf + b_lane + 32 * PITCH);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int gp = min(g0 + ks + AD, last_kstep);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aring[(ks + AD) % AR][c] = E::load(wb[c] + (size_t)gp * 512);
+        if (ks + 1 < NKS) {
+          bn[0] = E::load(buf + b_lane + (ks + 1) * 16 * ES); bn[1] = E::load(buf + b_lane + 32 * PITCH + (ks + 1) * 16 * ES);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          acc[c][0] = E::mma(aring[ks % AR][c], bc[0], acc[c][0]);
+          acc[c][1] = E::mma(aring[ks % AR][c], bc[1], acc[c][1]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        bc[0] = bn[0]; bc[1] = bn[1];
+      }
+    };
+    issue(0);
+#pragma unroll
+    for (int i = 0; i < AD; ++i)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) aring[i][c] = E::load(wb[c] + (size_t)min(i, last_kstep) * 512);
+    commit(lds);
+    if (total_chunks > 1) issue(1);
+    __syncthreads();
+    for (int chunk = 0; chunk < total_chunks; ++chunk) {
+      const unsigned char* buf = lds + (chunk & 1) * XTILE;
+      if (chunk < nchunks) compute(chunk, buf, std::integral_constant<int, CK / 16>{});
+      else compute(chunk, buf, std::integral_constant<int, 2>{});         // trailing half chunk (K % 64 == 32)
+      if (chunk + 1 < total_chunks) {
+        commit(lds + ((chunk + 1) & 1) * XTILE);
+        if (chunk + 2 < total_chunks) issue(chunk + 2);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: [token][128 channels] through LDS, then coalesced 16-byte residual loads / stores
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int tok = wp * 64 + f * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        store4((T*)(lds + tok * EP_PITCH) + (wc * NC + c) * 32 + 8 * g + 4 * h, acc[c][f][4 * g], acc[c][f][4 * g + 1], acc[c][f][4 * g + 2],
+               acc[c][f][4 * g + 3]);
+    }
+  __syncthreads();
+  constexpr int EPC = 16 / ES;                         // channels per 16-byte piece
+  constexpr int PPT = TN / EPC;                        // pieces per token
+  constexpr int TPI = 256 / PPT;                       // tokens per iteration
+  const int piece = tid % PPT, trow = tid / PPT;
+  const int co = n0 + piece * EPC;
+  if (co < p.N) {
+#pragma unroll 4
+    for (int it = 0; it < TM / TPI; ++it) {
+      const int tok = it * TPI + trow;
+      const long long m = m0 + tok;
+      if (m >= p.M) continue;
+      u32x4 v = *(const u32x4*)(lds + tok * EP_PITCH + piece * 16);
+      if (p.residual) {
+        const u32x4 rr = *(const u32x4*)((const T*)p.residual + (size_t)m * p.N + co);
+        if constexpr (ES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(v[j] << 16) + __uint_as_float(rr[j] << 16);
+            const float hi = __uint_as_float(v[j] & 0xffff0000u) + __uint_as_float(rr[j] & 0xffff0000u);
+            v[j] = pack2bf(lo, hi);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(__uint_as_float(v[j]) + __uint_as_float(rr[j]));
+        }
+      }
+      *(u32x4*)((T*)p.y + (size_t)m * p.N + co) = v;
+    }
+  }
+}
+
+template <typename T, int NC>
+static int launch_linear(const LinP& p, hipStream_t st) {
+  constexpr int ES = Elem<T>::BYTES;
+  constexpr int XT = 128 * (64 * ES + 16), EPI = 128 * (64 * NC * ES + 16);
+  constexpr int LDS = 2 * XT > EPI ? 2 * XT : EPI;
+  auto kern = linear_kernel<T, NC>;
+  if (LDS > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        set_error("pd_linear: cannot reserve %d bytes of LDS", LDS);
+        return PD_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.t_tiles * p.c_tiles)), dim3(256), LDS, st, p);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+}  // namespace pd
+
+using namespace pd;
+
+extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_linear: null args");
+  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16, PD_ERR_ARG, "pd_linear: bad dtype %d", a->dtype);
+  PD_CHECK(a->M > 0 && a->K > 0 && a->K % 32 == 0 && a->N > 0 && a->N % 8 == 0 && a->N_pad >= a->N && a->N_pad % 32 == 0, PD_ERR_SHAPE,
+           "pd_linear: M=%lld K=%d (multiple of 32) N=%d (multiple of 8) N_pad=%d (multiple of 32)", a->M, a->K, a->N, a->N_pad);
+  PD_CHECK(a->x_stride >= a->K && a->x_stride % 8 == 0, PD_ERR_SHAPE, "pd_linear: x_stride must cover K and be a multiple of 8");
+  PD_CHECK(a->x && a->w_packed && a->bias && a->y, PD_ERR_ARG, "pd_linear: null pointer");
+  const size_t esz = a->dtype == PD_F32 ? 4 : 2;
+  const size_t xbytes = ((size_t)(a->M - 1) * a->x_stride + a->K) * esz;
+  PD_CHECK(xbytes < 0x80000000ull, PD_ERR_SHAPE, "pd_linear: input exceeds 2 GiB (32-bit buffer offsets); split the rows");
+  LinP p{};
+  p.M = a->M; p.K = a->K; p.N = a->N; p.N_pad = a->N_pad; p.x_stride = a->x_stride;
+  p.t_tiles = (int)((a->M + 127) / 128); p.c_tiles = (a->N_pad + 127) / 128;
+  PD_CHECK((long long)p.t_tiles * p.c_tiles < (1ll << 30), PD_ERR_SHAPE, "pd_linear: grid too large");
+  // 128-channel tiles halve the LDS reads per MFMA; 64-channel tiles when those would leave most of the 256 CUs (x 3
+  // resident workgroups) idle
+  const bool narrow = (long long)p.t_tiles * p.c_tiles < 512;
+  if (narrow) p.c_tiles = (a->N_pad + 63) / 64;
+  p.xbytes = (unsigned)xbytes;
+  p.x = a->x; p.w = a->w_packed; p.bias = a->bias; p.residual = a->residual; p.y = a->y;
+  if (a->dtype == PD_F32) return narrow ? launch_linear<float, 1>(p, (hipStream_t)stream) : launch_linear<float, 2>(p, (hipStream_t)stream);
+  return narrow ? launch_linear<bf16_t, 1>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2>(p, (hipStream_t)stream);
+}

@@ -336,6 +336,20 @@ class SDUNetPlan(UNetPlan):
         self.ops.append(_Op(self.lib.pd_layernorm, a, "layernorm", 0.0, 2.0 * x.numel() * self._esz()))
         return y
 
+    def _linear(self, x, wpk, bias, cout, residual=None, y=None, what="linear"):
+        """nn.Linear over the tokens of an NHWC tensor through the dedicated GEMM (``pd_linear``); ``wpk`` is pd_conv's packed
+        1x1 layout, so forward and input-gradient weights are shared with the convolution path."""
+        B, h, w, K = x.shape
+        if y is None:
+            y = self._act(h, w, cout)
+        M = B * h * w
+        a = L.LinearArgs(dtype=self.code, M=M, K=K, N=cout, N_pad=((cout + 31) // 32) * 32, x=x.data_ptr(), x_stride=K,
+                         w_packed=wpk.data_ptr(), bias=bias.data_ptr(), residual=L.ptr(residual), y=y.data_ptr())
+        esz = self._esz()
+        self.ops.append(_Op(self.lib.pd_linear, a, what, 2.0 * M * K * cout,
+                            (M * K + M * cout * (2 if residual is not None else 1) + K * cout) * esz))
+        return y
+
     def _attention(self, q, qs, k, v, kvs, heads, nq, nkv):
         out = self._act(1, nq, heads * 64).view(self.B, 1, nq, heads * 64)
         lse = self._f32(self.B, heads, nq) if self.train else None
@@ -349,9 +363,9 @@ class SDUNetPlan(UNetPlan):
         e, zb = self.w.transformers[name], self.w.zero_bias
         B, h, w, ch = x.shape
         N, esz = h * w, self._esz()
-        lin = lambda src, wt, bias, cout, **kw: self._conv(src, None, wt, bias, cout, ksize=1, pad=0, stats=False, **kw)[0]
+        lin = lambda src, wt, bias, cout, residual=None: self._linear(src, wt, bias, cout, residual)
         gn = self._gn(x, None, e.g, e.be, e.eps)
-        h0 = lin(x, e.w_in, e.b_in, ch, gn=gn)
+        h0, _ = self._conv(x, None, e.w_in, e.b_in, ch, ksize=1, pad=0, stats=False, gn=gn)     # GroupNorm applied while staging
         # self attention
         y1 = self._layernorm(h0, e.ln1)
         qkv = lin(y1, e.wqkv1, zb, 3 * ch)

@@ -164,6 +164,24 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         else:
             super()._bwd_record(rec)
 
+    def _dgrad(self, dy, wpk, cout, *, ksize=3, zero_stuff=False, into=None, tag="dz"):
+        """Input gradients of the Linear layers go through ``pd_linear`` (same packed transposed weights as ``pd_conv``)."""
+        if ksize != 1 or zero_stuff:
+            return super()._dgrad(dy, wpk, cout, ksize=ksize, zero_stuff=zero_stuff, into=into, tag=tag)
+        B, h, w, _ = dy.shape
+        if into is not None:
+            y, res = into[0], (into[0] if into[1] else None)
+            into[1] = True
+            self._drop_fused_sums(into[0])
+        else:
+            y, res = self._tmp((B, h, w, cout), tag), None
+        ops, self.ops = self.ops, self.bwd_ops
+        try:
+            self._linear(dy, wpk, self._zero_bias, cout, residual=res, y=y, what="dgrad_linear")
+        finally:
+            self.ops = ops
+        return y
+
     def _ln_bwd(self, x, ln, pname, dy, res, tag):
         gamma, _, eps = ln
         B, h, w, ch = x.shape

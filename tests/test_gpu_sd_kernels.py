@@ -165,3 +165,34 @@ def test_geglu_backward(env, mode):
     L.check(lib.pd_geglu_bwd(C.byref(a), stream()), "pd_geglu_bwd")
     torch.cuda.synchronize()
     assert rel(dx.float(), x.grad) < (2e-6 if mode == "f32" else 4e-3)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(1024, 320, 960, 0, 0), (300, 64, 64, 1, 0), (2048, 1280, 10240, 0, 0), (77 * 3, 96, 256, 0, 0), (515, 5120, 1280, 1, 0),
+                                 (4096, 96, 320, 1, 32), (130, 32, 8, 0, 0)])
+def test_linear_gemm(env, mode, cfg):
+    """pd_linear against F.linear: full / ragged token tiles, K with a trailing half chunk (96, 32), N not a multiple of the
+    128-channel tile, residual, strided input rows (a slice of a fused projection's output)."""
+    from phendiff_amd.packing import pack_conv_weight
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    M, K, N, with_res, xpad = cfg
+    g = torch.Generator().manual_seed(61)
+    xs = K + xpad
+    xfull = bf16_round(torch.randn(M, xs, generator=g), mode)
+    w = bf16_round(torch.randn(N, K, generator=g) / K ** 0.5, mode)
+    bias = torch.randn(N, generator=g)
+    res = bf16_round(torch.randn(M, N, generator=g), mode) if with_res else None
+    npad = ((N + 31) // 32) * 32
+    wp = pack_conv_weight(w[:, :, None, None], tdt, npad).to(dev)
+    bp = torch.zeros(npad)
+    bp[:N] = bias
+    X, Bv = xfull.to(tdt).to(dev), bp.to(dev)
+    R = res.to(tdt).to(dev) if with_res else None
+    y = torch.full((M, N), float("nan"), dtype=tdt, device=dev)
+    a = L.LinearArgs(dtype=code, M=M, K=K, N=N, N_pad=npad, x=X.data_ptr(), x_stride=xs, w_packed=wp.data_ptr(), bias=Bv.data_ptr(),
+                     residual=L.ptr(R), y=y.data_ptr())
+    L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+    torch.cuda.synchronize()
+    ref = F.linear(xfull[:, :K], w, bias) + (res if with_res else 0)
+    assert rel(y.float(), ref) < (2e-6 if mode == "f32" else 4e-3)
