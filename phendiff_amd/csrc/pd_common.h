@@ -50,6 +50,17 @@ __device__ __forceinline__ float silu_fast(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 }
 
+// two lanes of fp32 per instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 run at full rate on CDNA: half the VALU issue
+// slots of the scalar form); the transcendentals stay scalar
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 silu_fast2(f32x2 v) {
+  const f32x2 t = v * (f32x2)(-1.4426950408889634f);
+  f32x2 e; e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = e + (f32x2)(1.0f);
+  f32x2 r; r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return v * r;
+}
+
 // ---- element traits: an "8-element fragment" is what one lane feeds to one MFMA k16-step ----------
 template <typename T> struct Elem;
 template <> struct Elem<float> {

@@ -23,10 +23,11 @@ template <> struct Stage<bf16_t> {
     if (affine || silu) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float lo = __uint_as_float(in.v[j] << 16), hi = __uint_as_float(in.v[j] & 0xffff0000u);
-        if (affine) { lo = lo * sc[2 * j] + sh[2 * j]; hi = hi * sc[2 * j + 1] + sh[2 * j + 1]; }
-        if (silu) { lo = silu_fast(lo); hi = silu_fast(hi); }
-        o[j] = pack2bf(lo, hi);
+        f32x2 x;                                     // packed fp32 math: one VALU slot per channel pair
+        x.x = __uint_as_float(in.v[j] << 16); x.y = __uint_as_float(in.v[j] & 0xffff0000u);
+        if (affine) x = x * (f32x2){sc[2 * j], sc[2 * j + 1]} + (f32x2){sh[2 * j], sh[2 * j + 1]};
+        if (silu) x = silu_fast2(x);
+        o[j] = pack2bf(x.x, x.y);
       }
       if (!valid) o = (u32x4)(0u);
     }
