@@ -404,6 +404,17 @@ typedef struct {
 } pd_attn_d64_args;
 int pd_attn_d64(const pd_attn_d64_args* a, void* stream);
 
+/* pd_gn_apply: y = silu?(GroupNorm([x0 | x1])) materialised once (scale / shift from pd_gn_finalize): the GroupNorm-apply +
+ * SiLU of ResnetBlock2D.norm1/norm2 (diffusers resnet.py; cond_unet_2d.py:171,187,217 and the SD UNet / VAE blocks) for layers
+ * whose convolution has many 64-channel output tiles, where pd_conv's in-flight transform would be repeated per tile. */
+typedef struct {
+  int dtype; int B, HW, C0, C1; int silu;
+  const void* x0; const void* x1;
+  const float* scale; const float* shift;   /* [B][C0+C1] */
+  void* y;                                  /* NHWC [B][HW][C0+C1] */
+} pd_gn_apply_args;
+int pd_gn_apply(const pd_gn_apply_args* a, void* stream);
+
 /* pd_linear: y[m][n] = sum_k x[m][k] * W[n][k] + bias[n] (+ residual[m][n]) -- nn.Linear over M tokens as a dedicated MFMA GEMM
  * (128 x 128 workgroup tiles, 64-channel K chunks).  Replaces the Linear layers of BasicTransformerBlock (attn1/attn2 to_q/k/v,
  * to_out.0, FeedForward; reached from custom_pipeline_stable_diffusion_img2img.py:680-686 and utils_training.py:486-494) and,

@@ -117,6 +117,11 @@ class AttnD64Args(C.Structure):
                 ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp), ("out_stride", C.c_int), ("lse", vp)]
 
 
+class GnApplyArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C0", C.c_int), ("C1", C.c_int), ("silu", C.c_int),
+                ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("y", vp)]
+
+
 class LinearArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_longlong), ("K", C.c_int), ("N", C.c_int), ("N_pad", C.c_int), ("x", vp),
                 ("x_stride", C.c_int), ("w_packed", vp), ("bias", vp), ("residual", vp), ("y", vp)]
@@ -234,6 +239,7 @@ SYMBOLS = {
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
     "pd_attn_d64": (C.c_int, [C.POINTER(AttnD64Args), vp]),
+    "pd_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
     "pd_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "pd_attn_wide": (C.c_int, [C.POINTER(AttnWideArgs), vp]),
     "pd_latent_sample": (C.c_int, [C.POINTER(LatentSampleArgs), vp]),

@@ -215,9 +215,51 @@ __global__ __launch_bounds__(256) void latent_sample_kernel(const pd_latent_samp
   }
 }
 
+// GroupNorm apply (+ SiLU) as its own pass: y[n][p][c] = silu?(x[n][p][c] * scale[n][c] + shift[n][c]) over the channel concat
+// [x0 | x1].  pd_conv applies this transform while staging, once per 64-channel OUTPUT tile: with Cout = 1280 the same halo
+// tile is transformed 20 times and the exp/rcp issue slots, not the MFMAs, pace the convolution.  Wide layers therefore read
+// a tensor normalised once here (one extra bandwidth-bound pass) and run pd_conv without a prologue.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const pd_gn_apply_args a) {
+  using E = Elem<T>;
+  const int C = a.C0 + a.C1, PP = C / 8;
+  const size_t total = (size_t)a.B * a.HW * PP;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int piece = (int)(idx % PP);
+    const size_t pix = idx / PP;                       // n * HW + p
+    const int n = (int)(pix / a.HW);
+    const int c8 = piece * 8;
+    const bool first = c8 < a.C0;
+    const T* src = first ? (const T*)a.x0 + pix * a.C0 + c8 : (const T*)a.x1 + pix * a.C1 + (c8 - a.C0);
+    typename Stage<T>::R r;
+    if constexpr (E::BYTES == 2) r.v = *(const u32x4*)src;
+    else { r.a = *(const u32x4*)src; r.b = *((const u32x4*)src + 1); }
+    float sc[8], sh[8];
+    const float* ps = a.scale + (size_t)n * C + c8;
+    const float* pb = a.shift + (size_t)n * C + c8;
+    const f32x4 s0 = *(const f32x4*)ps, s1 = *((const f32x4*)ps + 1), b0 = *(const f32x4*)pb, b1 = *((const f32x4*)pb + 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sc[4 + j] = s1[j]; sh[j] = b0[j]; sh[4 + j] = b1[j]; }
+    Stage<T>::xform_store((unsigned char*)((T*)a.y + pix * C + c8), r, sc, sh, true, a.silu != 0, true);   // the conv's own transform
+  }
+}
+
 }  // namespace pd
 
 using namespace pd;
+
+extern "C" int pd_gn_apply(const pd_gn_apply_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->B > 0 && a->HW > 0 && a->C0 > 0 && a->C0 % 8 == 0 && a->C1 >= 0 && a->C1 % 8 == 0, PD_ERR_SHAPE,
+           "pd_gn_apply: bad shape");
+  PD_CHECK(a->x0 && a->scale && a->shift && a->y && ((a->C1 == 0) == (a->x1 == nullptr)), PD_ERR_ARG, "pd_gn_apply: null pointer / x1 mismatch");
+  const size_t total = (size_t)a->B * a->HW * ((a->C0 + a->C1) / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else { set_error("pd_gn_apply: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
 
 extern "C" int pd_latent_sample(const pd_latent_sample_args* a, void* stream) {
   PD_CHECK(a != nullptr && a->B > 0 && a->C > 0 && a->HW > 0 && a->moments && a->out, PD_ERR_ARG, "pd_latent_sample: bad args");

@@ -508,16 +508,34 @@ class UNetPlan:
         self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}", flops, nbytes))
         return y, a
 
+    # pd_conv applies GroupNorm + SiLU while staging, once per 64-channel output tile; from this many output channels on
+    # (inference plans) the input is normalised ONCE by pd_gn_apply instead and the convolution runs without a prologue
+    PREAPPLY_MIN_COUT = 320      # measured: a win from 5 output tiles on (SD UNet: 7.7 vs 9.4 ms of 3x3 convs per forward), neutral at 4
+
+    def _gn_apply(self, x0, x1, gn, silu):
+        B, h, w, c0 = x0.shape
+        c1 = x1.shape[3] if x1 is not None else 0
+        y = self._act(h, w, c0 + c1)
+        a = L.GnApplyArgs(dtype=self.code, B=B, HW=h * w, C0=c0, C1=c1, silu=silu, x0=x0.data_ptr(), x1=L.ptr(x1),
+                          scale=gn[0].data_ptr(), shift=gn[1].data_ptr(), y=y.data_ptr())
+        self.ops.append(_Op(self.lib.pd_gn_apply, a, "gn_apply", 0.0, 2.0 * y.numel() * (2 if self.code == L.PD_BF16 else 4)))
+        return y
+
     def _resnet(self, name, x0, x1=None):
         e = self.w.resnets[name]
+        pre = (not self.train) and e.cout >= self.PREAPPLY_MIN_COUT
         gn1 = self._gn(x0, x1, e.g1, e.be1, e.eps)
-        h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=e.temb_off)
+        if pre:
+            h1, _ = self._conv(self._gn_apply(x0, x1, gn1, 1), None, e.w1, e.b1, e.cout, temb_off=e.temb_off)
+        else:
+            h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=e.temb_off)
         gn2 = self._gn(h1, None, e.g2, e.be2, e.eps)
+        src, kw = (self._gn_apply(h1, None, gn2, 1), dict()) if pre else (h1, dict(silu=1, gn=gn2))
         if e.fused_shortcut:
-            out, _ = self._conv(h1, None, e.w2, e.b2, e.cout, silu=1, gn=gn2, tail=(x0, x1))
+            out, _ = self._conv(src, None, e.w2, e.b2, e.cout, tail=(x0, x1), **kw)
         else:
             assert x1 is None
-            out, _ = self._conv(h1, None, e.w2, e.b2, e.cout, silu=1, gn=gn2, residual=x0)
+            out, _ = self._conv(src, None, e.w2, e.b2, e.cout, residual=x0, **kw)
         self.tape.append(SimpleNamespace(kind="resnet", name=name, x0=x0, x1=x1, h1=h1, out=out, gn1=gn1, gn2=gn2, e=e))
         return out
 
