@@ -509,7 +509,7 @@ class UNetPlan:
         return y, a
 
     # pd_conv applies GroupNorm + SiLU while staging, once per 64-channel output tile; from this many output channels on
-    # (inference plans) the input is normalised ONCE by pd_gn_apply instead and the convolution runs without a prologue
+    # the input is normalised ONCE by pd_gn_apply instead and the convolution (and its weight gradient) runs without a prologue
     PREAPPLY_MIN_COUT = 320      # measured: a win from 5 output tiles on (SD UNet: 7.7 vs 9.4 ms of 3x3 convs per forward), neutral at 4
 
     def _gn_apply(self, x0, x1, gn, silu):
@@ -523,20 +523,26 @@ class UNetPlan:
 
     def _resnet(self, name, x0, x1=None):
         e = self.w.resnets[name]
-        pre = (not self.train) and e.cout >= self.PREAPPLY_MIN_COUT
+        pre = e.cout >= self.PREAPPLY_MIN_COUT
+        z1 = z2 = None
         gn1 = self._gn(x0, x1, e.g1, e.be1, e.eps)
         if pre:
-            h1, _ = self._conv(self._gn_apply(x0, x1, gn1, 1), None, e.w1, e.b1, e.cout, temb_off=e.temb_off)
+            z1 = self._gn_apply(x0, x1, gn1, 1)
+            h1, _ = self._conv(z1, None, e.w1, e.b1, e.cout, temb_off=e.temb_off)
         else:
             h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=e.temb_off)
         gn2 = self._gn(h1, None, e.g2, e.be2, e.eps)
-        src, kw = (self._gn_apply(h1, None, gn2, 1), dict()) if pre else (h1, dict(silu=1, gn=gn2))
+        if pre:
+            z2 = self._gn_apply(h1, None, gn2, 1)
+        src, kw = (z2, dict()) if pre else (h1, dict(silu=1, gn=gn2))
         if e.fused_shortcut:
             out, _ = self._conv(src, None, e.w2, e.b2, e.cout, tail=(x0, x1), **kw)
         else:
             assert x1 is None
             out, _ = self._conv(src, None, e.w2, e.b2, e.cout, residual=x0, **kw)
-        self.tape.append(SimpleNamespace(kind="resnet", name=name, x0=x0, x1=x1, h1=h1, out=out, gn1=gn1, gn2=gn2, e=e))
+        # z1 / z2: the normalised conv inputs when they were materialised (the weight gradients read them instead of
+        # rebuilding GroupNorm + SiLU per tile)
+        self.tape.append(SimpleNamespace(kind="resnet", name=name, x0=x0, x1=x1, h1=h1, out=out, gn1=gn1, gn2=gn2, e=e, z1=z1, z2=z2))
         return out
 
     def _attn(self, name, x):

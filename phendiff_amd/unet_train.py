@@ -384,7 +384,10 @@ class UNetTrainPlan(UNetPlan):
         cin = e.cin
         dout = self._g(rec.out)[0]
         self._bias_grad(dout, G(n + ".conv2.bias"))
-        self._wgrad(rec.h1, None, rec.gn2, 1, dout, G(n + ".conv2.weight"))
+        if rec.z2 is not None:
+            self._wgrad(rec.z2, None, None, 0, dout, G(n + ".conv2.weight"))
+        else:
+            self._wgrad(rec.h1, None, rec.gn2, 1, dout, G(n + ".conv2.weight"))
         if e.fused_shortcut:
             self._bias_grad(dout, G(n + ".conv_shortcut.bias"))
             self._wgrad(x0, x1, None, 0, dout, G(n + ".conv_shortcut.weight"), ksize=1, pad=0)
@@ -397,7 +400,10 @@ class UNetTrainPlan(UNetPlan):
         # d time_emb_proj output [n][co] = sum over pixels of d h1 (the projection is broadcast over the pixels)
         per = self.dproj[:, e.temb_off:]
         self._bias_grad(dh1, G(n + ".conv1.bias"), per_sample=per, per_stride=self.w.proj_dim)
-        self._wgrad(x0, x1, rec.gn1, 1, dh1, G(n + ".conv1.weight"))
+        if rec.z1 is not None:
+            self._wgrad(rec.z1, None, None, 0, dh1, G(n + ".conv1.weight"))
+        else:
+            self._wgrad(x0, x1, rec.gn1, 1, dh1, G(n + ".conv1.weight"))
         dz1 = self._dgrad(dh1, te.w1d, cin, tag="dz1")
         self._gn_bwd(rec.gn1, dz1, 1, combined=True, res=res, wname=n + ".norm1")
 

@@ -16,6 +16,12 @@ SMALL = dict(in_channels=4, out_channels=4, block_out_channels=(64, 128, 192), l
              attention_head_dim=(1, 2, 3), cross_attention_dim=128, norm_num_groups=32)
 
 
+# 320 output channels: the ResNet blocks take the pre-applied GroupNorm path (pd_gn_apply + pd_conv without a prologue)
+WIDE = dict(in_channels=4, out_channels=4, block_out_channels=(64, 320), layers_per_block=1,
+            down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+            attention_head_dim=(1, 5), cross_attention_dim=64, norm_num_groups=32)
+
+
 def make_pair(cfg, mode, seed=0):
     import phendiff_amd as P
     from oracle import CustomEmbeddingRef, UNet2DConditionRef
@@ -30,7 +36,7 @@ def make_pair(cfg, mode, seed=0):
 
 
 @pytest.mark.parametrize("mode,tol", [("f32", 5e-5), ("bf16", 3e-2)])
-@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32)])
+@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32), (WIDE, 16)])
 def test_sd_unet_forward(mode, tol, cfg, size):
     import phendiff_amd as P
     from oracle import class_emb_to_encoder_hidden_states as ehs_ref

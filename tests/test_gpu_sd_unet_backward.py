@@ -4,7 +4,7 @@ reference (utils_training.py:459-496,415-454; BASELINE configs[3])."""
 import pytest
 import torch
 
-from test_gpu_sd_unet import SMALL, TINY, make_pair
+from test_gpu_sd_unet import SMALL, TINY, WIDE, make_pair
 from test_gpu_unet_backward import compare
 from test_gpu_unet_ddib import rel
 
@@ -39,7 +39,7 @@ def oracle_grads(r, emb, noisy, ts, target, labels, unconditional=False):
 
 
 @pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 3e-4, 3e-5), ("bf16", 1e-1, 2.5e-2)])
-@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32)])
+@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32), (WIDE, 16)])
 def test_sd_unet_backward_matches_autograd(mode, per_tol, glob_tol, cfg, size):
     import phendiff_amd as P
     r, emb, m, e2 = make_pair(cfg, mode)
