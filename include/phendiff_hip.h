@@ -404,6 +404,21 @@ typedef struct {
 } pd_attn_d64_args;
 int pd_attn_d64(const pd_attn_d64_args* a, void* stream);
 
+/* pd_token_wgrad: dw[n][k] (+)= sum_m dy[m][n] * x[m][k] -- weight gradient of nn.Linear over M tokens (the Linear layers of
+ * BasicTransformerBlock trained through utils_training.py:436), MFMA GEMM with the reduction over tokens; dw is the fp32
+ * [N][K] gradient of the nn.Linear weight.  slab: workspace of slab_bytes >= pd_token_wgrad_workspace(a) (smaller is accepted
+ * down to one split); partial sums are reduced in a fixed order (bitwise reproducible). */
+typedef struct {
+  int dtype;
+  long long M; int K, N;
+  const void* x; int x_stride;
+  const void* dy; int dy_stride;
+  float* dw; int accumulate;
+  float* slab; size_t slab_bytes;
+} pd_token_wgrad_args;
+int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream);
+size_t pd_token_wgrad_workspace(const pd_token_wgrad_args* a);
+
 /* pd_gn_apply: y = silu?(GroupNorm([x0 | x1])) materialised once (scale / shift from pd_gn_finalize): the GroupNorm-apply +
  * SiLU of ResnetBlock2D.norm1/norm2 (diffusers resnet.py; cond_unet_2d.py:171,187,217 and the SD UNet / VAE blocks) for layers
  * whose convolution has many 64-channel output tiles, where pd_conv's in-flight transform would be repeated per tile. */

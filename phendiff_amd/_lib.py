@@ -117,6 +117,11 @@ class AttnD64Args(C.Structure):
                 ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp), ("out_stride", C.c_int), ("lse", vp)]
 
 
+class TokenWgradArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("M", C.c_longlong), ("K", C.c_int), ("N", C.c_int), ("x", vp), ("x_stride", C.c_int), ("dy", vp),
+                ("dy_stride", C.c_int), ("dw", vp), ("accumulate", C.c_int), ("slab", vp), ("slab_bytes", C.c_size_t)]
+
+
 class GnApplyArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("HW", C.c_int), ("C0", C.c_int), ("C1", C.c_int), ("silu", C.c_int),
                 ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("y", vp)]
@@ -239,6 +244,8 @@ SYMBOLS = {
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
     "pd_attn_d64": (C.c_int, [C.POINTER(AttnD64Args), vp]),
+    "pd_token_wgrad": (C.c_int, [C.POINTER(TokenWgradArgs), vp]),
+    "pd_token_wgrad_workspace": (C.c_size_t, [C.POINTER(TokenWgradArgs)]),
     "pd_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
     "pd_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "pd_attn_wide": (C.c_int, [C.POINTER(AttnWideArgs), vp]),

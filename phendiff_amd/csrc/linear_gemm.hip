@@ -232,6 +232,143 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pd_token_wgrad: dW[n][k] (+)= sum_m dY[m][n] X[m][k] -- the weight gradient of nn.Linear over M tokens, an MFMA GEMM whose
+// reduction runs over the tokens.  Both operands need 8 consecutive TOKENS per lane for a fixed channel, i.e. transposed
+// reads of the token-major tiles (ds_read_b64_tr_b16; 32-channel planes with 64-byte token rows, conflict-free), as in
+// pd_conv_wgrad -- but shaped for a plain GEMM: workgroup tile 128 (n) x 128 (k), wave 64 x 64 (2 x 2 MFMA tiles: 8
+// transposed reads per 4 MFMAs instead of 4 per 1), 64-token stages double-buffered in LDS (one barrier per 16 MFMAs per
+// wave).  The token range is split over workgroups; partial tiles go to a slab [split][n][k] that pd_conv_wgrad's ordered
+// reduce folds into the fp32 gradient (bitwise reproducible, no atomics).
+struct TwP {
+  long long M;
+  int K, N, x_stride, dy_stride, NP, KP, n_tiles, k_tiles, splits, chunks_per_split, nchunks;
+  unsigned xbytes, dybytes;
+  const void* x; const void* dy; float* slab;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void token_wgrad_kernel(const TwP p) {
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  using SR = typename Stage<T>::R;
+  constexpr int ES = E::BYTES, TM = 64, PXB = 32 * ES;                 // one token row of a 32-channel plane
+  constexpr int PLANE = TM * PXB, OPER = 4 * PLANE, BUF = 2 * OPER;    // [dY planes 0..3 | X planes 0..3]
+  constexpr int NIT = TM * 128 / 8 / 256;                              // 8-channel pieces per thread per operand per stage (4)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [2][BUF]
+
+  const int ncombo = p.n_tiles * p.k_tiles;
+  const int split = blockIdx.x / ncombo, combo = blockIdx.x - split * ncombo;
+  const int nt = combo / p.k_tiles, kt = combo - nt * p.k_tiles;
+  const int n0 = nt * 128, k0 = kt * 128;
+  const int c_begin = split * p.chunks_per_split, c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dybytes, 0x00020000);
+
+  // this thread's pieces: token = q >> 4, 8-channel sub-block = q & 15 of the 128-channel tile
+  SR sdy[NIT], sx[NIT];
+  auto issue = [&](int chunk) {
+    const long long m0 = (long long)chunk * TM;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = tid + 256 * i, tok = q >> 4, sub = q & 15;
+      const long long m = m0 + tok;
+      const bool okd = m < p.M && n0 + sub * 8 < p.N, okx = m < p.M && k0 + sub * 8 < p.K;
+      sdy[i] = Stage<T>::load(rsd, okd ? (unsigned)(((size_t)m * p.dy_stride + n0 + sub * 8) * ES) : OOB_OFF);
+      sx[i] = Stage<T>::load(rsx, okx ? (unsigned)(((size_t)m * p.x_stride + k0 + sub * 8) * ES) : OOB_OFF);
+    }
+  };
+  auto commit = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = tid + 256 * i, tok = q >> 4, sub = q & 15;
+      unsigned char* d = buf + (sub >> 2) * PLANE + tok * PXB + (sub & 3) * 8 * ES;
+      if constexpr (ES == 2) { *(u32x4*)d = sdy[i].v; *(u32x4*)(d + OPER) = sx[i].v; }
+      else { *(u32x4*)d = sdy[i].a; *(u32x4*)(d + 16) = sdy[i].b; *(u32x4*)(d + OPER) = sx[i].a; *(u32x4*)(d + OPER + 16) = sx[i].b; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16)(0.f);
+  const unsigned lo = FragLd<T>::lane_off(lane, PXB);
+  const int a_off = (wn * 2) * PLANE + lo, b_off = OPER + (wk * 2) * PLANE + lo;
+
+  if (c_begin < c_end) {
+    issue(c_begin);
+    commit(lds);
+    if (c_begin + 1 < c_end) issue(c_begin + 1);
+    __syncthreads();
+  }
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const unsigned char* buf = lds + ((chunk - c_begin) & 1) * BUF;
+#pragma unroll
+    for (int ks = 0; ks < TM / 16; ++ks) {
+      const Frag a0 = FragLd<T>::template load<PXB>(buf + a_off + ks * 16 * PXB);
+      const Frag a1 = FragLd<T>::template load<PXB>(buf + a_off + PLANE + ks * 16 * PXB);
+      const Frag b0 = FragLd<T>::template load<PXB>(buf + b_off + ks * 16 * PXB);
+      const Frag b1 = FragLd<T>::template load<PXB>(buf + b_off + PLANE + ks * 16 * PXB);
+      __builtin_amdgcn_s_setprio(1);
+      acc[0][0] = E::mma(a0, b0, acc[0][0]);
+      acc[0][1] = E::mma(a0, b1, acc[0][1]);
+      acc[1][0] = E::mma(a1, b0, acc[1][0]);
+      acc[1][1] = E::mma(a1, b1, acc[1][1]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (chunk + 1 < c_end) {
+      commit(lds + ((chunk + 1 - c_begin) & 1) * BUF);
+      if (chunk + 2 < c_end) issue(chunk + 2);
+    }
+    __syncthreads();
+  }
+
+  // partial tile -> slab[split][n][k]: lane = column k, register g <-> row n = 8 (g>>2) + 4 h + (g&3)
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* out = p.slab + ((size_t)split * p.NP + n0 + wn * 64 + a * 32) * p.KP + k0 + wk * 64 + b * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) out[(size_t)((g & 3) + 8 * (g >> 2) + 4 * h) * p.KP] = acc[a][b][g];
+    }
+}
+
+// dw[n][k] (+)= sum over splits of slab[split][n][k] (splits added in order: bitwise reproducible); coalesced rows
+__global__ __launch_bounds__(256) void token_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int NP, int KP,
+                                                                  int N, int K, int accumulate) {
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const size_t per = (size_t)NP * KP;
+  const float* src = slab + (size_t)n * KP + k;
+  float s0 = 0.f, s1 = 0.f;
+  int sp = 0;
+  for (; sp + 2 <= splits; sp += 2) { s0 += src[(size_t)sp * per]; s1 += src[(size_t)(sp + 1) * per]; }
+  if (sp < splits) s0 += src[(size_t)sp * per];
+  float* o = dw + (size_t)n * K + k;
+  *o = accumulate ? *o + (s0 + s1) : (s0 + s1);
+}
+
+static void token_wgrad_plan(long long M, int K, int N, int* n_tiles, int* k_tiles, int* splits, int* cps, int* nchunks) {
+  *n_tiles = (N + 127) / 128; *k_tiles = (K + 127) / 128;
+  *nchunks = (int)((M + 63) / 64);
+  const int combos = *n_tiles * *k_tiles;
+  int want = (768 + combos - 1) / combos;              // fill 256 CUs x up to 3 resident workgroups
+  int amort = *nchunks / 4 > 1 ? *nchunks / 4 : 1;     // >= 4 stages per slab tile written
+  int s = want < amort ? want : amort;
+  if (s < 1) s = 1;
+  *cps = (*nchunks + s - 1) / s;
+  *splits = (*nchunks + *cps - 1) / *cps;
+}
+
 template <typename T, int NC>
 static int launch_linear(const LinP& p, hipStream_t st) {
   constexpr int ES = Elem<T>::BYTES;
@@ -279,4 +416,57 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   p.x = a->x; p.w = a->w_packed; p.bias = a->bias; p.residual = a->residual; p.y = a->y;
   if (a->dtype == PD_F32) return narrow ? launch_linear<float, 1>(p, (hipStream_t)stream) : launch_linear<float, 2>(p, (hipStream_t)stream);
   return narrow ? launch_linear<bf16_t, 1>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2>(p, (hipStream_t)stream);
+}
+
+extern "C" size_t pd_token_wgrad_workspace(const pd_token_wgrad_args* a) {
+  if (!a || a->M < 1 || a->K < 1 || a->N < 1) return 0;
+  int nt, kt, splits, cps, nch;
+  token_wgrad_plan(a->M, a->K, a->N, &nt, &kt, &splits, &cps, &nch);
+  return (size_t)splits * nt * 128 * kt * 128 * sizeof(float);
+}
+
+extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_token_wgrad: null args");
+  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16, PD_ERR_ARG, "pd_token_wgrad: bad dtype %d", a->dtype);
+  PD_CHECK(a->M > 0 && a->K > 0 && a->K % 8 == 0 && a->N > 0 && a->N % 8 == 0 && a->x_stride >= a->K && a->dy_stride >= a->N &&
+               a->x_stride % 8 == 0 && a->dy_stride % 8 == 0, PD_ERR_SHAPE, "pd_token_wgrad: K, N and the row strides must be multiples of 8");
+  PD_CHECK(a->x && a->dy && a->dw && a->slab, PD_ERR_ARG, "pd_token_wgrad: null pointer");
+  const size_t esz = a->dtype == PD_F32 ? 4 : 2;
+  const size_t xbytes = ((size_t)(a->M - 1) * a->x_stride + a->K) * esz, dybytes = ((size_t)(a->M - 1) * a->dy_stride + a->N) * esz;
+  PD_CHECK(xbytes < 0x80000000ull && dybytes < 0x80000000ull, PD_ERR_SHAPE, "pd_token_wgrad: operands must be < 2 GiB (32-bit buffer offsets)");
+  TwP p{};
+  p.M = a->M; p.K = a->K; p.N = a->N; p.x_stride = a->x_stride; p.dy_stride = a->dy_stride;
+  token_wgrad_plan(a->M, a->K, a->N, &p.n_tiles, &p.k_tiles, &p.splits, &p.chunks_per_split, &p.nchunks);
+  p.NP = p.n_tiles * 128; p.KP = p.k_tiles * 128;
+  const size_t per_split = (size_t)p.NP * p.KP * sizeof(float);
+  if ((size_t)p.splits * per_split > a->slab_bytes) {
+    const int s = (int)(a->slab_bytes / per_split);
+    PD_CHECK(s >= 1, PD_ERR_ARG, "pd_token_wgrad: slab of %zu bytes cannot hold one split (%zu bytes)", a->slab_bytes, per_split);
+    p.chunks_per_split = (p.nchunks + s - 1) / s;
+    p.splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+  }
+  p.xbytes = (unsigned)xbytes; p.dybytes = (unsigned)dybytes;
+  p.x = a->x; p.dy = a->dy; p.slab = a->slab;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(p.splits * p.n_tiles * p.k_tiles);
+  if (a->dtype == PD_BF16) {
+    constexpr int LDS = 2 * 2 * 4 * 64 * 64;            // 64 KiB
+    hipLaunchKernelGGL(token_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), LDS, st, p);
+  } else {
+    constexpr int LDS = 2 * 2 * 4 * 64 * 128;           // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)token_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        set_error("pd_token_wgrad: cannot reserve %d bytes of LDS", LDS);
+        return PD_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(token_wgrad_kernel<float>, dim3(grid), dim3(256), LDS, st, p);
+  }
+  PD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)((a->K + 255) / 256), (unsigned)a->N), dim3(256), 0, st, (const float*)a->slab, a->dw,
+                     p.splits, p.NP, p.KP, a->N, a->K, a->accumulate);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
 }

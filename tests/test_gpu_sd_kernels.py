@@ -196,3 +196,37 @@ def test_linear_gemm(env, mode, cfg):
     torch.cuda.synchronize()
     ref = F.linear(xfull[:, :K], w, bias) + (res if with_res else 0)
     assert rel(y.float(), ref) < (2e-6 if mode == "f32" else 4e-3)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(4096, 320, 960, 0), (300, 64, 64, 0), (2048, 1280, 2560, 0), (77 * 3, 96, 256, 0), (8200, 640, 200, 24), (64, 8, 8, 0)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_token_wgrad(env, mode, cfg, accumulate):
+    """pd_token_wgrad against dY^T X: ragged token chunks, channel counts that are not multiples of the 128 tile, strided rows,
+    a deliberately small slab (fewer splits), accumulation into an existing gradient."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    M, K, N, pad = cfg
+    g = torch.Generator().manual_seed(62)
+    x = bf16_round(torch.randn(M, K + pad, generator=g), mode)
+    dy = bf16_round(torch.randn(M, N + pad, generator=g), mode)
+    X, DY = x.to(tdt).to(dev), dy.to(tdt).to(dev)
+    prev = torch.randn(N, K, generator=g)
+    dw = prev.clone().to(dev) if accumulate else torch.full((N, K), float("nan"), device=dev)
+    a = L.TokenWgradArgs(dtype=code, M=M, K=K, N=N, x=X.data_ptr(), x_stride=K + pad, dy=DY.data_ptr(), dy_stride=N + pad,
+                         dw=dw.data_ptr(), accumulate=accumulate)
+    need = lib.pd_token_wgrad_workspace(C.byref(a))
+    if M == 8200:
+        need = max(need // 3, ((N + 127) // 128) * 128 * ((K + 127) // 128) * 128 * 4)       # fewer splits than planned
+    slab = torch.empty(need // 4, dtype=torch.float32, device=dev)
+    a.slab, a.slab_bytes = slab.data_ptr(), need
+    L.check(lib.pd_token_wgrad(C.byref(a), stream()), "pd_token_wgrad")
+    torch.cuda.synchronize()
+    ref = dy[:, :N].double().t() @ x[:, :K].double()
+    got = dw.cpu().double() - (prev.double() if accumulate else 0)
+    assert rel(got.float(), ref.float()) < (2e-5 if mode == "f32" else 2e-3)
+    # bitwise reproducible
+    dw2 = prev.clone().to(dev) if accumulate else torch.full((N, K), float("nan"), device=dev)
+    a.dw = dw2.data_ptr()
+    L.check(lib.pd_token_wgrad(C.byref(a), stream()), "pd_token_wgrad")
+    assert torch.equal(dw2, dw)
