@@ -228,3 +228,35 @@ def test_plan_grad_buckets_cover_buffer_in_ready_order():
     assert [r for _, _, r in b] == sorted(r for _, _, r in b) and b[0] == (100, 160, 20)
     assert dict(((s, e), r) for s, e, r in b)[(0, 40)] == 99                        # a bucket is ready when its LAST gradient is
     assert plan_grad_buckets([7], [3], 1 << 20) == [(0, 7, 3)]
+
+
+def test_sd_training_param_order_keeps_fused_projections_adjacent():
+    """Host logic of the SD trainer (no GPU): the flat-buffer order covers every parameter once, stacks the time_emb_proj
+    matrices and keeps attn1 q/k/v and attn2 k/v weights adjacent (the fused projections read them as one matrix)."""
+    import torch
+    from phendiff_amd.sd_unet import SDUNet2DConditionModel
+    from phendiff_amd.sd_unet_train import sd_training_param_order
+    from phendiff_amd.unet_train import plan_grad_buckets
+    cfg = dict(in_channels=4, out_channels=4, block_out_channels=(64, 128), layers_per_block=1,
+               down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+               attention_head_dim=(1, 2), cross_attention_dim=96, norm_num_groups=32)
+    m = SDUNet2DConditionModel(compute_dtype="f32", **cfg)
+    order = sd_training_param_order(m)
+    names = [n for n, _ in order]
+    assert sorted(names) == sorted(n for n, _ in m.named_parameters()) and len(set(names)) == len(names)
+    pos = {n: i for i, n in enumerate(names)}
+    tproj_w = [n for n in names if n.endswith("time_emb_proj.weight")]
+    assert [pos[n] for n in tproj_w] == list(range(len(tproj_w)))                     # stacked first, in module order
+    for n in names:
+        if n.endswith("attn1.to_q.weight"):
+            b = n[:-len("to_q.weight")]
+            assert pos[b + "to_k.weight"] == pos[n] + 1 and pos[b + "to_v.weight"] == pos[n] + 2
+        if n.endswith("attn2.to_k.weight"):
+            assert pos[n[:-len("to_k.weight")] + "to_v.weight"] == pos[n] + 1
+    # bucket planning over these sizes: contiguous cover, sorted by readiness
+    sizes = [p.numel() for _, p in order]
+    ready = list(range(len(sizes), 0, -1))
+    buckets = plan_grad_buckets(sizes, ready, 1 << 16)
+    cover = sorted((s, e) for s, e, _ in buckets)
+    assert cover[0][0] == 0 and cover[-1][1] == sum(sizes) and all(a[1] == b[0] for a, b in zip(cover[:-1], cover[1:]))
+    assert [r for _, _, r in buckets] == sorted(r for _, _, r in buckets)
