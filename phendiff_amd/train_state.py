@@ -30,7 +30,7 @@ ADAMW_GROUP_DEFAULTS = dict(amsgrad=False, foreach=None, maximize=False, captura
 
 def optimizer_state_dict(param_names: Sequence[str], flat_names: Sequence[str], sizes: Dict[str, torch.Size],
                          exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int, lr: float, betas, eps: float,
-                         weight_decay: float) -> dict:
+                         weight_decay: float, steps_by_name: Optional[Dict[str, int]] = None) -> dict:
     """``torch.optim.AdamW.state_dict()`` built from flat moment buffers.  ``param_names``: ``unet.named_parameters()``
     order (torch's parameter indices); ``flat_names``: order of the flat buffers."""
     off, where = 0, {}
@@ -42,7 +42,10 @@ def optimizer_state_dict(param_names: Sequence[str], flat_names: Sequence[str], 
     if step > 0:
         for i, n in enumerate(param_names):
             o, k = where[n]
-            state[i] = {"step": torch.tensor(float(step)),
+            st_n = (steps_by_name or {}).get(n, step)     # a parameter torch skipped on some steps (no gradient) counts its own
+            if st_n <= 0:
+                continue
+            state[i] = {"step": torch.tensor(float(st_n)),
                         "exp_avg": exp_avg[o:o + k].detach().cpu().reshape(sizes[n]).clone(),
                         "exp_avg_sq": exp_avg_sq[o:o + k].detach().cpu().reshape(sizes[n]).clone()}
     group = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, **ADAMW_GROUP_DEFAULTS,
@@ -51,8 +54,9 @@ def optimizer_state_dict(param_names: Sequence[str], flat_names: Sequence[str], 
 
 
 def load_optimizer_state_dict(sd: dict, param_names: Sequence[str], flat_names: Sequence[str], sizes: Dict[str, torch.Size],
-                              exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> int:
-    """Inverse of :func:`optimizer_state_dict`: fills the flat moment buffers in place, returns the step count."""
+                              exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, steps_out: Optional[Dict[str, int]] = None) -> int:
+    """Inverse of :func:`optimizer_state_dict`: fills the flat moment buffers in place, returns the step count (the largest
+    per-parameter count; ``steps_out`` receives every parameter's own)."""
     off, where = 0, {}
     for n in flat_names:
         k = int(np.prod(sizes[n])) if len(sizes[n]) else 1
@@ -74,6 +78,8 @@ def load_optimizer_state_dict(sd: dict, param_names: Sequence[str], flat_names: 
         exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1).to(exp_avg.device, torch.float32))
         exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1).to(exp_avg.device, torch.float32))
         step = max(step, int(float(st["step"])))
+        if steps_out is not None:
+            steps_out[n] = int(float(st["step"]))
     return step
 
 
@@ -124,7 +130,8 @@ def save_state(trainer, output_dir: str, rank: int = 0, base_lr: Optional[float]
     fnames = list(trainer.params)
     sizes = {n: trainer.params[n].shape for n in fnames}
     torch.save({k: v.detach().cpu() for k, v in m.state_dict().items()}, os.path.join(output_dir, "pytorch_model.bin"))
-    torch.save(optimizer_state_dict(pnames, fnames, sizes, opt.exp_avg, opt.exp_avg_sq, opt.t, opt.lr, opt.betas, opt.eps, opt.wd),
+    torch.save(optimizer_state_dict(pnames, fnames, sizes, opt.exp_avg, opt.exp_avg_sq, opt.t, opt.lr, opt.betas, opt.eps, opt.wd,
+                                    {n: opt.t_tail for n in getattr(opt, "tail_names", ())}),
                os.path.join(output_dir, "optimizer.bin"))
     torch.save(lr_scheduler_state_dict(base_lr if base_lr is not None else opt.lr, lr_step if lr_step is not None else opt.t,
                                        current_lr if current_lr is not None else opt.lr), os.path.join(output_dir, "scheduler.bin"))
@@ -151,7 +158,10 @@ def load_state(trainer, input_dir: str, rank: int = 0) -> dict:
         for k, p in own.items():
             p.data.copy_(sd[k].to(p.device, p.dtype))            # in place: the flat buffer and every plan stay valid
     osd = torch.load(os.path.join(input_dir, "optimizer.bin"), map_location="cpu")
-    opt.t = load_optimizer_state_dict(osd, pnames, fnames, sizes, opt.exp_avg, opt.exp_avg_sq)
+    steps = {}
+    opt.t = load_optimizer_state_dict(osd, pnames, fnames, sizes, opt.exp_avg, opt.exp_avg_sq, steps)
+    if getattr(opt, "tail_names", ()):
+        opt.t_tail = max([steps.get(n, 0) for n in opt.tail_names])
     g = osd["param_groups"][0]
     opt.lr, opt.betas, opt.eps, opt.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
     ema_path = os.path.join(input_dir, "custom_checkpoint_0.pkl")

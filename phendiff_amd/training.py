@@ -131,16 +131,18 @@ class FlatAdamWEMA:
         self.ema_kwargs = ema_kwargs or {}
         self.t = 0
         self.tail = None            # (offset, numel): a trailing segment with its own AdamW step count (see set_tail)
+        self.tail_names = ()
         self.t_tail = 0
         self.partial = torch.empty(1024, dtype=torch.float64, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.clip_coef = torch.ones(1, dtype=torch.float32, device=dev)
 
-    def set_tail(self, numel: int):
+    def set_tail(self, numel: int, names=()):
         """The last ``numel`` elements are a parameter that does not receive a gradient on every step (the ``CustomEmbedding``
         on unconditional steps): torch's AdamW skips a parameter whose ``.grad`` is None and counts its steps separately, so
         that segment keeps its own step count and ``step(tail_active=False)`` leaves it (and its moments) untouched."""
         self.tail = (self.flat.numel() - numel, numel)
+        self.tail_names = tuple(names)        # state_dict names of the tail parameters (checkpoints record their own step count)
 
     def step(self, lr: Optional[float] = None, zero_grad: bool = True, tail_active: bool = True):
         """clip_grad_norm_ -> optimizer.step -> zero_grad -> EMA.step (utils_training.py:438-454, 553-556). No host sync:

@@ -32,7 +32,9 @@ from .unet import CustomCondUNet2DModel, UNetPlan, _Attention, _Op, _PackedWeigh
 def training_param_order(m: CustomCondUNet2DModel) -> List[Tuple[str, torch.nn.Parameter]]:
     """(name, parameter) pairs in the order the flat training buffers use: all ``time_emb_proj`` weights (then biases)
     stacked in module order -- one [proj_dim][tdim] matrix, as ``pd_temb`` sees them --, each attention's
-    to_q / to_k / to_v weights (then biases) adjacent -- the fused [3C][C] projection --, then everything else."""
+    to_q / to_k / to_v weights (then biases) adjacent -- the fused [3C][C] projection --, then everything else, the class
+    embedding table LAST (it receives no gradient on unconditional steps: torch's AdamW then skips it, so it is a tail
+    segment of the flat optimizer with its own step count)."""
     named = dict(m.named_parameters())
     out, seen = [], set()
 
@@ -50,8 +52,10 @@ def training_param_order(m: CustomCondUNet2DModel) -> List[Tuple[str, torch.nn.P
                 for which in ("to_q", "to_k", "to_v"):
                     take(f"{n}.{which}.{suffix}")
     for n in named:
-        if n not in seen:
+        if n not in seen and n != "class_embedding.weight":
             take(n)
+    if "class_embedding.weight" in named:
+        take("class_embedding.weight")
     return out
 
 
@@ -597,6 +601,9 @@ class UNetTrainer:
             raise L.PhenDiffHipError("phendiff_amd trains on MI355X only (no CPU fallback): move the model to 'cuda'")
         order = training_param_order(model)
         self.opt = FlatAdamWEMA([p for _, p in order], lr, use_ema=use_ema, max_grad_norm=max_grad_norm, **adamw)
+        if order[-1][0] == "class_embedding.weight":
+            self.opt.set_tail(order[-1][1].numel(), ("class_embedding.weight",))
+        self._cond = True
         self.params = {n: p.data for n, p in order}
         self.grads = {n: p.grad for n, p in order}
         model.invalidate()
@@ -629,6 +636,7 @@ class UNetTrainer:
         ts = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
         labels = class_labels.to(device=self.device, dtype=torch.int64).contiguous() if class_labels is not None else None
         cemb = class_emb.to(device=self.device, dtype=torch.float32).contiguous() if class_emb is not None else None
+        self._cond = labels is not None        # the class table has a gradient only when the labels went through it
         out = torch.empty_like(x)
         plan.forward(x, ts, labels, cemb, out, st)
         loss, dout = self.loss_fn(out, clean, noise, timesteps)
@@ -656,7 +664,9 @@ class UNetTrainer:
         return loss
 
     def _optimizer_step(self, lr):
-        self.opt.step(lr)
+        # unconditional step (class_emb = zeros, utils_training.py:510-516): the class table's .grad stays None in the
+        # reference, torch's AdamW skips it (no decay, no moment update, no step count) -- EMA still steps
+        self.opt.step(lr, tail_active=self._cond)
 
     def _forward_backward_overlapped(self, noisy, timesteps, clean, noise, class_labels, class_emb, group, world, bucket_bytes):
         import torch.distributed as dist
