@@ -4,10 +4,12 @@
 (``utils_training.py:459-496``), with the reference's class conditioning: ``CustomEmbedding`` -> one 1024-d token padded
 with 76 zero tokens as ``encoder_hidden_states`` (``utils_training.py:472-484``).
 
-Forward only in this round.  Same engine as :mod:`phendiff_amd.unet`: the module tree only holds parameters under
-diffusers' ``state_dict`` names; a static launch plan runs ResnetBlock2D / GroupNorm / sampling convs and EVERY ``nn.Linear``
-(as a 1x1 convolution over NHWC tokens) through ``pd_conv``, and the Transformer2DModel additions through ``pd_layernorm``,
-``pd_attn_d64`` (self attention and the 77-token cross attention) and ``pd_geglu``.  No torch operator runs in the plan.
+Forward here; the backward / training step is :mod:`phendiff_amd.sd_unet_train`.  Same engine as :mod:`phendiff_amd.unet`: the
+module tree only holds parameters under diffusers' ``state_dict`` names; a static launch plan runs ResnetBlock2D / GroupNorm /
+sampling convs through ``pd_conv`` (+ ``pd_gn_apply`` for the wide blocks), the plain ``nn.Linear`` layers through the ``pd_linear``
+GEMM (``proj_in`` / ``proj_out``, which carry a GroupNorm prologue / emit GroupNorm statistics, as 1x1 ``pd_conv``), and the
+Transformer2DModel additions through ``pd_layernorm``, ``pd_attn_d64`` (self attention and the 77-token cross attention) and
+``pd_geglu``.  No torch operator runs in the plan.
 """
 from __future__ import annotations
 
