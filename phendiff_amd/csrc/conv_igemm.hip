@@ -538,11 +538,11 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
 }
 
 // tile shape by output width: 32-wide rows when possible (bank-conflict-free), else squarer tiles
-static void tile_shape(int ksize, int stride, int wout, int* th, int* tw) {
+static void tile_shape(int ksize, int stride, int hout, int wout, int* th, int* tw) {
 #ifdef PD_EXP_TP128
   const int tp = (ksize == 3) ? 128 : 256;
 #else
-  const int tp = (ksize == 3 && stride == 2) ? 128 : 256;
+  const int tp = ((ksize == 3 && stride == 2) || (ksize == 3 && stride == 1 && wout < 16 && hout <= 16)) ? 128 : 256;
 #endif
   *tw = wout >= 32 ? 32 : (wout >= 16 ? 16 : 8);
   *th = tp / *tw;
@@ -558,13 +558,17 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
     if (w >= 16) return launch_conv<T, 3, 1, 8, 16>(p, st);
     return launch_conv<T, 3, 1, 16, 8>(p, st);
 #else
+    // 8-wide images (the SD UNet's innermost level): a 16 x 8 tile wastes half of an 8 x 8 image's tile instead of three quarters
+    const bool tiny = p.Hout <= 16;
     if (p.n_tail > 0) {
       if (w >= 32) return launch_conv<T, 3, 1, 8, 32, true>(p, st);
       if (w >= 16) return launch_conv<T, 3, 1, 16, 16, true>(p, st);
+      if (tiny) return launch_conv<T, 3, 1, 16, 8, true>(p, st);
       return launch_conv<T, 3, 1, 32, 8, true>(p, st);
     }
     if (w >= 32) return launch_conv<T, 3, 1, 8, 32>(p, st);
     if (w >= 16) return launch_conv<T, 3, 1, 16, 16>(p, st);
+    if (tiny) return launch_conv<T, 3, 1, 16, 8>(p, st);
     return launch_conv<T, 3, 1, 32, 8>(p, st);
 #endif
   }
@@ -668,6 +672,6 @@ extern "C" int pd_debug_read_conv_stamps(unsigned long long* host, size_t bytes)
 
 extern "C" int pd_conv_stat_tiles(int Hout, int Wout, int ksize, int stride) {
   int th, tw;
-  pd::tile_shape(ksize, stride, Wout, &th, &tw);
+  pd::tile_shape(ksize, stride, Hout, Wout, &th, &tw);
   return ((Hout + th - 1) / th) * ((Wout + tw - 1) / tw);
 }
