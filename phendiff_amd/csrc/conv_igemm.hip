@@ -65,7 +65,7 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 #define PD_STAMP(k) do {} while (0)
 #endif
 template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, (KS == 1 && sizeof(T) == 2) ? 3 : 2) void conv_kernel(const ConvP p) {   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -539,11 +539,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
 
 // tile shape by output width: 32-wide rows when possible (bank-conflict-free), else squarer tiles
 static void tile_shape(int ksize, int stride, int hout, int wout, int* th, int* tw) {
-#ifdef PD_EXP_TP128
-  const int tp = (ksize == 3) ? 128 : 256;
-#else
   const int tp = ((ksize == 3 && stride == 2) || (ksize == 3 && stride == 1 && wout < 16 && hout <= 16)) ? 128 : 256;
-#endif
   *tw = wout >= 32 ? 32 : (wout >= 16 ? 16 : 8);
   *th = tp / *tw;
 }
@@ -553,11 +549,6 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
   // tile shape by output width: 32-wide rows when possible (bank-conflict-free), else squarer tiles
   const int w = p.Wout;
   if (ksize == 3 && stride == 1) {
-#ifdef PD_EXP_TP128
-    if (w >= 32) return launch_conv<T, 3, 1, 4, 32>(p, st);
-    if (w >= 16) return launch_conv<T, 3, 1, 8, 16>(p, st);
-    return launch_conv<T, 3, 1, 16, 8>(p, st);
-#else
     // 8-wide images (the SD UNet's innermost level): a 16 x 8 tile wastes half of an 8 x 8 image's tile instead of three quarters
     const bool tiny = p.Hout <= 16;
     if (p.n_tail > 0) {
@@ -570,7 +561,6 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
     if (w >= 16) return launch_conv<T, 3, 1, 16, 16>(p, st);
     if (tiny) return launch_conv<T, 3, 1, 16, 8>(p, st);
     return launch_conv<T, 3, 1, 32, 8>(p, st);
-#endif
   }
   if (ksize == 3 && stride == 2) {
     if (w >= 32) return launch_conv<T, 3, 2, 4, 32>(p, st);
