@@ -231,11 +231,14 @@ class AutoencoderKL(nn.Module):
             self._plans[key] = p
         return p
 
-    def _max_batch(self, H, W):
+    def _max_batch(self, H, W, kind="dec"):
         """pd_conv addresses a source tensor with 32-bit byte offsets: the widest full-resolution activation of a chunk
-        must stay below 2 GiB."""
+        must stay below 2 GiB.  Encoder: block_out_channels[0] channels at H x W; decoder: the last up block's first ResNet
+        reads block_out_channels[1] channels at full resolution (the previous stage's upsampled output)."""
         esz = 2 if self.compute_dtype == "bf16" else 4
-        return max(1, ((1 << 31) - 1) // (H * W * max(self.config.block_out_channels[0], 64) * esz))
+        boc = self.config.block_out_channels
+        ch = boc[0] if kind == "enc" else max(boc[0], boc[min(1, len(boc) - 1)])
+        return max(1, ((1 << 31) - 1) // (H * W * max(ch, 64) * esz))
 
     def _run(self, kind, x, out_shape):
         if not x.is_cuda:
@@ -246,7 +249,7 @@ class AutoencoderKL(nn.Module):
         H, W = (x.shape[2], x.shape[3]) if kind == "enc" else (x.shape[2] * s, x.shape[3] * s)
         out = torch.empty((B,) + out_shape, dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        step = self._max_batch(H, W)
+        step = self._max_batch(H, W, kind)
         for b0 in range(0, B, step):
             nb = min(step, B - b0)
             self._plan(kind, nb, x.shape[2], x.shape[3], dev).run(x[b0:b0 + nb].data_ptr(), out[b0:b0 + nb].data_ptr(), stream)

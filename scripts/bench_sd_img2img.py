@@ -49,7 +49,7 @@ def main():
           f"UNet share {(t_all - t_enc - t_dec) / t_all:.3f}")
     st = torch.cuda.current_stream().cuda_stream
     for kind in ("enc", "dec"):
-        plan = next(p for k, p in vae._plans.items() if k[0] == kind and k[1] == min(B, vae._max_batch(size, size)))
+        plan = next(p for k, p in vae._plans.items() if k[0] == kind and k[1] == min(B, vae._max_batch(size, size, kind)))
         acc = plan._profile_ops(plan.ops, st, reps=2)
         print(f" VAE {kind} per-kernel ({len(plan.ops)} launches):")
         for k, d in sorted(acc.items(), key=lambda kv: -kv[1]["ms"]):

@@ -125,7 +125,7 @@ def test_vae_batch_chunking_and_errors():
     x = torch.rand(5, 3, 16, 16) * 2 - 1
     with torch.no_grad():
         ref = r.quant_conv(r.encoder(x))
-    m._max_batch = lambda H, W: 2                             # force 3 chunks (2 + 2 + 1)
+    m._max_batch = lambda H, W, kind="dec": 2                 # force 3 chunks (2 + 2 + 1)
     assert rel(m.encode(x.cuda()).latent_dist.parameters, ref) < 5e-5
     with pytest.raises(P.PhenDiffHipError):
         m.encode(x)
@@ -133,6 +133,16 @@ def test_vae_batch_chunking_and_errors():
         m.decode(torch.zeros(1, 3, 4, 4, device="cuda"))
     with pytest.raises(NotImplementedError):
         P.AutoencoderKL(block_out_channels=(32, 96))
+
+
+def test_vae_chunk_size_respects_the_2gib_source_limit():
+    """SD VAE at 512x512: the decoder's last stage reads 256 channels at full resolution (134 MB / sample in bf16), so a batch of
+    16 must be split (it overflowed pd_conv's 32-bit source offsets before the limit accounted for that tensor)."""
+    import phendiff_amd as P
+    m = P.AutoencoderKL(compute_dtype="bf16")
+    assert m._max_batch(512, 512, "enc") == 31 and m._max_batch(512, 512, "dec") == 15
+    f = P.AutoencoderKL(compute_dtype="f32")
+    assert f._max_batch(512, 512, "dec") == 7
 
 
 def test_image_processor():
