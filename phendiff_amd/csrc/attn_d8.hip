@@ -17,6 +17,17 @@ constexpr int KT = 256;   // keys per LDS tile (double-buffered: one barrier per
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct AttnOps;
 
+// max over each row of 16 lanes with DPP-modified VALU ops (no LDS crossbar traffic): xor 1, xor 2, mirror within 8, mirror within 16
+__device__ __forceinline__ float row16_max(float x) {
+#define PD_DPP_MAX(ctrl) x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, 0xf, 0xf, false)))
+  PD_DPP_MAX(0xB1);    // quad_perm:[1,0,3,2]
+  PD_DPP_MAX(0x4E);    // quad_perm:[2,3,0,1]
+  PD_DPP_MAX(0x141);   // row_half_mirror
+  PD_DPP_MAX(0x140);   // row_mirror
+#undef PD_DPP_MAX
+  return x;
+}
+
 template <> struct AttnOps<bf16_t> {
   static constexpr int VT_PITCH = (KT + 8) * 2;   // bytes per V^T row (pad -> rows on distinct banks)
   struct QF { s16x8 v; };
@@ -40,6 +51,20 @@ template <> struct AttnOps<bf16_t> {
 #pragma unroll
     for (int j = 0; j < 8; ++j) t += bf2f((bf16_t)x.v[j]) * bf2f((bf16_t)y.v[j]);
     return t;
+  }
+  // |k|^2 of a staged key row: four v_dot2c_f32_bf16 on the packed pairs (no unpacking)
+  static __device__ __forceinline__ float k_norm2(const Elem<bf16_t>::Frag& k) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const u32x4 w = __builtin_bit_cast(u32x4, k.v);
+    float n2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const bf2 pr = __builtin_bit_cast(bf2, w[j]); n2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, n2, false); }
+    return n2;
+  }
+  // V row -> column vp of the 8 V^T rows: the bf16 halves are stored as they are (ds_write_b16 / _d16_hi), no conversion
+  static __device__ __forceinline__ void store_vt(unsigned char* vl, int vp, const Elem<bf16_t>::Frag& v) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) *(unsigned short*)(vl + d * VT_PITCH + vp * 2) = (unsigned short)v.v[d];
   }
   // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
   static constexpr int KROW = 16;                 // bytes per K row in LDS
@@ -94,6 +119,16 @@ template <> struct AttnOps<float> {
   }
   static __device__ __forceinline__ float dot(const QF& x, const QF& y) {
     return x.v[0] * y.v[0] + x.v[1] * y.v[1] + x.v[2] * y.v[2] + x.v[3] * y.v[3];
+  }
+  static __device__ __forceinline__ float k_norm2(const Elem<float>::Frag& k) {
+    float n2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n2 += k.lo[j] * k.lo[j] + k.hi[j] * k.hi[j];
+    return n2;
+  }
+  static __device__ __forceinline__ void store_vt(unsigned char* vl, int vp, const Elem<float>::Frag& v) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { *(float*)(vl + d * VT_PITCH + vp * 4) = v.lo[d]; *(float*)(vl + (4 + d) * VT_PITCH + vp * 4) = v.hi[d]; }
   }
   static constexpr int KROW = 32;
   static constexpr int KSTEP = 32 * KROW;
@@ -197,18 +232,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
   };
   auto commit = [&](int b2) {
     E::store(klds[b2] + tid * KROW, stk);
-    float kv[8], n2 = 0.f;
-    E::unpack(stk, kv);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) n2 += kv[d] * kv[d];
-#pragma unroll
-    for (int msk = 16; msk >= 1; msk >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, msk));
-    if ((tid & 31) == 0) knmax[b2][tid >> 5] = sqrtf(n2) * 1.00001f;
-    float v[8];
-    E::unpack(stv, v);
-    const int vp_ = Ops::vpos(tid);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) *(T*)(vlds[b2] + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(v[d]);
+    float n2 = row16_max(Ops::k_norm2(stk));
+    n2 = fmaxf(n2, __shfl_xor(n2, 16));
+    if ((tid & 31) == 0) knmax[b2][tid >> 5] = sqrtf(n2) * 1.00002f;
+    Ops::store_vt(vlds[b2], Ops::vpos(tid), stv);
   };
 
   issue(0);
