@@ -65,7 +65,7 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 #define PD_STAMP(k) do {} while (0)
 #endif
 template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL>
-__global__ __launch_bounds__(256, (KS == 1 && sizeof(T) == 2) ? 3 : 2) void conv_kernel(const ConvP p) {   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
+__global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2) void conv_kernel(const ConvP p) {   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -76,11 +76,15 @@ __global__ __launch_bounds__(256, (KS == 1 && sizeof(T) == 2) ? 3 : 2) void conv
   constexpr int IN_TH = (TH - 1) * STRIDE + KS;
   constexpr int IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int NPIX = IN_TH * IN_TW;
-  constexpr int PITCH = 32 * E::BYTES + 16;
+  // double-buffered variants interleave the two buffers per pixel -- [chunk c: 32 ch | chunk c+1: 32 ch | 16 B pad] -- so both
+  // share ONE pad: 144-byte pixels (bf16; an odd number of 16-B slots, conflict-free like the 80-byte single pitch) make the
+  // 10 x 34 halo tile 48 960 B instead of 2 x 27 200 B, which (with the 168-register budget) admits a third workgroup per CU
+  constexpr int CHB = 32 * E::BYTES;                 // bytes of one 32-channel chunk of a pixel
+  constexpr int PITCH = DB ? 2 * CHB + 16 : CHB + 16;
   constexpr int NIT = (NPIX * 4 + 255) / 256;
   constexpr int TAPS = KS * KS;
   constexpr int KSTEPS = TAPS * 2;
-  constexpr int LDS_TILE = ((NPIX * PITCH + 15) / 16) * 16;
+  constexpr int LDS_TILE = DB ? CHB : 0;             // offset of the second buffer
   static_assert(RPF >= 1 && TW * RPF == 32, "TW must divide 32");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -136,8 +140,6 @@ __global__ __launch_bounds__(256, (KS == 1 && sizeof(T) == 2) ? 3 : 2) void conv
 
   SR stage[NIT];
   float sc[8], sh[8];
-  unsigned soff[NIT];     // byte offset of (pixel, sub-block) in the CURRENT source; OOB_OFF for padding
-  int soff_src = -1;
   bool stage_plain = false;   // the staged chunk is a tail chunk: no affine / SiLU
   auto issue_loads = [&](int chunk) {
     // source of this chunk: 0/1 = main [x0 | x1], 2/3 = tail [t0 | t1]
@@ -145,20 +147,16 @@ __global__ __launch_bounds__(256, (KS == 1 && sizeof(T) == 2) ? 3 : 2) void conv
     if (!TAIL || chunk < p.n_main) { cch = chunk * 32; src = cch < p.C0 ? 0 : 1; if (src == 1) cch -= p.C0; }
     else { cch = (chunk - p.n_main) * 32; src = cch < p.Ct0 ? 2 : 3; if (src == 3) cch -= p.Ct0; }
     stage_plain = TAIL && src >= 2;
-    if (soff_src != src) {      // (re)computed once per source
-      soff_src = src;
-      const unsigned cs = src == 0 ? p.C0 : (src == 1 ? p.C1 : (src == 2 ? p.Ct0 : p.Ct1));
-#pragma unroll
-      for (int i = 0; i < NIT; ++i)
-        soff[i] = spix[i] >= 0 ? ((unsigned)spix[i] * cs + sub * 8) * E::BYTES : OOB_OFF;
-    }
-    const unsigned cbytes = (unsigned)cch * E::BYTES;
+    // byte offset of (pixel, sub-block) in the source, recomputed per chunk (6 multiplies: keeping them across the chunk loop
+    // costs 6 registers that decide between 2 and 3 resident workgroups per CU)
+    const unsigned cs = src == 0 ? p.C0 : (src == 1 ? p.C1 : (src == 2 ? p.Ct0 : p.Ct1));
+    const unsigned cbytes = (unsigned)(cch + sub * 8) * E::BYTES;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
 #ifdef PD_ABL_X0
       const unsigned off = OOB_OFF;   // ablation: no activation traffic
 #else
-      const unsigned off = soff[i] + (spix[i] >= 0 ? cbytes : 0u);
+      const unsigned off = spix[i] >= 0 ? (unsigned)spix[i] * cs * E::BYTES + cbytes : OOB_OFF;
 #endif
       stage[i] = src == 0 ? Stage<T>::load(rs0, off) : (src == 1 ? Stage<T>::load(rs1, off)
                  : (src == 2 ? Stage<T>::load(rt0, off) : Stage<T>::load(rt1, off)));
@@ -241,28 +239,22 @@ __global__ __launch_bounds__(256, (KS == 1 && sizeof(T) == 2) ? 3 : 2) void conv
     constexpr bool HAVE_NEXT = decltype(have_next_c)::value;
     constexpr bool ACTIVE = decltype(active_c)::value;
     const int g0 = chunk * KSTEPS;
-    Frag bc[NF], bn[NF];                   // activation fragments, prefetched 1 k-step ahead
-    if constexpr (ACTIVE) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) bc[f] = E::load(buf + rbase[f]);
-    }
+    Frag bc[NF];                           // activation fragments of the current k-step (3 waves per SIMD cover the LDS latency)
     int piece = 0;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if constexpr (ACTIVE) {
         aring[(ks + AD) % AR] = E::load(wbase + (size_t)PD_WIDX(min(g0 + ks + AD, last_kstep)) * 512);
-        if (ks + 1 < KSTEPS) {
-          const int tap = (ks + 1) >> 1, s = (ks + 1) & 1;
+        {
+          const int tap = ks >> 1, s = ks & 1;
           const int toff = ((tap / KS) * IN_TW + (tap % KS)) * PITCH + s * 16 * E::BYTES;
 #pragma unroll
-          for (int f = 0; f < NF; ++f) bn[f] = E::load(buf + rbase[f] + toff);
+          for (int f = 0; f < NF; ++f) bc[f] = E::load(buf + rbase[f] + toff);
         }
         __builtin_amdgcn_s_setprio(1);   // keeps the 4-MFMA cluster together and ahead of the other wave's VALU work (+5 %)
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[f] = E::mma(aring[ks % AR], bc[f], acc[f]);
         __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) bc[f] = bn[f];
       }
       if constexpr (DB && HAVE_NEXT) {
         // spread the NIT pieces of the next chunk evenly over the k-steps
@@ -513,8 +505,9 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
   constexpr int LDS_TILE = ((IN_TH * IN_TW * PITCH + 15) / 16) * 16;
   constexpr bool DB = 2 * LDS_TILE <= 100 * 1024;       // double-buffer when two tiles fit comfortably
+  constexpr int LDS_DB = ((IN_TH * IN_TW * (2 * 32 * Elem<T>::BYTES + 16) + 15) / 16) * 16;   // interleaved buffers, one shared pad
   constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 256 * 64;   // output tile + stats scratch [256][2*EPC] fp32
-  constexpr int LDS_MAIN = DB ? 2 * LDS_TILE : LDS_TILE;
+  constexpr int LDS_MAIN = DB ? LDS_DB : LDS_TILE;
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
   auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL>;

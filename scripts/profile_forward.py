@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import phendiff_amd as P
 from phendiff_amd import _lib as L
+if os.environ.get("PD_LIB"): L.LIB_PATH = os.environ["PD_LIB"]      # same-box A/B of two builds (scripts/ab_forward.sh)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--size", type=int, default=256)
