@@ -446,6 +446,11 @@ typedef struct {
   const float* bias;        /* [N_pad] */
   const void* residual;     /* [M][N] or NULL */
   void* y;                  /* [M][N] */
+  /* optional fusions for the q/k/v projection of diffusers' Attention (cond_unet_2d.py:176-178; AttnProcessor2_0):
+     GroupNorm apply on x while staging, and the head-major layout pd_attn_d8 reads */
+  const float* scale; const float* shift;   /* [M / rows_per_sample][K] or NULL: x <- x*scale + shift (pd_gn_finalize's output) */
+  int rows_per_sample;      /* tokens per sample (multiple of 128 with scale; required with qkv_heads) */
+  int qkv_heads;            /* 0: dense y; > 0: y = [3][B][heads][rows_per_sample][8] (N = 3*heads*8, as pd_conv PD_OUT_QKV_HEADS) */
 } pd_linear_args;
 int pd_linear(const pd_linear_args* a, void* stream);
 

@@ -20,6 +20,9 @@ struct LinP {
   int t_tiles, c_tiles;
   unsigned xbytes;
   const void* x; const void* w; const float* bias; const void* residual; void* y;
+  const float* scale; const float* shift;   // optional GroupNorm affine on x: [sample][K], sample = row / rows_per_sample
+  int rows_per_sample;                      // multiple of 128 when scale is set (a token tile never straddles samples)
+  int qkv_heads, B;                         // > 0: head-major q / k / v output [3][B][heads][rows_per_sample][8] (N = 3 * heads * 8)
 };
 
 template <typename T, int NC>
@@ -70,17 +73,29 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
     soff[i] = m < p.M ? (unsigned)(((size_t)m * p.x_stride + sub * 8) * ES) : OOB_OFF;
   }
   SR stage[NIT];
+  // GroupNorm apply fused into the staging (Attention.group_norm in front of the q/k/v projection): this thread's 8 channels
+  // (sub-block tid & 7 of the chunk) of the tile's sample
+  const bool affine = p.scale != nullptr;
+  const size_t aff_row = affine ? (size_t)(m0 / p.rows_per_sample) * p.K + (tid & 7) * 8 : 0;
+  float sc[8], sh[8];
   auto issue = [&](int chunk) {
     const unsigned cb = (unsigned)(chunk * CK * ES);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) stage[i] = Stage<T>::load(rsx, soff[i] == OOB_OFF ? OOB_OFF : soff[i] + cb);
+    if (affine) {
+      const int kc = min(chunk * CK, p.K - 8 - (tid & 7) * 8);       // a trailing half chunk's upper sub-blocks are never read
+      const float* ps = p.scale + aff_row + kc;
+      const float* pb = p.shift + aff_row + kc;
+      const f32x4 a0 = *(const f32x4*)ps, a1 = *((const f32x4*)ps + 1), b0 = *(const f32x4*)pb, b1 = *((const f32x4*)pb + 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sc[j] = a0[j]; sc[4 + j] = a1[j]; sh[j] = b0[j]; sh[4 + j] = b1[j]; }
+    }
   };
   auto commit = [&](unsigned char* buf) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int pc = tid + 256 * i, tok = pc >> 3, sub = pc & 7;
-      if constexpr (ES == 2) *(u32x4*)(buf + tok * PITCH + sub * 16) = stage[i].v;
-      else { *(u32x4*)(buf + tok * PITCH + sub * 32) = stage[i].a; *(u32x4*)(buf + tok * PITCH + sub * 32 + 16) = stage[i].b; }
+      Stage<T>::xform_store(buf + tok * PITCH + sub * 8 * ES, stage[i], sc, sh, affine, false, soff[i] != OOB_OFF);
     }
   };
 
@@ -227,7 +242,13 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
           for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(__uint_as_float(v[j]) + __uint_as_float(rr[j]));
         }
       }
-      *(u32x4*)((T*)p.y + (size_t)m * p.N + co) = v;
+      if (p.qkv_heads > 0) {           // [which][B][heads][token][8]; a 16-byte piece never crosses a head
+        const int Cq = p.qkv_heads * 8, which = co / Cq, cc = co - which * Cq;
+        const long long nn = m / p.rows_per_sample, tok_s = m - nn * p.rows_per_sample;
+        *(u32x4*)((T*)p.y + ((((size_t)which * p.B + nn) * p.qkv_heads + (cc >> 3)) * p.rows_per_sample + tok_s) * 8 + (cc & 7)) = v;
+      } else {
+        *(u32x4*)((T*)p.y + (size_t)m * p.N + co) = v;
+      }
     }
   }
 }
@@ -414,6 +435,13 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   if (narrow) p.c_tiles = (a->N_pad + 63) / 64;
   p.xbytes = (unsigned)xbytes;
   p.x = a->x; p.w = a->w_packed; p.bias = a->bias; p.residual = a->residual; p.y = a->y;
+  PD_CHECK((a->scale == nullptr) == (a->shift == nullptr), PD_ERR_ARG, "pd_linear: scale/shift must be given together");
+  PD_CHECK(a->scale == nullptr || (a->rows_per_sample > 0 && a->rows_per_sample % 128 == 0 && a->M % a->rows_per_sample == 0 && a->K % 64 == 0),
+           PD_ERR_SHAPE, "pd_linear: the GroupNorm prologue needs rows_per_sample %% 128 == 0 and K %% 64 == 0");
+  PD_CHECK(a->qkv_heads == 0 || (a->N == 3 * a->qkv_heads * 8 && a->rows_per_sample > 0 && a->M % a->rows_per_sample == 0 && !a->residual),
+           PD_ERR_SHAPE, "pd_linear: head-major output needs N == 3*heads*8, rows_per_sample and no residual");
+  p.scale = a->scale; p.shift = a->shift; p.rows_per_sample = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+  p.qkv_heads = a->qkv_heads; p.B = a->rows_per_sample > 0 ? (int)(a->M / a->rows_per_sample) : 0;
   if (a->dtype == PD_F32) return narrow ? launch_linear<float, 1>(p, (hipStream_t)stream) : launch_linear<float, 2>(p, (hipStream_t)stream);
   return narrow ? launch_linear<bf16_t, 1>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2>(p, (hipStream_t)stream);
 }

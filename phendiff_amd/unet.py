@@ -551,8 +551,20 @@ class UNetPlan:
         if ch != e.heads * 8:
             raise NotImplementedError(f"pd_attn_d8 implements head_dim 8 only (got {ch // e.heads})")
         gn = self._gn(x, None, e.g, e.be, e.eps)
-        qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, out_mode=L.PD_OUT_QKV_HEADS,
-                            heads=e.heads)
+        if (h * w) % 128 == 0 and ch % 64 == 0:
+            # fused q/k/v projection through the GEMM kernel (GroupNorm apply while staging, head-major output): a 1x1 pd_conv
+            # stages 32-channel chunks with a barrier per 8 MFMAs and runs at about half its rate
+            qkv = torch.empty((3, B, e.heads, h * w, 8), dtype=self.tdt, device=self.device)
+            self.bufs.append(qkv)
+            M = B * h * w
+            a = L.LinearArgs(dtype=self.code, M=M, K=ch, N=3 * ch, N_pad=3 * ch, x=x.data_ptr(), x_stride=ch, w_packed=e.wqkv.data_ptr(),
+                             bias=e.bqkv.data_ptr(), residual=None, y=qkv.data_ptr(), scale=gn[0].data_ptr(), shift=gn[1].data_ptr(),
+                             rows_per_sample=h * w, qkv_heads=e.heads)
+            esz_ = 2 if self.code == L.PD_BF16 else 4
+            self.ops.append(_Op(self.lib.pd_linear, a, "conv1x1", 2.0 * M * ch * 3 * ch, (M * ch * 4 + 3 * ch * ch) * esz_))
+        else:
+            qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, out_mode=L.PD_OUT_QKV_HEADS,
+                                heads=e.heads)
         o = self._act(h, w, ch)
         lse = self._f32(B, e.heads, h * w) if self.train else None
         a = L.AttnArgs(dtype=self.code, B=B, heads=e.heads, N=h * w, q=qkv[0].data_ptr(), k=qkv[1].data_ptr(),
