@@ -230,3 +230,32 @@ def test_token_wgrad(env, mode, cfg, accumulate):
     a.dw = dw2.data_ptr()
     L.check(lib.pd_token_wgrad(C.byref(a), stream()), "pd_token_wgrad")
     assert torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_linear_gemm_groupnorm_prologue_and_head_major_output(env, mode):
+    """pd_linear as the fused q/k/v projection of the pixel-UNet attention: x*scale[n] + shift[n] applied while staging, output
+    written head-major [3][B][heads][tokens][8] (what pd_attn_d8 reads)."""
+    from phendiff_amd.packing import pack_conv_weight
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, Ntok, Cc, heads = 3, 256, 128, 16
+    g = torch.Generator().manual_seed(63)
+    x = bf16_round(torch.randn(B, Ntok, Cc, generator=g), mode)
+    scale, shift = torch.rand(B, Cc, generator=g) + 0.5, torch.randn(B, Cc, generator=g)
+    w = bf16_round(torch.randn(3 * Cc, Cc, generator=g) / Cc ** 0.5, mode)
+    bias = torch.randn(3 * Cc, generator=g)
+    z = bf16_round(x * scale[:, None, :] + shift[:, None, :], mode)          # the staged operand is rounded to the compute dtype
+    ref = torch.nn.functional.linear(z, w, bias)                             # [B][N][3C]
+    ref = ref.reshape(B, Ntok, 3, heads, 8).permute(2, 0, 3, 1, 4).contiguous()
+    wp = pack_conv_weight(w[:, :, None, None], tdt).to(dev)
+    X, sc, sh, bv = x.to(tdt).to(dev), scale.to(dev), shift.to(dev), bias.to(dev)
+    y = torch.full((3, B, heads, Ntok, 8), float("nan"), dtype=tdt, device=dev)
+    a = L.LinearArgs(dtype=code, M=B * Ntok, K=Cc, N=3 * Cc, N_pad=3 * Cc, x=X.data_ptr(), x_stride=Cc, w_packed=wp.data_ptr(),
+                     bias=bv.data_ptr(), residual=None, y=y.data_ptr(), scale=sc.data_ptr(), shift=sh.data_ptr(),
+                     rows_per_sample=Ntok, qkv_heads=heads)
+    L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+    torch.cuda.synchronize()
+    assert rel(y.float(), ref) < (3e-6 if mode == "f32" else 4e-3)
+    a.rows_per_sample = 200                                                   # not a multiple of 128: refused, not mis-addressed
+    assert lib.pd_linear(C.byref(a), stream()) == -2
