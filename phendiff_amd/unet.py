@@ -510,7 +510,7 @@ class UNetPlan:
 
     # pd_conv applies GroupNorm + SiLU while staging, once per 64-channel output tile; from this many output channels on
     # the input is normalised ONCE by pd_gn_apply instead and the convolution (and its weight gradient) runs without a prologue
-    PREAPPLY_MIN_COUT = 320      # measured: a win from 5 output tiles on (SD UNet: 7.7 vs 9.4 ms of 3x3 convs per forward), neutral at 4
+    PREAPPLY_MIN_COUT = int(__import__("os").environ.get("PD_PREAPPLY_MIN_COUT", 320))      # measured: a win from 5 output tiles on (SD UNet: 7.7 vs 9.4 ms of 3x3 convs per forward), neutral at 4
 
     def _gn_apply(self, x0, x1, gn, silu):
         B, h, w, c0 = x0.shape
