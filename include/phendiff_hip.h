@@ -451,6 +451,8 @@ typedef struct {
   const float* scale; const float* shift;   /* [M / rows_per_sample][K] or NULL: x <- x*scale + shift (pd_gn_finalize's output) */
   int rows_per_sample;      /* tokens per sample (multiple of 128 with scale; required with qkv_heads) */
   int qkv_heads;            /* 0: dense y; > 0: y = [3][B][heads][rows_per_sample][8] (N = 3*heads*8, as pd_conv PD_OUT_QKV_HEADS) */
+  float* stats_out;         /* NULL, or [M / rows_per_sample][rows_per_sample / 128][N][2]: per-128-token-tile channel (sum, sum of
+                               squares) of the stored y -- the consumer's GroupNorm statistics, folded by pd_gn_finalize (T = rows_per_sample/128) */
 } pd_linear_args;
 int pd_linear(const pd_linear_args* a, void* stream);
 

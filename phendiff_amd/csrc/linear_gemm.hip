@@ -23,6 +23,7 @@ struct LinP {
   const float* scale; const float* shift;   // optional GroupNorm affine on x: [sample][K], sample = row / rows_per_sample
   int rows_per_sample;                      // multiple of 128 when scale is set (a token tile never straddles samples)
   int qkv_heads, B;                         // > 0: head-major q / k / v output [3][B][heads][rows_per_sample][8] (N = 3 * heads * 8)
+  float* stats;                             // optional [B][rows_per_sample / 128][N][2]: per-tile channel (sum, sum of squares) of y
 };
 
 template <typename T, int NC>
@@ -221,6 +222,9 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
   constexpr int TPI = 256 / PPT;                       // tokens per iteration
   const int piece = tid % PPT, trow = tid / PPT;
   const int co = n0 + piece * EPC;
+  float ssum[EPC], ssq[EPC];           // GroupNorm statistics of what is stored (the consumer's norm input), as pd_conv emits them
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   if (co < p.N) {
 #pragma unroll 4
     for (int it = 0; it < TM / TPI; ++it) {
@@ -242,12 +246,43 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
           for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(__uint_as_float(v[j]) + __uint_as_float(rr[j]));
         }
       }
+      if (p.stats) {
+        if constexpr (ES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+            ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float xv = __uint_as_float(v[j]); ssum[j] += xv; ssq[j] += xv * xv; }
+        }
+      }
       if (p.qkv_heads > 0) {           // [which][B][heads][token][8]; a 16-byte piece never crosses a head
         const int Cq = p.qkv_heads * 8, which = co / Cq, cc = co - which * Cq;
         const long long nn = m / p.rows_per_sample, tok_s = m - nn * p.rows_per_sample;
         *(u32x4*)((T*)p.y + ((((size_t)which * p.B + nn) * p.qkv_heads + (cc >> 3)) * p.rows_per_sample + tok_s) * 8 + (cc & 7)) = v;
       } else {
         *(u32x4*)((T*)p.y + (size_t)m * p.N + co) = v;
+      }
+    }
+  }
+  if (p.stats) {       // kernel-uniform: per-thread partials -> LDS behind the output tile; (channel, sum | sumsq) threads add the
+                       // TPI token rows in a fixed order (deterministic)
+    float* red = (float*)(lds + TM * EP_PITCH);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) { red[tid * (2 * EPC) + j] = ssum[j]; red[tid * (2 * EPC) + EPC + j] = ssq[j]; }
+    __syncthreads();
+    if (tid < 2 * TN) {
+      const int c = tid >> 1, which = tid & 1;
+      const int pc = c / EPC, j = c % EPC;
+      float tot = 0.f;
+#pragma unroll 8
+      for (int pr = 0; pr < TPI; ++pr) tot += red[(pr * PPT + pc) * (2 * EPC) + which * EPC + j];
+      if (n0 + c < p.N) {
+        const long long nn = m0 / p.rows_per_sample;
+        const int tile = (int)((m0 - nn * p.rows_per_sample) / TM), T_ = p.rows_per_sample / TM;
+        p.stats[((nn * T_ + tile) * (size_t)p.N + n0 + c) * 2 + which] = tot;
       }
     }
   }
@@ -394,7 +429,8 @@ template <typename T, int NC>
 static int launch_linear(const LinP& p, hipStream_t st) {
   constexpr int ES = Elem<T>::BYTES;
   constexpr int XT = 128 * (64 * ES + 16), EPI = 128 * (64 * NC * ES + 16);
-  constexpr int LDS = 2 * XT > EPI ? 2 * XT : EPI;
+  constexpr int EPI_ST = EPI + 256 * (2 * 16 / ES) * 4;        // + per-thread statistics partials
+  constexpr int LDS = 2 * XT > EPI_ST ? 2 * XT : EPI_ST;
   auto kern = linear_kernel<T, NC>;
   if (LDS > 64 * 1024) {
     static bool attr_set = false;
@@ -442,6 +478,9 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
            PD_ERR_SHAPE, "pd_linear: head-major output needs N == 3*heads*8, rows_per_sample and no residual");
   p.scale = a->scale; p.shift = a->shift; p.rows_per_sample = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
   p.qkv_heads = a->qkv_heads; p.B = a->rows_per_sample > 0 ? (int)(a->M / a->rows_per_sample) : 0;
+  PD_CHECK(a->stats_out == nullptr || (a->rows_per_sample > 0 && a->rows_per_sample % 128 == 0 && a->M % a->rows_per_sample == 0 && a->qkv_heads == 0),
+           PD_ERR_SHAPE, "pd_linear: stats_out needs rows_per_sample %% 128 == 0 and dense output");
+  p.stats = a->stats_out;
   if (a->dtype == PD_F32) return narrow ? launch_linear<float, 1>(p, (hipStream_t)stream) : launch_linear<float, 2>(p, (hipStream_t)stream);
   return narrow ? launch_linear<bf16_t, 1>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2>(p, (hipStream_t)stream);
 }

@@ -338,20 +338,6 @@ class SDUNetPlan(UNetPlan):
         self.ops.append(_Op(self.lib.pd_layernorm, a, "layernorm", 0.0, 2.0 * x.numel() * self._esz()))
         return y
 
-    def _linear(self, x, wpk, bias, cout, residual=None, y=None, what="linear"):
-        """nn.Linear over the tokens of an NHWC tensor through the dedicated GEMM (``pd_linear``); ``wpk`` is pd_conv's packed
-        1x1 layout, so forward and input-gradient weights are shared with the convolution path."""
-        B, h, w, K = x.shape
-        if y is None:
-            y = self._act(h, w, cout)
-        M = B * h * w
-        a = L.LinearArgs(dtype=self.code, M=M, K=K, N=cout, N_pad=((cout + 31) // 32) * 32, x=x.data_ptr(), x_stride=K,
-                         w_packed=wpk.data_ptr(), bias=bias.data_ptr(), residual=L.ptr(residual), y=y.data_ptr())
-        esz = self._esz()
-        self.ops.append(_Op(self.lib.pd_linear, a, what, 2.0 * M * K * cout,
-                            (M * K + M * cout * (2 if residual is not None else 1) + K * cout) * esz))
-        return y
-
     def _attention(self, q, qs, k, v, kvs, heads, nq, nkv):
         out = self._act(1, nq, heads * 64).view(self.B, 1, nq, heads * 64)
         lse = self._f32(self.B, heads, nq) if self.train else None
@@ -367,7 +353,10 @@ class SDUNetPlan(UNetPlan):
         N, esz = h * w, self._esz()
         lin = lambda src, wt, bias, cout, residual=None: self._linear(src, wt, bias, cout, residual)
         gn = self._gn(x, None, e.g, e.be, e.eps)
-        h0, _ = self._conv(x, None, e.w_in, e.b_in, ch, ksize=1, pad=0, stats=False, gn=gn)     # GroupNorm applied while staging
+        if self._linear_ok(x):
+            h0 = self._linear(x, e.w_in, e.b_in, ch, gn=gn)                                       # GroupNorm applied while staging
+        else:
+            h0, _ = self._conv(x, None, e.w_in, e.b_in, ch, ksize=1, pad=0, stats=False, gn=gn)
         # self attention
         y1 = self._layernorm(h0, e.ln1)
         qkv = lin(y1, e.wqkv1, zb, 3 * ch)
@@ -389,7 +378,10 @@ class SDUNetPlan(UNetPlan):
         ga = L.GegluArgs(dtype=self.code, rows=B * N, inner=4 * ch, x=ff.data_ptr(), y=gg.data_ptr())
         self.ops.append(_Op(self.lib.pd_geglu, ga, "geglu", 0.0, 3.0 * gg.numel() * esz))
         h3 = lin(gg, e.wff2, e.bff2, ch, residual=h2)
-        out, _ = self._conv(h3, None, e.w_out, e.b_out, ch, ksize=1, pad=0, residual=x)       # statistics for the next GroupNorm
+        if self._linear_ok(h3):
+            out = self._linear(h3, e.w_out, e.b_out, ch, residual=x, stats=True)                  # statistics for the next GroupNorm
+        else:
+            out, _ = self._conv(h3, None, e.w_out, e.b_out, ch, ksize=1, pad=0, residual=x)
         self.tape.append(SimpleNamespace(kind="transformer", name=name, e=e, x=x, gn=gn, h0=h0, y1=y1, qkv=qkv, a1=a1, lse1=lse1,
                                          h1=h1, y2=y2, q2=q2, kv=kv, a2=a2, lse2=lse2, h2=h2, y3=y3, ff=ff, gg=gg, h3=h3, out=out))
         return out

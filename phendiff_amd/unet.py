@@ -521,6 +521,33 @@ class UNetPlan:
         self.ops.append(_Op(self.lib.pd_gn_apply, a, "gn_apply", 0.0, 2.0 * y.numel() * (2 if self.code == L.PD_BF16 else 4)))
         return y
 
+    def _linear(self, x, wpk, bias, cout, residual=None, y=None, gn=None, stats=False, what="linear"):
+        """nn.Linear over the tokens of an NHWC tensor through the GEMM kernel (``pd_linear``); ``wpk`` is pd_conv's packed 1x1
+        layout, so forward and input-gradient weights are shared with the convolution path.  ``gn``: GroupNorm apply fused into
+        the staging; ``stats``: emit the output's per-tile GroupNorm statistics.  Both need tokens-per-sample % 128 == 0
+        (:meth:`_linear_ok`)."""
+        B, h, w, K = x.shape
+        if y is None:
+            y = self._act(h, w, cout)
+        M, esz = B * h * w, (2 if self.code == L.PD_BF16 else 4)
+        st = None
+        if stats:
+            T = (h * w) // 128
+            st = self._f32(B, T, cout, 2)
+            self.stats[id(y)] = (st, T)
+        a = L.LinearArgs(dtype=self.code, M=M, K=K, N=cout, N_pad=((cout + 31) // 32) * 32, x=x.data_ptr(), x_stride=K,
+                         w_packed=wpk.data_ptr(), bias=bias.data_ptr(), residual=L.ptr(residual), y=y.data_ptr(),
+                         scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None, rows_per_sample=h * w, qkv_heads=0,
+                         stats_out=L.ptr(st))
+        self.ops.append(_Op(self.lib.pd_linear, a, what, 2.0 * M * K * cout,
+                            (M * K + M * cout * (2 if residual is not None else 1) + K * cout) * esz))
+        return y
+
+    @staticmethod
+    def _linear_ok(x):
+        """pd_linear's fused GroupNorm prologue / statistics epilogue work on whole 128-token tiles of one sample."""
+        return (x.shape[1] * x.shape[2]) % 128 == 0 and x.shape[3] % 64 == 0
+
     def _resnet(self, name, x0, x1=None):
         e = self.w.resnets[name]
         pre = e.cout >= self.PREAPPLY_MIN_COUT
@@ -572,7 +599,10 @@ class UNetPlan:
         esz = 2 if self.code == L.PD_BF16 else 4
         N = h * w
         self.ops.append(_Op(self.lib.pd_attn_d8, a, "attn_d8", 4.0 * B * e.heads * N * N * 8, 4.0 * B * N * ch * esz))
-        out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
+        if self._linear_ok(o):
+            out = self._linear(o, e.wo, e.bo, ch, residual=x, stats=True, what="conv1x1")
+        else:
+            out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
         self.tape.append(SimpleNamespace(kind="attn", name=name, x=x, qkv=qkv, o=o, out=out, lse=lse, gn=gn, e=e))
         return out
 

@@ -367,6 +367,8 @@ class _VaePlan(UNetPlan):
                                k=p + ch * esz, v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch)
             fn, what = self.lib.pd_attn_wide, "attn_wide"
         self.ops.append(_Op(fn, a, what, 4.0 * B * N * N * ch, 4.0 * B * N * ch * esz))
+        if self._linear_ok(o):
+            return self._linear(o, e.wo, e.bo, ch, residual=x, stats=True, what="conv1x1")
         out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
         return out
 
