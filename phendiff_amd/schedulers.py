@@ -132,8 +132,10 @@ class _SchedulerBase:
         L.check(lib.pd_ddim_step(C.byref(a), st), "pd_ddim_step")
         if eta > 0:
             if variance_noise is None:
-                variance_noise = torch.randn(mo.shape, generator=generator, device=mo.device, dtype=mo.dtype)
-            prev = prev + sigma * variance_noise
+                # diffusers randn_tensor: a CPU generator draws on the CPU (then moves), a device generator on the device
+                gdev = generator.device if generator is not None else mo.device
+                variance_noise = torch.randn(mo.shape, generator=generator, device=gdev, dtype=mo.dtype).to(mo.device)
+            prev = prev + sigma * variance_noise.to(device=mo.device, dtype=mo.dtype)
         return prev, x0
 
     def _per_sample_coefs(self, timesteps, device):
