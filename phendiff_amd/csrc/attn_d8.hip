@@ -8,6 +8,7 @@
 //   O^T[row][query] += A[row][key] . P^T[key][query]  A rows 0..7 = V^T (d), rows 8..15 = 1.0  (=> row sum l for free)
 // Workgroup = 4 waves = 128 queries; K and V^T tiles of 256 keys are staged through double-buffered LDS (V transposed on
 // the way, next tile's global loads in flight during the current tile's math, one barrier per tile).
+#include <stdlib.h>
 #include "pd_common.h"
 
 namespace pd {
@@ -159,10 +160,12 @@ template <> struct AttnOps<float> {
   }
 };
 
-template <typename T, int QB>
-__global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
+// WPB waves per workgroup share every staged K / V^T tile: with 8 waves (512 threads, 256 queries) each thread stages a key
+// every other tile, i.e. half the staging VALU / LDS-write work per query of the 4-wave form at the same 4 waves per SIMD
+template <typename T, int QB, int WPB>
+__global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
   constexpr int QPW = 32 * QB;                       // queries per wave
-  constexpr int QPB = 4 * QPW;                       // queries per workgroup
+  constexpr int QPB = WPB * QPW;                     // queries per workgroup
   using E = Elem<T>;
   using Ops = AttnOps<T>;
   constexpr int KROW = Ops::KROW;
@@ -218,28 +221,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
     if (tid == 0) *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f);
-    *(T*)(vlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(1.0f);
+    if (tid < KT) *(T*)(vlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(1.0f);
   }
   const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
   const int ka0 = Ops::kaddr(r, h), kst = Ops::kstep(h);
 
-  // staging: thread t owns K row t and V row t of the 256-key tile
+  // staging: thread (t & 255) owns K row t and V row t of a 256-key tile; with 8 waves the two halves of the workgroup take
+  // the even / odd tiles in turn (wave-uniform), so the staging work is spread over all waves
+  const int st = tid & (KT - 1);
+  const int my_parity = (WPB * 64 > KT) ? (tid / KT) : 0;
+  auto mine = [&](int tile) { return (WPB * 64 > KT) ? ((tile & 1) == my_parity) : true; };
   typename E::Frag stk, stv;
   auto issue = [&](int k0) {
-    const int key = k0 + tid;
+    if (!mine(k0 / KT)) return;
+    const int key = k0 + st;
     if (key < N) { stk = E::load(kp + (size_t)key * 8); stv = E::load(vp + (size_t)key * 8); }
     else { stk = E::zero(); stv = E::zero(); }
   };
-  auto commit = [&](int b2) {
-    E::store(klds[b2] + tid * KROW, stk);
+  auto commit = [&](int b2, int k0) {
+    if (!mine(k0 / KT)) return;
+    E::store(klds[b2] + st * KROW, stk);
     float n2 = row16_max(Ops::k_norm2(stk));
     n2 = fmaxf(n2, __shfl_xor(n2, 16));
-    if ((tid & 31) == 0) knmax[b2][tid >> 5] = sqrtf(n2) * 1.00002f;
-    Ops::store_vt(vlds[b2], Ops::vpos(tid), stv);
+    if ((st & 31) == 0) knmax[b2][st >> 5] = sqrtf(n2) * 1.00002f;
+    Ops::store_vt(vlds[b2], Ops::vpos(st), stv);
   };
 
   issue(0);
-  commit(0);
+  commit(0, 0);
   if (KT < N) issue(KT);
   __syncthreads();
   for (int k0 = 0, cur = 0; k0 < N; k0 += KT, cur ^= 1) {
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args a) {
       }
     }
     if (k0 + KT < N) {
-      commit(cur ^ 1);                       // tile k0+KT: loaded during the previous tile's math
+      commit(cur ^ 1, k0 + KT);              // tile k0+KT: loaded during the previous tile's math
       if (k0 + 2 * KT < N) issue(k0 + 2 * KT);
     }
     __syncthreads();
@@ -574,15 +583,19 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
 #else
   const int qbw = 1;
 #endif
-  const int qpb = 128 * qbw;
+  // 8-wave workgroups (256 queries share each staged tile) once there are enough query blocks to fill the chip with them
+  static const bool wpb4_only = getenv("PD_ATTN_WPB4") != nullptr;      // diagnostic: same-box A/B
+  const bool wide = !wpb4_only && qbw == 1 && a->N >= 1024 && (long long)(a->N / 256) * a->heads * a->B >= 1024;
+  const int qpb = wide ? 256 : 128 * qbw;
   PD_CHECK((long long)((a->N + qpb - 1) / qpb) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8: grid too large");
   dim3 grid(((a->N + qpb - 1) / qpb) * a->heads * a->B);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PD_F32) {
-    hipLaunchKernelGGL((attn_kernel<float, 1>), dim3(((a->N + 127) / 128) * a->heads * a->B), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL((attn_kernel<float, 1, 4>), dim3(((a->N + 127) / 128) * a->heads * a->B), dim3(256), 0, st, *a);
   } else if (a->dtype == PD_BF16) {
-    if (qbw == 2) hipLaunchKernelGGL((attn_kernel<bf16_t, 2>), grid, dim3(256), 0, st, *a);
-    else hipLaunchKernelGGL((attn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, *a);
+    if (qbw == 2) hipLaunchKernelGGL((attn_kernel<bf16_t, 2, 4>), grid, dim3(256), 0, st, *a);
+    else if (wide) hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, *a);
+    else hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 4>), grid, dim3(256), 0, st, *a);
   } else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

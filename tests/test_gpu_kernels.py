@@ -193,7 +193,8 @@ def test_gn_stats(env, mode, cfg):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [(2, 4, 64), (1, 32, 1024), (2, 8, 200), (1, 2, 16)])
+@pytest.mark.parametrize("cfg", [(2, 4, 64), (1, 32, 1024), (2, 8, 200), (1, 2, 16),
+                                 (8, 32, 1024), (4, 32, 2100)])      # the last two: 8-wave workgroups in bf16 (even / ragged N)
 def test_attention(env, mode, cfg):
     L, lib, _, dev = env
     code, tdt = DT[mode]
@@ -224,6 +225,25 @@ def test_attention_online_softmax_rescale(env):
     torch.cuda.synchronize()
     ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).transpose(1, 2).reshape(B, N, heads * 8)
     assert float((out.cpu().double() - ref).abs().max()) < 1e-4
+
+
+def test_attention_rescale_8_wave_workgroups(env):
+    """The same spikes through the bf16 8-wave variant (two halves of the workgroup stage alternate key tiles)."""
+    L, lib, _, dev = env
+    g = torch.Generator().manual_seed(18)
+    B, heads, N = 4, 32, 2048
+    q, k, v = (bf16_round(torch.randn(B, heads, N, 8, generator=g), "bf16") for _ in range(3))
+    k[:, :, 1900] = q[:, :, 5] * 6.0
+    k[:, :, 300] = q[:, :, 1030] * 9.0
+    k[:, :, 777] = q[:, :, 2047] * 4.0
+    q, k = bf16_round(q, "bf16"), bf16_round(k, "bf16")
+    Q, K, V = (t.to(torch.bfloat16).to(dev).contiguous() for t in (q, k, v))
+    out = torch.full((B, N, heads * 8), float("nan"), dtype=torch.bfloat16, device=dev)
+    a = L.AttnArgs(dtype=1, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), out=out.data_ptr())
+    L.check(lib.pd_attn_d8(C.byref(a), stream()), "pd_attn_d8")
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, heads * 8)
+    assert rel(out.float(), ref) < 1.5e-2
 
 
 def test_conv_in(env):
