@@ -37,3 +37,5 @@ from .pipeline_ref import (  # noqa: F401
     linear_interp_custom_guidance_inverted_start_ref,
     tensor_to_uint8_ref,
 )
+from .eval_generation_ref import (  # noqa: F401
+    EMASwapRef, eval_batch_sizes_ref, eval_generation_ddim_ref, eval_generation_sd_ref, latents_preview_ref, split_ref)

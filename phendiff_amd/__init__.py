@@ -16,6 +16,7 @@ from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401
 from . import training  # noqa: F401
 from .unet_train import UNetTrainer, UNetTrainPlan, training_param_order  # noqa: F401
 from . import train_state  # noqa: F401
+from . import eval_generation  # noqa: F401
 from .sd_unet import SDUNet2DConditionModel, CustomEmbedding, class_emb_to_encoder_hidden_states, SD21_UNET_CONFIG  # noqa: F401
 from .vae import AutoencoderKL, VaeImageProcessor, DiagonalGaussianDistribution, SD_VAE_CONFIG  # noqa: F401
 from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline, hack_class_embedding  # noqa: F401
