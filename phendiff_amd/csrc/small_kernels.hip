@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a, int ski
   const int row = blockIdx.x, tid = threadIdx.x;
   const float t = a.timesteps[row];
   const int half = a.c0 / 2;
+  const bool first = blockIdx.y == 0;    // gridDim.y > 1 (wide models): every block redoes the cheap first layer, and takes a
+                                         // 256-output slice of the second; same per-output summation order either way
   for (int i = tid; i < a.c0; i += 256) {
     // get_timestep_embedding: emb = [sin | cos], flipped to [cos | sin] when flip_sin_to_cos
     const bool second = i >= half;
@@ -34,19 +36,23 @@ __global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a, int ski
     const float arg = t * expf(expo);
     const bool want_sin = a.flip_sin_to_cos ? second : !second;
     se[i] = want_sin ? sinf(arg) : cosf(arg);
-    if (a.feat) a.feat[(size_t)row * a.c0 + i] = se[i];
+    if (a.feat && first) a.feat[(size_t)row * a.c0 + i] = se[i];
   }
   __syncthreads();
   for (int o = tid; o < a.tdim; o += 256) {
     float acc = a.b1[o];
-    for (int i = 0; i < a.c0; ++i) acc += a.w1[(size_t)i * a.tdim + o] * se[i];
-    if (a.z1) a.z1[(size_t)row * a.tdim + o] = acc;
+    const float* w = a.w1 + o;
+#pragma unroll 8
+    for (int i = 0; i < a.c0; ++i) acc += w[(size_t)i * a.tdim] * se[i];
+    if (a.z1 && first) a.z1[(size_t)row * a.tdim + o] = acc;
     h1[o] = silu_f(acc);
   }
   __syncthreads();
-  for (int o = tid; o < a.tdim; o += 256) {
+  for (int o = blockIdx.y * 256 + tid; o < a.tdim; o += 256 * gridDim.y) {
     float acc = a.b2[o];
-    for (int i = 0; i < a.tdim; ++i) acc += a.w2[(size_t)i * a.tdim + o] * h1[i];
+    const float* w = a.w2 + o;
+#pragma unroll 8
+    for (int i = 0; i < a.tdim; ++i) acc += w[(size_t)i * a.tdim] * h1[i];
     if (a.class_emb) acc += a.class_emb[(size_t)row * a.tdim + o];
     else if (a.labels && a.class_table) acc += a.class_table[(size_t)a.labels[row] * a.tdim + o];
     if (a.emb) a.emb[(size_t)row * a.tdim + o] = acc;
@@ -56,23 +62,41 @@ __global__ __launch_bounds__(256) void temb_kernel(const pd_temb_args a, int ski
   if (skip_proj) return;                 // the projections run in temb_proj_kernel (wide models: one block per 256 outputs)
   for (int o = tid; o < a.proj_dim; o += 256) {
     float acc = a.bp[o];
-    for (int i = 0; i < a.tdim; ++i) acc += a.wp[(size_t)i * a.proj_dim + o] * act[i];
+    const float* w = a.wp + o;
+#pragma unroll 8
+    for (int i = 0; i < a.tdim; ++i) acc += w[(size_t)i * a.proj_dim] * act[i];
     a.proj[(size_t)row * a.proj_dim + o] = acc;
   }
 }
 
-// proj[r][o] = bp[o] + sum_i wp[i][o] * silu(emb[r][i]);  grid (rows, proj_dim / 256).  Same summation order as the tail of
-// temb_kernel, so both paths give identical bits.
+// proj[r][o] = bp[o] + sum_i wp[i][o] * silu(emb[r][i]);  grid (ceil(rows / TEMB_R), proj_dim / 256): a block keeps TEMB_R rows
+// of activations in LDS so each weight it streams serves TEMB_R rows.  Same summation order as the tail of temb_kernel, so
+// both paths give identical bits.
+constexpr int TEMB_R = 8;
 __global__ __launch_bounds__(256) void temb_proj_kernel(const pd_temb_args a) {
-  extern __shared__ float act[];
-  const int row = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < a.tdim; i += 256) act[i] = silu_f(a.emb[(size_t)row * a.tdim + i]);
+  extern __shared__ float act[];         // [TEMB_R][tdim]
+  const int row0 = blockIdx.x * TEMB_R, tid = threadIdx.x;
+  const int nr = min(TEMB_R, a.rows - row0);
+  for (int i = tid; i < TEMB_R * a.tdim; i += 256) {
+    const int r = i / a.tdim;
+    act[i] = r < nr ? silu_f(a.emb[(size_t)(row0 + r) * a.tdim + (i - r * a.tdim)]) : 0.f;
+  }
   __syncthreads();
   const int o = blockIdx.y * 256 + tid;
   if (o >= a.proj_dim) return;
-  float acc = a.bp[o];
-  for (int i = 0; i < a.tdim; ++i) acc += a.wp[(size_t)i * a.proj_dim + o] * act[i];
-  a.proj[(size_t)row * a.proj_dim + o] = acc;
+  float acc[TEMB_R];
+#pragma unroll
+  for (int r = 0; r < TEMB_R; ++r) acc[r] = a.bp[o];
+  const float* w = a.wp + o;
+#pragma unroll 4
+  for (int i = 0; i < a.tdim; ++i) {
+    const float wv = w[(size_t)i * a.proj_dim];
+#pragma unroll
+    for (int r = 0; r < TEMB_R; ++r) acc[r] += wv * act[r * a.tdim + i];
+  }
+#pragma unroll
+  for (int r = 0; r < TEMB_R; ++r)
+    if (r < nr) a.proj[(size_t)(row0 + r) * a.proj_dim + o] = acc[r];
 }
 
 // ================================================================================================
@@ -336,11 +360,12 @@ extern "C" int pd_temb(const pd_temb_args* a, void* stream) {
   // wide projection stacks (the SD UNet: 22 720 outputs of 1280 inputs per row) on few rows: spread the projections over
   // proj_dim / 256 blocks per row; needs the emb buffer as the hand-over
   const int split = a->emb != nullptr && (long long)a->proj_dim * a->tdim >= (1 << 22) && a->rows < 1024;
-  hipLaunchKernelGGL(temb_kernel, dim3(a->rows), dim3(256), sm, (hipStream_t)stream, *a, split);
+  hipLaunchKernelGGL(temb_kernel, dim3(a->rows, split ? (a->tdim + 255) / 256 : 1), dim3(256), sm, (hipStream_t)stream, *a, split);
   PD_LAUNCH_CHECK();
   if (split) {
-    hipLaunchKernelGGL(temb_proj_kernel, dim3(a->rows, (a->proj_dim + 255) / 256), dim3(256), (size_t)a->tdim * sizeof(float),
-                       (hipStream_t)stream, *a);
+    PD_CHECK((size_t)TEMB_R * a->tdim * sizeof(float) <= 64 * 1024, PD_ERR_SHAPE, "pd_temb: tdim too large for the split projection");
+    hipLaunchKernelGGL(temb_proj_kernel, dim3((a->rows + TEMB_R - 1) / TEMB_R, (a->proj_dim + 255) / 256), dim3(256),
+                       (size_t)TEMB_R * a->tdim * sizeof(float), (hipStream_t)stream, *a);
     PD_LAUNCH_CHECK();
   }
   return PD_OK;

@@ -311,6 +311,43 @@ def test_temb(env):
     assert rel(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("rows,with_emb", [(11, True), (11, False), (3, True)])
+def test_temb_wide_projection_stack(env, rows, with_emb):
+    """pd_temb at SD width (tdim 1280, > 4 M projection weights): with the `emb` hand-over buffer the second layer is split
+    over tdim / 256 blocks per row and the projections run 8 rows per block; without it one block per row does everything.
+    Both against a CPU fp64 restatement of Timesteps -> TimestepEmbedding -> silu -> stacked time_emb_proj."""
+    import math
+    L, lib, _, dev = env
+    g = torch.Generator().manual_seed(21)
+    c0, tdim, pdim = 320, 1280, 3400                   # 3400: not a multiple of 256
+    w1, w2, wp = (torch.randn(i, o, generator=g) / math.sqrt(i) for i, o in ((c0, tdim), (tdim, tdim), (tdim, pdim)))
+    b1, b2, bp = (torch.randn(n, generator=g) * 0.1 for n in (tdim, tdim, pdim))
+    ts = torch.randint(0, 1000, (rows,), generator=g).float()
+    D = [t.to(dev).contiguous() for t in (w1, b1, w2, b2, wp, bp, ts)]
+    emb = torch.full((rows, tdim), float("nan"), device=dev) if with_emb else None
+    proj = torch.full((rows, pdim), float("nan"), device=dev)
+    z1 = torch.full((rows, tdim), float("nan"), device=dev)
+    feat = torch.full((rows, c0), float("nan"), device=dev)
+    a = L.TembArgs(rows=rows, c0=c0, tdim=tdim, proj_dim=pdim, flip_sin_to_cos=1, freq_shift=0.0, num_classes=0,
+                   timesteps=D[6].data_ptr(), labels=None, class_emb=None, w1=D[0].data_ptr(), b1=D[1].data_ptr(),
+                   w2=D[2].data_ptr(), b2=D[3].data_ptr(), class_table=None, wp=D[4].data_ptr(), bp=D[5].data_ptr(),
+                   emb=L.ptr(emb), proj=proj.data_ptr(), feat=feat.data_ptr(), z1=z1.data_ptr())
+    L.check(lib.pd_temb(C.byref(a), stream()), "pd_temb")
+    torch.cuda.synchronize()
+    half = c0 // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float64) / half)
+    arg = ts.double()[:, None] * freqs[None]
+    se = torch.cat([arg.cos(), arg.sin()], 1)          # flip_sin_to_cos
+    z1_ref = se @ w1.double() + b1.double()
+    emb_ref = F.silu(z1_ref) @ w2.double() + b2.double()
+    proj_ref = F.silu(emb_ref) @ wp.double() + bp.double()
+    assert rel(feat.cpu().double(), se) < 1e-4         # fp32 sin / cos of arguments up to 1000
+    assert rel(z1.cpu().double(), z1_ref) < 1e-4
+    if with_emb:
+        assert rel(emb.cpu().double(), emb_ref) < 1e-4
+    assert rel(proj.cpu().double(), proj_ref) < 1e-4
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 64, 64, 40, 72, 3, 1), (1, 32, 96, 16, 16, 3, 1), (2, 64, 64, 32, 32, 3, 2), (2, 64, 128, 8, 8, 1, 1)])
 def test_conv_fused_gn_statistics(env, mode, shape):
