@@ -368,7 +368,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many concurrently replayed "
-                    "trajectories (separate HIP streams): MFMA-bound convs of one overlap VALU-bound attention of another")
+                    "trajectories (separate HIP streams); measured: no gain (DESIGN.md section 6, scripts/bench_concurrent.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -416,7 +416,9 @@ def main():
         def run(self, x, labels, target):
             for i, r_ in enumerate(runners):
                 sl = slice(i * Bs, (i + 1) * Bs)
-                r_.run(x[sl], labels[sl], target[sl])
+                r_.run(x[sl], labels[sl], target[sl], join=False)
+            for r_ in runners:
+                r_.join()
     multi = _Multi()
 
     def barrier():

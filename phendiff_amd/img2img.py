@@ -323,7 +323,10 @@ class DDIBGraph:
         L.check(rc, "pd_graph_end")
 
     @torch.no_grad()
-    def run(self, clean_images: torch.Tensor, orig_class_labels: torch.Tensor, target_class_labels: torch.Tensor):
+    def run(self, clean_images: torch.Tensor, orig_class_labels: torch.Tensor, target_class_labels: torch.Tensor,
+            join: bool = True):
+        """``join=False`` leaves the caller's stream un-joined (call ``self.join()`` before reading the outputs), so several
+        runners can replay concurrently on their own streams."""
         B = self.B
         if clean_images.shape != self.x.shape:
             raise ValueError(f"expected images of shape {tuple(self.x.shape)}, got {tuple(clean_images.shape)}")
@@ -343,7 +346,12 @@ class DDIBGraph:
                     self._ones = torch.ones((B,), dtype=torch.float32, device=self.device)
                     self._zeros = torch.zeros((B,), dtype=torch.float32, device=self.device)
                 self._enqueue(self.stream.cuda_stream)
-        cur.wait_stream(self.stream)
+        if join:
+            cur.wait_stream(self.stream)
+        return self
+
+    def join(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self
 
     def __del__(self):
