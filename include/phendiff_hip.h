@@ -453,6 +453,10 @@ typedef struct {
   int qkv_heads;            /* 0: dense y; > 0: y = [3][B][heads][rows_per_sample][8] (N = 3*heads*8, as pd_conv PD_OUT_QKV_HEADS) */
   float* stats_out;         /* NULL, or [M / rows_per_sample][rows_per_sample / 128][N][2]: per-128-token-tile channel (sum, sum of
                                squares) of the stored y -- the consumer's GroupNorm statistics, folded by pd_gn_finalize (T = rows_per_sample/128) */
+  int glu;                  /* 1: fused GEGLU (diffusers FeedForward.net[0] = GEGLU: proj -> chunk(2) -> value * gelu(gate)):
+                               y = [M][N/2]; w_packed holds the projection's value rows (0 .. N/2) in the even and its gate rows
+                               (N/2 .. N) in the odd 32-channel tiles (two pd_pack_weight calls with dst_ct_stride = two tiles);
+                               bias stays in module order [N].  N % 64 == 0, no residual / statistics / head-major output */
 } pd_linear_args;
 int pd_linear(const pd_linear_args* a, void* stream);
 

@@ -130,7 +130,7 @@ class GnApplyArgs(C.Structure):
 class LinearArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_longlong), ("K", C.c_int), ("N", C.c_int), ("N_pad", C.c_int), ("x", vp),
                 ("x_stride", C.c_int), ("w_packed", vp), ("bias", vp), ("residual", vp), ("y", vp), ("scale", vp), ("shift", vp),
-                ("rows_per_sample", C.c_int), ("qkv_heads", C.c_int), ("stats_out", vp)]
+                ("rows_per_sample", C.c_int), ("qkv_heads", C.c_int), ("stats_out", vp), ("glu", C.c_int)]
 
 
 class AttnWideArgs(C.Structure):

@@ -26,7 +26,22 @@ struct LinP {
   float* stats;                             // optional [B][rows_per_sample / 128][N][2]: per-tile channel (sum, sum of squares) of y
 };
 
-template <typename T, int NC>
+// gelu(g) = g/2 (1 + erf(g / sqrt 2)), F.gelu's default (exact) form.  The bf16 engine takes erf from Abramowitz-Stegun 7.1.26
+// (|error| < 1.5e-7, far below bf16's 2^-9; one v_exp + one v_rcp + 7 FMAs), the fp32 parity mode calls erff.
+template <int ES> __device__ __forceinline__ float gelu_f(float g) {
+  if constexpr (ES == 4) return 0.5f * g * (1.0f + erff(g * 0.7071067811865476f));
+  const float x = fabsf(g) * 0.7071067811865476f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);     // erf(|g| / sqrt 2)
+  return 0.5f * g + 0.5f * fabsf(g) * e;                                                     // g/2 (1 + sign(g) erf) 
+}
+
+// GLU = true (NC = 2): the weights are packed with the VALUE and GATE rows of FeedForward.net[0].proj (GEGLU) interleaved per
+// 32-channel tile -- packed tile 2u = value channels 32u.., tile 2u+1 = gate channels N/2 + 32u.. -- so a wave's two channel
+// tiles are a value / gate pair and the epilogue stores value * gelu(gate): N/2 output channels, the 2N-wide projection
+// never reaches HBM.
+template <typename T, int NC, bool GLU = false>
 __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -36,7 +51,9 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
   constexpr int PITCH = CK * ES + 16;                  // odd number of 16-B slots: conflict-free ds_read_b128 over 32 tokens
   constexpr int XTILE = TM * PITCH;
   constexpr int NIT = TM * CK / 8 / 256;               // 8-channel pieces per thread per chunk (4)
+  constexpr int TNO = GLU ? TN / 2 : TN;               // output channels per workgroup tile
   constexpr int EP_PITCH = TN * ES + 16;
+  static_assert(!GLU || NC == 2, "the fused GEGLU epilogue pairs the two channel tiles of a wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][XTILE] | epilogue [TM][EP_PITCH]
 
   // block -> (token tile, channel tile): the channel tiles of one token tile are 8 blocks apart in dispatch order, i.e. on
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     f32x16 init;
-    const int cob = ct32[c] * 32;
+    const int cob = GLU ? ((ct32[c] & 1) ? p.N / 2 : 0) + 32 * (ct32[c] >> 1) : ct32[c] * 32;   // bias stays in module order
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 bv = *(const f32x4*)(p.bias + cob + 8 * g + 4 * h);
@@ -206,6 +223,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
   }
 
   // ---- epilogue: [token][128 channels] through LDS, then coalesced 16-byte residual loads / stores
+  if constexpr (GLU) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int tok = wp * 64 + f * 32 + r;
+      f32x16 o;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = acc[0][f][i] * gelu_f<ES>(acc[NC - 1][f][i]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        store4((T*)(lds + tok * EP_PITCH) + wc * 32 + 8 * g + 4 * h, o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+    }
+  } else
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -218,14 +247,16 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
     }
   __syncthreads();
   constexpr int EPC = 16 / ES;                         // channels per 16-byte piece
-  constexpr int PPT = TN / EPC;                        // pieces per token
+  constexpr int PPT = TNO / EPC;                       // pieces per token
   constexpr int TPI = 256 / PPT;                       // tokens per iteration
   const int piece = tid % PPT, trow = tid / PPT;
-  const int co = n0 + piece * EPC;
+  const int NO = GLU ? p.N / 2 : p.N;                  // output row length
+  const int n0o = GLU ? ct * TNO : n0;
+  const int co = n0o + piece * EPC;
   float ssum[EPC], ssq[EPC];           // GroupNorm statistics of what is stored (the consumer's norm input), as pd_conv emits them
 #pragma unroll
   for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  if (co < p.N) {
+  if (co < NO) {
 #pragma unroll 4
     for (int it = 0; it < TM / TPI; ++it) {
       const int tok = it * TPI + trow;
@@ -233,7 +264,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
       if (m >= p.M) continue;
       u32x4 v = *(const u32x4*)(lds + tok * EP_PITCH + piece * 16);
       if (p.residual) {
-        const u32x4 rr = *(const u32x4*)((const T*)p.residual + (size_t)m * p.N + co);
+        const u32x4 rr = *(const u32x4*)((const T*)p.residual + (size_t)m * NO + co);
         if constexpr (ES == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
         const long long nn = m / p.rows_per_sample, tok_s = m - nn * p.rows_per_sample;
         *(u32x4*)((T*)p.y + ((((size_t)which * p.B + nn) * p.qkv_heads + (cc >> 3)) * p.rows_per_sample + tok_s) * 8 + (cc & 7)) = v;
       } else {
-        *(u32x4*)((T*)p.y + (size_t)m * p.N + co) = v;
+        *(u32x4*)((T*)p.y + (size_t)m * NO + co) = v;
       }
     }
   }
@@ -425,13 +456,13 @@ static void token_wgrad_plan(long long M, int K, int N, int* n_tiles, int* k_til
   *splits = (*nchunks + *cps - 1) / *cps;
 }
 
-template <typename T, int NC>
+template <typename T, int NC, bool GLU = false>
 static int launch_linear(const LinP& p, hipStream_t st) {
   constexpr int ES = Elem<T>::BYTES;
   constexpr int XT = 128 * (64 * ES + 16), EPI = 128 * (64 * NC * ES + 16);
   constexpr int EPI_ST = EPI + 256 * (2 * 16 / ES) * 4;        // + per-thread statistics partials
   constexpr int LDS = 2 * XT > EPI_ST ? 2 * XT : EPI_ST;
-  auto kern = linear_kernel<T, NC>;
+  auto kern = linear_kernel<T, NC, GLU>;
   if (LDS > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -467,7 +498,10 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK((long long)p.t_tiles * p.c_tiles < (1ll << 30), PD_ERR_SHAPE, "pd_linear: grid too large");
   // 128-channel tiles halve the LDS reads per MFMA; 64-channel tiles when those would leave most of the 256 CUs (x 3
   // resident workgroups) idle
-  const bool narrow = (long long)p.t_tiles * p.c_tiles < 512;
+  const bool glu = a->glu != 0;
+  PD_CHECK(!glu || (a->N % 64 == 0 && a->N_pad == a->N && !a->residual && !a->stats_out && a->qkv_heads == 0), PD_ERR_SHAPE,
+           "pd_linear: glu needs N %% 64 == 0 (value | gate halves of whole 32-channel tiles), dense output, no residual / statistics");
+  const bool narrow = !glu && (long long)p.t_tiles * p.c_tiles < 512;
   if (narrow) p.c_tiles = (a->N_pad + 63) / 64;
   p.xbytes = (unsigned)xbytes;
   p.x = a->x; p.w = a->w_packed; p.bias = a->bias; p.residual = a->residual; p.y = a->y;
@@ -481,6 +515,7 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a->stats_out == nullptr || (a->rows_per_sample > 0 && a->rows_per_sample % 128 == 0 && a->M % a->rows_per_sample == 0 && a->qkv_heads == 0),
            PD_ERR_SHAPE, "pd_linear: stats_out needs rows_per_sample %% 128 == 0 and dense output");
   p.stats = a->stats_out;
+  if (glu) return a->dtype == PD_F32 ? launch_linear<float, 2, true>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2, true>(p, (hipStream_t)stream);
   if (a->dtype == PD_F32) return narrow ? launch_linear<float, 1>(p, (hipStream_t)stream) : launch_linear<float, 2>(p, (hipStream_t)stream);
   return narrow ? launch_linear<bf16_t, 1>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2>(p, (hipStream_t)stream);
 }

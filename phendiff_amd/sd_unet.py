@@ -300,6 +300,10 @@ class _SDPackedWeights:
                 e.wkv2 = pk(lin(torch.cat([a2.to_k.weight, a2.to_v.weight], 0)))
                 e.wo2, e.bo2 = pk(lin(a2.to_out[0].weight)), f32(a2.to_out[0].bias)
                 e.wff1, e.bff1 = pk(lin(blk.ff.net[0].proj.weight)), f32(blk.ff.net[0].proj.bias)
+                # inference copy for the fused GEGLU epilogue of pd_linear: value rows in the even, gate rows in the odd 32-row tiles
+                wf = blk.ff.net[0].proj.weight
+                pv, pg = pk(lin(wf[:4 * ch])), pk(lin(wf[4 * ch:]))
+                e.wff1_glu = torch.stack([pv, pg], 1).reshape(2 * pv.shape[0], *pv.shape[1:]).contiguous()
                 e.wff2, e.bff2 = pk(lin(blk.ff.net[2].weight)), f32(blk.ff.net[2].bias)
                 maxc = max(maxc, 8 * ch)
                 self.transformers[name] = e
@@ -373,10 +377,13 @@ class SDUNetPlan(UNetPlan):
         h2 = lin(a2, e.wo2, e.bo2, ch, residual=h1)
         # GEGLU feed-forward
         y3 = self._layernorm(h2, e.ln3)
-        ff = lin(y3, e.wff1, e.bff1, 8 * ch)
-        gg = self._act(h, w, 4 * ch)
-        ga = L.GegluArgs(dtype=self.code, rows=B * N, inner=4 * ch, x=ff.data_ptr(), y=gg.data_ptr())
-        self.ops.append(_Op(self.lib.pd_geglu, ga, "geglu", 0.0, 3.0 * gg.numel() * esz))
+        if self.train:                   # the backward needs the 8C-wide projection (pd_geglu_bwd)
+            ff = lin(y3, e.wff1, e.bff1, 8 * ch)
+            gg = self._act(h, w, 4 * ch)
+            ga = L.GegluArgs(dtype=self.code, rows=B * N, inner=4 * ch, x=ff.data_ptr(), y=gg.data_ptr())
+            self.ops.append(_Op(self.lib.pd_geglu, ga, "geglu", 0.0, 3.0 * gg.numel() * esz))
+        else:                            # value * gelu(gate) in the GEMM's epilogue: the projection never reaches HBM
+            ff, gg = None, self._linear(y3, e.wff1_glu, e.bff1, 8 * ch, glu=True)
         h3 = lin(gg, e.wff2, e.bff2, ch, residual=h2)
         if self._linear_ok(h3):
             out = self._linear(h3, e.w_out, e.b_out, ch, residual=x, stats=True)                  # statistics for the next GroupNorm

@@ -338,6 +338,10 @@ class _SDRepacker:
                 both(e.wkv2, t.wkv2_d, a2.to_k.weight, 2 * ch, D)
                 both(e.wo2, t.wo2_d, a2.to_out[0].weight, ch, ch)
                 both(e.wff1, t.wff1_d, blk.ff.net[0].proj.weight, 8 * ch, ch)
+                wf = blk.ff.net[0].proj.weight                       # inference copy: value / gate tiles interleaved
+                tile = (ch // 32) * 2 * 512
+                job(e.wff1_glu, wf.data[:4 * ch], 4 * ch, ch, 1, ct_stride=2 * tile)
+                job(e.wff1_glu, wf.data[4 * ch:], 4 * ch, ch, 1, ct_stride=2 * tile, dst_off=tile)
                 both(e.wff2, t.wff2_d, blk.ff.net[2].weight, ch, 4 * ch)
             elif isinstance(mod, _Sampler):
                 ch = mod.conv.weight.shape[0]

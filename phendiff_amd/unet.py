@@ -521,14 +521,14 @@ class UNetPlan:
         self.ops.append(_Op(self.lib.pd_gn_apply, a, "gn_apply", 0.0, 2.0 * y.numel() * (2 if self.code == L.PD_BF16 else 4)))
         return y
 
-    def _linear(self, x, wpk, bias, cout, residual=None, y=None, gn=None, stats=False, what="linear"):
+    def _linear(self, x, wpk, bias, cout, residual=None, y=None, gn=None, stats=False, what="linear", glu=False):
         """nn.Linear over the tokens of an NHWC tensor through the GEMM kernel (``pd_linear``); ``wpk`` is pd_conv's packed 1x1
         layout, so forward and input-gradient weights are shared with the convolution path.  ``gn``: GroupNorm apply fused into
         the staging; ``stats``: emit the output's per-tile GroupNorm statistics.  Both need tokens-per-sample % 128 == 0
-        (:meth:`_linear_ok`)."""
+        (:meth:`_linear_ok`).  ``glu``: fused GEGLU epilogue (``wpk`` with value / gate tiles interleaved) -> ``cout // 2`` channels."""
         B, h, w, K = x.shape
         if y is None:
-            y = self._act(h, w, cout)
+            y = self._act(h, w, cout // 2 if glu else cout)
         M, esz = B * h * w, (2 if self.code == L.PD_BF16 else 4)
         st = None
         if stats:
@@ -538,9 +538,9 @@ class UNetPlan:
         a = L.LinearArgs(dtype=self.code, M=M, K=K, N=cout, N_pad=((cout + 31) // 32) * 32, x=x.data_ptr(), x_stride=K,
                          w_packed=wpk.data_ptr(), bias=bias.data_ptr(), residual=L.ptr(residual), y=y.data_ptr(),
                          scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None, rows_per_sample=h * w, qkv_heads=0,
-                         stats_out=L.ptr(st))
+                         stats_out=L.ptr(st), glu=int(glu))
         self.ops.append(_Op(self.lib.pd_linear, a, what, 2.0 * M * K * cout,
-                            (M * K + M * cout * (2 if residual is not None else 1) + K * cout) * esz))
+                            (M * K + M * (cout // 2 if glu else cout) * (2 if residual is not None else 1) + K * cout) * esz))
         return y
 
     @staticmethod

@@ -199,6 +199,40 @@ def test_linear_gemm(env, mode, cfg):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(1024, 320, 1280), (300, 64, 256), (515, 1280, 5120), (130, 96, 32)])
+def test_linear_gemm_fused_geglu(env, mode, cfg):
+    """pd_linear(glu = 1) = diffusers GEGLU: proj -> chunk(2) -> value * F.gelu(gate), with the value / gate weight rows
+    interleaved per 32-row tile (two pd_pack_weight calls with a two-tile stride, as the re-pack after an optimizer step
+    does) and the bias in module order.  M ragged, inner widths that are / are not multiples of the 64-channel output tile."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    M, K, inner = cfg
+    g = torch.Generator().manual_seed(64)
+    x = bf16_round(torch.randn(M, K, generator=g), mode)
+    w = bf16_round(torch.randn(2 * inner, K, generator=g) / K ** 0.5, mode)
+    bias = torch.randn(2 * inner, generator=g)
+    X, W, Bv = x.to(tdt).to(dev), w.to(dev), bias.to(dev)
+    tile = (K // 32) * 2 * 512
+    wp = torch.full((2 * inner // 32, tile), float("nan"), dtype=tdt, device=dev)
+    for half in (0, 1):
+        src = W[half * inner:(half + 1) * inner].contiguous()
+        a = L.PackWeightArgs(dtype=code, cout=inner, cin=K, cout_pad=inner, cin_pad=K, ksize=1, src_in=K, dgrad=0,
+                             src=src.data_ptr(), dst=wp.data_ptr() + half * tile * wp.element_size(), dst_ct_stride=2 * tile)
+        L.check(lib.pd_pack_weight(C.byref(a), stream()), "pd_pack_weight")
+    y = torch.full((M, inner), float("nan"), dtype=tdt, device=dev)
+    a = L.LinearArgs(dtype=code, M=M, K=K, N=2 * inner, N_pad=2 * inner, x=X.data_ptr(), x_stride=K, w_packed=wp.data_ptr(),
+                     bias=Bv.data_ptr(), residual=None, y=y.data_ptr(), glu=1)
+    L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+    torch.cuda.synchronize()
+    assert not torch.isnan(wp.float()).any()
+    proj = F.linear(x.double(), w.double(), bias.double())
+    ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+    assert rel(y.float(), ref) < (2e-6 if mode == "f32" else 4e-3)
+    a.N = a.N_pad = 2 * inner + 32                                             # halves that are not whole tiles: refused
+    assert lib.pd_linear(C.byref(a), stream()) == -2
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("cfg", [(4096, 320, 960, 0), (300, 64, 64, 0), (2048, 1280, 2560, 0), (77 * 3, 96, 256, 0), (8200, 640, 200, 24), (64, 8, 8, 0)])
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_token_wgrad(env, mode, cfg, accumulate):
