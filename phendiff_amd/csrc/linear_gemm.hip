@@ -42,7 +42,7 @@ template <int ES> __device__ __forceinline__ float gelu_f(float g) {
 // tiles are a value / gate pair and the epilogue stores value * gelu(gate): N/2 output channels, the 2N-wide projection
 // never reaches HBM.
 template <typename T, int NC, bool GLU = false>
-__global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void linear_kernel(const LinP p) {   // bf16 wide tiles: 3 workgroups per CU (<= 168 registers)
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using SR = typename Stage<T>::R;
@@ -137,12 +137,20 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
   const int b_lane = (wp * 64 + r) * PITCH + 8 * h * ES;
 
   if constexpr (NC == 2) {
-    // wide tiles (big grids): weight fragments one k-step ahead in registers, activation fragments read at the top of the
-    // k-step; deeper rings / unrolled k-steps cost a wave of occupancy, which pays more here (measured) -- the other
-    // resident waves cover both latencies
-    Frag a[NC];
+    // wide tiles (big grids): weight fragments two k-steps ahead in registers, activation fragments read at the top of the
+    // k-step; the kernel is held at 3 workgroups per CU (__launch_bounds__: 164-166 registers, accumulators in VGPRs) --
+    // prefetching the activation fragments as well spills there (measured), the other resident waves cover that latency
+#ifdef PD_LIN_AD                                       // diagnostic builds: same-box A/B of the prefetch depth
+    constexpr int AD = PD_LIN_AD, AR = 4;
+#else
+    constexpr int AD = 2, AR = 4;                      // weight fragments 2 k-steps ahead in a ring of 4 (static indices: 4 k-steps / chunk)
+#endif
+    Frag aring[AR][NC];
+    const int last_kstep = ksteps - 1;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) a[c] = E::load(wb[c]);
+    for (int i = 0; i < AD; ++i)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) aring[i][c] = E::load(wb[c] + (size_t)min(i, last_kstep) * 512);
     issue(0);
     commit(lds);
     if (total_chunks > 1) issue(1);
@@ -151,21 +159,21 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinP p) {
       const unsigned char* buf = lds + (chunk & 1) * XTILE;
       const int nks = (chunk < nchunks) ? CK / 16 : tail_ksteps;
       const int g0 = chunk * (CK / 16);
-      for (int ks = 0; ks < nks; ++ks) {
-        const int gn = min(g0 + ks + 1, ksteps - 1);   // next k-step's weight fragments (clamped at the end)
-        Frag an[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) an[c] = E::load(wb[c] + (size_t)gn * 512);
-        const Frag b0 = E::load(buf + b_lane + ks * 16 * ES), b1 = E::load(buf + b_lane + 32 * PITCH + ks * 16 * ES);
-        __builtin_amdgcn_s_setprio(1);
+      for (int ks = 0; ks < CK / 16; ++ks) {
+        if (ks < nks) {
+          const int gn = min(g0 + ks + AD, last_kstep);   // clamped at the end
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          acc[c][0] = E::mma(a[c], b0, acc[c][0]);
-          acc[c][1] = E::mma(a[c], b1, acc[c][1]);
+          for (int c = 0; c < NC; ++c) aring[(ks + AD) % AR][c] = E::load(wb[c] + (size_t)gn * 512);
+          const Frag b0 = E::load(buf + b_lane + ks * 16 * ES), b1 = E::load(buf + b_lane + 32 * PITCH + ks * 16 * ES);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            acc[c][0] = E::mma(aring[ks % AR][c], b0, acc[c][0]);
+            acc[c][1] = E::mma(aring[ks % AR][c], b1, acc[c][1]);
+          }
+          __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) a[c] = an[c];
       }
       if (chunk + 1 < total_chunks) {
         commit(lds + ((chunk + 1) & 1) * XTILE);

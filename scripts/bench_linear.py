@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from phendiff_amd import _lib as L
 from phendiff_amd.packing import pack_conv_weight
+if os.environ.get("PD_LIB"): L.LIB_PATH = os.environ["PD_LIB"]      # same-box A/B of two builds
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev, lib = "cuda:0", L.lib()
 st = torch.cuda.current_stream().cuda_stream
@@ -26,5 +27,11 @@ for hw, ch in ((64, 320), (32, 640), (16, 1280)):
                         out_mode=0, heads=0, x0=x.data_ptr(), x1=None, scale=None, shift=None, w_packed=w.data_ptr(), bias=bias.data_ptr(), temb=None,
                         temb_stride=0, residual=None, y=y.data_ptr())
         fl = 2.0 * M * K * N
-        tl, tc = run(lib.pd_linear, la), run(lib.pd_conv, ca)
-        print(f"{hw}x{hw} C={ch} {name:4s} M={M} K={K} N={N}: pd_linear {tl*1e3:.3f} ms {fl/tl/1e12:6.0f} TF/s | pd_conv 1x1 {tc*1e3:.3f} ms {fl/tc/1e12:6.0f} TF/s")
+        tl = run(lib.pd_linear, la)
+        tc = run(lib.pd_conv, ca) if os.environ.get("PD_BENCH_CONV1X1") else float("nan")
+        extra = ""
+        if name == "ff1":          # fused GEGLU epilogue (weights are random: the tile interleave does not matter for timing)
+            la.glu = 1
+            tg = run(lib.pd_linear, la)
+            extra = f" | glu {tg*1e3:.3f} ms {fl/tg/1e12:6.0f} TF/s"
+        print(f"{hw}x{hw} C={ch} {name:4s} M={M} K={K} N={N}: pd_linear {tl*1e3:.3f} ms {fl/tl/1e12:6.0f} TF/s | pd_conv 1x1 {tc*1e3:.3f} ms {fl/tc/1e12:6.0f} TF/s{extra}", flush=True)
