@@ -21,7 +21,7 @@ namespace pd {
 //                                                      [key][d] in LDS; the A operand V^T is a TRANSPOSED read
 //                                                      (ds_read_b64_tr_b16, rows chosen per lane to match P's key order).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_d64_kernel(const pd_attn_d64_args a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_d64_kernel(const pd_attn_d64_args a) {
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using X = D64<T>;
@@ -54,7 +54,16 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const pd_attn_d64_args a)
     qf[ks] = E::pack(v);
   }
   f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);      // O^T row tiles d 0..31, 32..63
-  float m = -INFINITY, l = 0.f;                      // l: this lane half's share of the row sum
+  // Deferred-rescale online softmax (as pd_attn_d8): `m` is a REFERENCE maximum (log2 domain) shared by both lane halves of a
+  // query, p = exp2(s - m).  It is only raised when some score of the sub-tile exceeds m + RESCALE_THR (p <= 2^THR
+  // otherwise: harmless in fp32 / bf16), so the accumulator rescale (32 multiplies), the cross-half exchange and the second
+  // exp2 leave the common path; the first sub-tile always takes the exact maximum.  The decision is wave-uniform.
+  constexpr float RESCALE_THR = 16.0f;
+  // -m rides in the C operand of the first QK^T MFMA (a register tile that only changes on a rescale), so the scores leave
+  // the matrix pipe ready for exp2.
+  float m = 0.f, l = 0.f;                            // l: this lane half's share of the row sum
+  f32x16 negm = (f32x16)(0.f);
+  bool first = true;
 
   Frag stk[PIECES], stv[PIECES];
   auto issue = [&](int k0) {
@@ -89,28 +98,41 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const pd_attn_d64_args a)
 #pragma unroll
     for (int sub = 0; sub < KT / 32; ++sub) {
       if (k0 + sub * 32 < a.Nkv) {                    // workgroup-uniform
-        f32x16 s = (f32x16)(0.f);
+        f32x16 s = E::mma(E::load(kb + k_lane + sub * 32 * KP), qf[0], negm);     // s = S - m
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 1; ks < 4; ++ks)
           s = E::mma(E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES), qf[ks], s);
         if (k0 + sub * 32 + 32 > a.Nkv) {              // keys beyond the context length
 #pragma unroll
           for (int i = 0; i < 16; ++i)
             if (k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Nkv) s[i] = -INFINITY;
         }
-        float tmax = s[0];
+        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);   // v_max3_f32 chain
 #pragma unroll
-        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every sub-tile visited holds at least one real key
-        const float mn = fmaxf(m, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        m = mn;
-        float ps = 0.f;
+        for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s[i]), s[i + 1]);
+        tmax = fmaxf(tmax, s[15]);
+        if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR) != 0) {
+          const float tq = fmaxf(tmax, __shfl_xor(tmax, 32));   // finite: every sub-tile visited holds at least one real key
+          const float delta = first ? tq : fmaxf(0.f, tq);      // how far the reference moves up (first: to the exact maximum)
+          const float alpha = __builtin_amdgcn_exp2f(-delta);   // first: l = o = 0, any finite factor will do
+          m += delta;
+          first = false;
+          l *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i] - mn); ps += s[i]; }
-        l = l * alpha + ps;
+          for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; s[i] -= delta; }
+          negm = (f32x16)(-m);
+        }
+        {
+          f32x2 acc2 = (f32x2)(0.f);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+          for (int i = 0; i < 16; i += 2) {              // packed fp32 add: one VALU slot per score pair
+            f32x2 d;
+            d.x = __builtin_amdgcn_exp2f(s[i]); d.y = __builtin_amdgcn_exp2f(s[i + 1]);
+            s[i] = d.x; s[i + 1] = d.y;
+            acc2 += d;
+          }
+          l += acc2.x + acc2.y;
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           const Frag pf = X::pack_p(s, st);

@@ -74,6 +74,39 @@ def test_geglu(env, mode):
 
 # ---- backward kernels of the Transformer2D blocks: against autograd over plain PyTorch fp32 ---------------------------------
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_attention_d64_deferred_rescale(env, mode):
+    """Scores that jump far above the running reference maximum late in the key sequence (and a first tile far BELOW the
+    rest) force the rescale branch of the deferred-rescale online softmax; checked against fp64 softmax, lse included."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, N = 2, 3, 320
+    Cc = heads * 64
+    g = torch.Generator().manual_seed(43)
+    q = torch.randn(B, N, Cc, generator=g)
+    k = torch.randn(B, N, Cc, generator=g)
+    v = torch.randn(B, N, Cc, generator=g)
+    sp = lambda t: t.reshape(B, N, heads, 64).transpose(1, 2)
+    qh, kh = sp(q), sp(k)                                   # views: writes land in q / k
+    kh[:, :, 200] = qh[:, :, 5] * 3.0                       # query 5: score ~ 3 |q|^2 / 8 ~ 24 (x log2 e = 35) at key 200
+    kh[:, :, 290] = qh[:, :, 170] * 6.0
+    kh[:, :, 100] = qh[:, :, 319] * 2.5
+    kh[:, :, :32] -= 4.0 * qh[:, :, 40:41] / qh[:, :, 40:41].norm(dim=-1, keepdim=True)   # query 40: first sub-tile ~ -32 below the rest
+    q, k, v = (bf16_round(t, mode) for t in (q, k, v))
+    Q, K, V = (t.to(tdt).to(dev).contiguous() for t in (q, k, v))
+    out = torch.full((B, N, Cc), float("nan"), dtype=tdt, device=dev)
+    lse = torch.full((B, heads, N), float("nan"), dtype=torch.float32, device=dev)
+    a = L.AttnD64Args(dtype=code, B=B, heads=heads, Nq=N, Nkv=N, q=Q.data_ptr(), q_stride=Cc, k=K.data_ptr(), v=V.data_ptr(),
+                      kv_stride=Cc, out=out.data_ptr(), out_stride=Cc, lse=lse.data_ptr())
+    L.check(lib.pd_attn_d64(C.byref(a), stream()), "pd_attn_d64")
+    torch.cuda.synchronize()
+    s = torch.einsum("bhid,bhjd->bhij", sp(q).double(), sp(k).double()) / 8
+    assert float((s.max(-1).values - s[..., :32].max(-1).values).max()) > 20         # the spikes are real
+    ref = (torch.softmax(s, -1) @ sp(v).double()).transpose(1, 2).reshape(B, N, Cc)
+    assert rel(out.float(), ref) < (1e-5 if mode == "f32" else 1.5e-2)
+    assert rel(lse.cpu(), torch.logsumexp(s, -1) * 1.4426950408889634) < (1e-5 if mode == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("cfg", [(2, 2, 256, 256), (1, 5, 1024, 1024), (2, 3, 200, 77), (1, 1, 16, 16), (2, 2, 130, 4), (1, 2, 70, 200)])
 def test_attention_d64_backward(env, mode, cfg):
     L, lib, _, dev = env
