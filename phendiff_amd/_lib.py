@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphendiff_hip.so")
+# PD_LIB: diagnostic override (same-box A/B of two builds of the library); the default is the in-tree build
+LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "libphendiff_hip.so")
 
 PD_F32, PD_BF16 = 0, 1
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}

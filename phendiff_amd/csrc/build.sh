@@ -12,8 +12,9 @@ for f in $SRCS; do
   if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_stage.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_d64.h" -nt "$HERE/build/$f.o" ] \
      || [ "$HERE/../../include/phendiff_hip.h" -nt "$HERE/build/$f.o" ]; then
     X=""
-    # attention: keep MFMA accumulators in VGPRs (the softmax works on them; AGPR form costs a copy per register)
-    if [ "$f" = "attn_d8" ]; then X="-mllvm -amdgpu-mfma-vgpr-form"; fi
+    # attention (forward d = 8, backward d = 64): keep MFMA accumulators in VGPRs (the softmax / its derivative work on them;
+    # AGPR form costs a copy per register -- d64 backward: 20.3 -> 17.8 ms per SD training step, dq kernel 2 -> 3 waves/SIMD)
+    if [ "$f" = "attn_d8" ] || [ "$f" = "sd_bwd_kernels" ]; then X="-mllvm -amdgpu-mfma-vgpr-form"; fi
     $HIPCC $FLAGS $X $EXTRA_HIPCC_FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
     pids+=($!)
   fi

@@ -116,11 +116,20 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
           s = E::mma(E::load(kb + row_lane + sub * 32 * VP + ks * 16 * ES), qf[ks], s);
           dp = E::mma(E::load(vb + row_lane + sub * 32 * VP + ks * 16 * ES), dof[ks], dp);
         }
+        if (k0 + sub * 32 + 32 > a.Nkv) {               // keys beyond the context length (workgroup-uniform): P = 0
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const bool valid = k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < a.Nkv;
-          const float p = valid ? __builtin_amdgcn_exp2f(s[i] - lse) : 0.f;
-          s[i] = p * (dp[i] - delta);                  // dS^T
+          for (int i = 0; i < 16; ++i)
+            if (k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Nkv) s[i] = -INFINITY;
+        }
+        {
+          const f32x2 lse2 = (f32x2)(lse), delta2 = (f32x2)(delta);
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {             // packed fp32 math: one VALU slot per score pair
+            const f32x2 e = (f32x2){s[i], s[i + 1]} - lse2;
+            f32x2 p; p.x = __builtin_amdgcn_exp2f(e.x); p.y = __builtin_amdgcn_exp2f(e.y);
+            const f32x2 ds = p * ((f32x2){dp[i], dp[i + 1]} - delta2);   // dS^T
+            s[i] = ds.x; s[i + 1] = ds.y;
+          }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -235,11 +244,17 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
           dp = E::mma(E::load(db + row_lane + sub * 32 * VP + ks * 16 * ES), vf[ks], dp);    // dP[query][key]
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {                  // register i <-> query sub*32 + 8(i>>2) + 4h + (i&3)
-          const int qi = sub * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-          const float p = __builtin_amdgcn_exp2f(s[i] - lse_t[qi]);
-          s[i] = p;
-          dp[i] = p * (dp[i] - del_t[qi]);              // dS
+        for (int g = 0; g < 4; ++g) {                   // registers 4g..4g+3 <-> queries sub*32 + 8g + 4h + (0..3)
+          const f32x4 l4 = *(const f32x4*)(lse_t + sub * 32 + 8 * g + 4 * h), d4 = *(const f32x4*)(del_t + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {              // packed fp32 math: one VALU slot per score pair
+            const int i = 4 * g + j;
+            const f32x2 e = (f32x2){s[i], s[i + 1]} - (f32x2){l4[j], l4[j + 1]};
+            f32x2 p; p.x = __builtin_amdgcn_exp2f(e.x); p.y = __builtin_amdgcn_exp2f(e.y);
+            const f32x2 ds = p * ((f32x2){dp[i], dp[i + 1]} - (f32x2){d4[j], d4[j + 1]});   // dS
+            s[i] = p.x; s[i + 1] = p.y;
+            dp[i] = ds.x; dp[i + 1] = ds.y;
+          }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
