@@ -143,13 +143,7 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         self._dehs = [torch.empty_like(self.ehs), False]
         self.bufs.append(self._dehs[0])
         self._token_grad_args = None
-        self._twgrad_args = []
         super()._build_backward()
-        if self._twgrad_args:       # one slab serves every token-reduction weight gradient (they run back to back on one stream)
-            need = max(self.lib.pd_token_wgrad_workspace(C.byref(a)) for a in self._twgrad_args)
-            self.slab_tokens = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
-            for a in self._twgrad_args:
-                a.slab, a.slab_bytes = self.slab_tokens.data_ptr(), need
         if self.param_grads and EMB_NAME in self.grads:
             dehs, dt = self._dehs[0], self.grads[EMB_NAME]
             a = L.TokenEmbeddingGradArgs(dtype=self.code, rows=self.B, dim=dt.shape[1], num_classes=dt.shape[0],
@@ -169,38 +163,6 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
             self._wgrad(rec.x, None, None, 0, dout, self._G("conv_in.weight"), cin_valid=self.m.config.in_channels)
         else:
             super()._bwd_record(rec)
-
-    def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0):
-        """Weight gradients of the plain Linear layers go through the token-reduction GEMM (``pd_token_wgrad``)."""
-        if not self.param_grads:
-            return
-        if ksize != 1 or gn is not None or x1 is not None or cout_valid or cin_valid:
-            return super()._wgrad(x0, x1, gn, silu, dy, dw, ksize=ksize, stride=stride, pad=pad, upsample=upsample,
-                                  cout_valid=cout_valid, cin_valid=cin_valid)
-        B, h, w, K = x0.shape
-        N, M = dy.shape[3], B * h * w
-        a = L.TokenWgradArgs(dtype=self.code, M=M, K=K, N=N, x=x0.data_ptr(), x_stride=K, dy=dy.data_ptr(), dy_stride=N,
-                             dw=dw.data_ptr(), accumulate=1)
-        self._twgrad_args.append(a)
-        self._b(self.lib.pd_token_wgrad, a, "wgrad_linear", 2.0 * M * K * N, (M * (K + N)) * self._esz() + K * N * 4.0)
-
-    def _dgrad(self, dy, wpk, cout, *, ksize=3, zero_stuff=False, into=None, tag="dz"):
-        """Input gradients of the Linear layers go through ``pd_linear`` (same packed transposed weights as ``pd_conv``)."""
-        if ksize != 1 or zero_stuff:
-            return super()._dgrad(dy, wpk, cout, ksize=ksize, zero_stuff=zero_stuff, into=into, tag=tag)
-        B, h, w, _ = dy.shape
-        if into is not None:
-            y, res = into[0], (into[0] if into[1] else None)
-            into[1] = True
-            self._drop_fused_sums(into[0])
-        else:
-            y, res = self._tmp((B, h, w, cout), tag), None
-        ops, self.ops = self.ops, self.bwd_ops
-        try:
-            self._linear(dy, wpk, self._zero_bias, cout, residual=res, y=y, what="dgrad_linear")
-        finally:
-            self.ops = ops
-        return y
 
     def _ln_bwd(self, x, ln, pname, dy, res, tag):
         gamma, _, eps = ln

@@ -19,6 +19,7 @@ gradients contiguous), which is what :class:`phendiff_amd.training.FlatAdamWEMA`
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
@@ -28,6 +29,9 @@ from . import _lib as L
 from .packing import dgrad_weight, pack_conv_weight
 from .unet import CustomCondUNet2DModel, UNetPlan, _Attention, _Op, _PackedWeights, _Resnet, _Sampler, _copy_into
 
+
+# diagnostic (same-box A/B): route the 1x1 gradients through pd_conv / pd_conv_wgrad as the 3x3 ones
+_NO_LINEAR_GRADS = bool(os.environ.get("PD_NO_LINEAR_GRADS"))
 
 def training_param_order(m: CustomCondUNet2DModel) -> List[Tuple[str, torch.nn.Parameter]]:
     """(name, parameter) pairs in the order the flat training buffers use: all ``time_emb_proj`` weights (then biases)
@@ -229,7 +233,18 @@ class UNetTrainPlan(UNetPlan):
         self._b(self.lib.pd_channel_sum, a, "channel_sum", 0.0, dy.numel() * self._esz())
 
     def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0):
+        """Weight gradient of a convolution (``pd_conv_wgrad``); plain Linear layers (1x1, one dense source, no fused GroupNorm)
+        go through the token-reduction GEMM ``pd_token_wgrad``."""
         if not self.param_grads:
+            return
+        if (ksize == 1 and gn is None and x1 is None and not cout_valid and not cin_valid and x0.shape[3] % 8 == 0 and dy.shape[3] % 8 == 0
+                and not _NO_LINEAR_GRADS):
+            B, h, w, K = x0.shape
+            N, M = dy.shape[3], B * h * w
+            a = L.TokenWgradArgs(dtype=self.code, M=M, K=K, N=N, x=x0.data_ptr(), x_stride=K, dy=dy.data_ptr(), dy_stride=N,
+                                 dw=dw.data_ptr(), accumulate=1)
+            self._twgrad_args.append(a)
+            self._b(self.lib.pd_token_wgrad, a, "wgrad_linear", 2.0 * M * K * N, (M * (K + N)) * self._esz() + K * N * 4.0)
             return
         B, hin, win, c0 = x0.shape
         c1 = x1.shape[3] if x1 is not None else 0
@@ -244,8 +259,9 @@ class UNetTrainPlan(UNetPlan):
         self._b(self.lib.pd_conv_wgrad, a, f"wgrad{ksize}x{ksize}", flops, nbytes)
 
     def _dgrad(self, dy, wpk, cout, *, ksize=3, zero_stuff=False, into=None, tag="dz"):
-        """Input gradient of a convolution: ``pd_conv`` over dy with the transposed/flipped weights.  ``into`` = [buffer,
-        initialised]: write (or accumulate, through ``residual``) straight into a gradient buffer."""
+        """Input gradient of a convolution: ``pd_conv`` over dy with the transposed/flipped weights (1x1: the GEMM kernel
+        ``pd_linear`` on the same packed weights).  ``into`` = [buffer, initialised]: write (or accumulate, through ``residual``)
+        straight into a gradient buffer."""
         B, h, w, cin = dy.shape
         ho, wo = (2 * h, 2 * w) if zero_stuff else (h, w)
         if into is not None:
@@ -256,11 +272,14 @@ class UNetTrainPlan(UNetPlan):
             y, res = self._tmp((B, ho, wo, cout), tag), None
         ops, self.ops = self.ops, self.bwd_ops
         try:
-            self._conv(dy, None, wpk, self._zero_bias, cout, ksize=ksize, pad=ksize // 2, upsample=2 if zero_stuff else 0,
-                       residual=res, y=y, stats=False)
+            if ksize == 1 and not zero_stuff and cin % 32 == 0 and cout % 8 == 0 and not _NO_LINEAR_GRADS:
+                self._linear(dy, wpk, self._zero_bias, cout, residual=res, y=y, what="dgrad_linear")
+            else:
+                self._conv(dy, None, wpk, self._zero_bias, cout, ksize=ksize, pad=ksize // 2, upsample=2 if zero_stuff else 0,
+                           residual=res, y=y, stats=False)
+                self.bwd_ops[-1].what = f"dgrad{ksize}x{ksize}"
         finally:
             self.ops = ops
-        self.bwd_ops[-1].what = f"dgrad{ksize}x{ksize}"
         return y
 
     def _gn_bwd(self, gn, dz, silu, *, combined=False, res=None, wname=None):
@@ -308,6 +327,7 @@ class UNetTrainPlan(UNetPlan):
         w = self.w
         self._zero_bias = torch.zeros(self._zero_bias_len(), dtype=torch.float32, device=self.device)
         self.dproj = self._f32(self.B, w.proj_dim)
+        self._twgrad_args = []
         for rec in reversed(self.tape):
             self._bwd_record(rec)
         if not self.param_grads:
@@ -318,6 +338,11 @@ class UNetTrainPlan(UNetPlan):
         self.slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
         for a in self._wgrad_args:
             a.slab, a.slab_bytes = self.slab.data_ptr(), need
+        if self._twgrad_args:       # likewise for the token-reduction weight gradients of the Linear layers
+            need = max(self.lib.pd_token_wgrad_workspace(C.byref(a)) for a in self._twgrad_args)
+            self.slab_tokens = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
+            for a in self._twgrad_args:
+                a.slab, a.slab_bytes = self.slab_tokens.data_ptr(), need
 
     def _bwd_record(self, rec):
         """Emit the backward launches of one forward tape record."""
