@@ -294,15 +294,17 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
 // dbeta = sum dy in registers; per-workgroup partials go to a workspace and are summed in a fixed order by a second kernel.
 constexpr int LN_MAXP = 4;                             // C <= 64 lanes * 8 * 4 = 2048
 
-template <typename T>
+// NP = 8-element pieces per lane (C <= 512 * NP): narrow rows keep few registers, so more waves hide the three dependent
+// reductions per token
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_bwd_args a) {
   using E = Elem<T>;
-  __shared__ float red[3][2][LN_MAXP][8][64];          // waves 1..3: [dgamma | dbeta] shares
+  __shared__ float red[3][2][NP][8][64];          // waves 1..3: [dgamma | dbeta] shares
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pieces = a.C / 8;
-  float gam[LN_MAXP][8], dg[LN_MAXP][8], db[LN_MAXP][8];
+  float gam[NP][8], dg[NP][8], db[NP][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXP; ++i) {
+  for (int i = 0; i < NP; ++i) {
     const int pc = lane + 64 * i;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gam[i][j] = pc < pieces ? a.gamma[pc * 8 + j] : 0.f; dg[i][j] = 0.f; db[i][j] = 0.f; }
@@ -311,10 +313,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
   for (long long row = (long long)blockIdx.x * 4 + wave; row < a.rows; row += (long long)gridDim.x * 4) {
     const T* x = (const T*)a.x + row * a.C;
     const T* dy = (const T*)a.dy + row * a.C;
-    float v[LN_MAXP][8], g[LN_MAXP][8];
+    float v[NP][8], g[NP][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXP; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int pc = lane + 64 * i;
       if (pc < pieces) {
         E::unpack(E::load(x + pc * 8), v[i]);
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
     const float mean = s * invC;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXP; ++i)
+    for (int i = 0; i < NP; ++i)
       if (lane + 64 * i < pieces) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
     const float rstd = 1.0f / sqrtf(q * invC + a.eps);
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXP; ++i)
+    for (int i = 0; i < NP; ++i)
       if (lane + 64 * i < pieces) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
     T* dx = (T*)a.dx + row * a.C;
     const T* res = a.res ? (const T*)a.res + row * a.C : nullptr;
 #pragma unroll
-    for (int i = 0; i < LN_MAXP; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int pc = lane + 64 * i;
       if (pc < pieces) {
         float o[8], rv[8];
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
   if (!a.partial) return;
   if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXP; ++i)
+    for (int i = 0; i < NP; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) { red[wave - 1][0][i][j][lane] = dg[i][j]; red[wave - 1][1][i][j][lane] = db[i][j]; }
   }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
   if (wave == 0) {
     float* pg = a.partial + (size_t)blockIdx.x * 2 * a.C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXP; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int pc = lane + 64 * i;
       if (pc < pieces) {
 #pragma unroll
@@ -496,7 +498,7 @@ extern "C" int pd_attn_d64_bwd(const pd_attn_d64_bwd_args* a, void* stream) {
 
 extern "C" int pd_layernorm_bwd_blocks(long long rows) {
   const long long nb = (rows + 3) / 4;
-  return (int)(nb < 1024 ? nb : 1024);
+  return (int)(nb < 2048 ? nb : 2048);
 }
 
 extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
@@ -506,9 +508,15 @@ extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
            "pd_layernorm_bwd: dgamma, dbeta and partial go together");
   const int grid = pd_layernorm_bwd_blocks(a->rows);
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == PD_F32) hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
-  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, *a);
-  else { set_error("pd_layernorm_bwd: bad dtype"); return PD_ERR_ARG; }
+  const int np = (a->C / 8 + 63) / 64;
+  if (a->dtype != PD_F32 && a->dtype != PD_BF16) { set_error("pd_layernorm_bwd: bad dtype"); return PD_ERR_ARG; }
+#define PD_LN_BWD(NP_)                                                                                             \
+  do {                                                                                                             \
+    if (a->dtype == PD_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, NP_>), dim3(grid), dim3(256), 0, st, *a); \
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NP_>), dim3(grid), dim3(256), 0, st, *a);                  \
+  } while (0)
+  if (np == 1) PD_LN_BWD(1); else if (np == 2) PD_LN_BWD(2); else if (np == 3) PD_LN_BWD(3); else PD_LN_BWD(4);
+#undef PD_LN_BWD
   PD_LAUNCH_CHECK();
   if (a->partial) {
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * a->C + 15) / 16), dim3(256), 0, st, (const float*)a->partial, grid, a->C,
