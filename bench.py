@@ -516,6 +516,17 @@ def main():
                     traffic, traffic_src = round(v["hbm_bytes_per_launch"]), "profiles/r1_hbm_traffic.json"
         except (OSError, ValueError, KeyError):
             pass
+        # matrix / vector pipe occupancy of the same kernel from the committed PMC pass (profiles/r1_mfma_busy.json:
+        # SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE with rocprofv3's MfmaUtil / VALUBusy formulas)
+        pipes = {}
+        try:
+            bj = json.load(open(os.path.join(ROOT, "profiles", "r1_mfma_busy.json")))
+            for name, v in bj["kernels"].items():
+                if key and key in name and B == 32 and args.dtype == "bf16" and size == 256:
+                    pipes = {"mfma_util_percent": v["MfmaUtil_percent"], "valu_busy_percent": v["VALUBusy_percent"],
+                             "pipes_source": "profiles/r1_mfma_busy.json"}
+        except (OSError, ValueError, KeyError):
+            pass
         extra = {}
         if kind == "attn_d8":
             # the d=8 attention is bound by the VALU/transcendental issue pipe, not by MFMA or HBM: report
@@ -524,7 +535,7 @@ def main():
             extra = {"issue_bound": {"what": "v_exp_f32 issue (64 lanes / 8 cycles / SIMD, 1024 SIMDs, 2.4 GHz)",
                                      "achieved_Texp_per_s": round(nexp / (d["ms"] * 1e-3) / 1e12, 2), "peak_Texp_per_s": 19.66,
                                      "frac": round(nexp / (d["ms"] * 1e-3) / 19.66e12, 4)}}
-        res["roofline"] = {**extra, "kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+        res["roofline"] = {**extra, **pipes, "kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
                            "launches_per_forward": round(d["launches"]), "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),

@@ -23,6 +23,9 @@ head)
   done
   python3 scripts/collect_traffic.py r1 "$(ls /tmp/pmc_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls /tmp/pmc_WRITE_SIZE/*/*_counter_collection.csv | head -1)" > $OUT/traffic.txt
   cp profiles/r1_hbm_traffic.json $OUT/
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_busy -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline > /dev/null 2>$OUT/pmc_busy.err
+  python3 scripts/collect_mfma_busy.py r1 "$(ls /tmp/pmc_busy/*/*_counter_collection.csv | head -1)" > $OUT/mfma_busy.txt
+  cp profiles/r1_mfma_busy.json $OUT/
   python3 bench.py --model small_denoiser_config --batch 16 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/r1_bench_small_denoiser_b16.json 2>/dev/null
   ;;
 train)
