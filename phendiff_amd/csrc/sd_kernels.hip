@@ -5,6 +5,7 @@
 //   pd_geglu     : GEGLU gate  h * gelu(g)  of FeedForward (exact erf form, F.gelu default)
 // Everything else of the SD UNet (ResnetBlock2D, GroupNorm, every Linear as a 1x1 conv on NHWC tokens, down/up-sampling)
 // reuses pd_conv / pd_gn_finalize / pd_temb.
+#include <stdlib.h>
 #include "pd_common.h"
 #include "pd_stage.h"
 #include "pd_d64.h"
@@ -20,19 +21,23 @@ namespace pd {
 //   O^T[d][query]  += V^T[64 x 32 keys] . P^T          ... as the B operand: 2 row tiles x 2 k-steps.  V sits row-major
 //                                                      [key][d] in LDS; the A operand V^T is a TRANSPOSED read
 //                                                      (ds_read_b64_tr_b16, rows chosen per lane to match P's key order).
-template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_d64_kernel(const pd_attn_d64_args a) {
+// QB = 32-query fragments per wave (workgroup = 4 waves = 128 QB queries).  QB = 2: every K and V^T fragment read from LDS
+// feeds two MFMAs, halving the LDS traffic per MFMA (with one fragment the LDS pipe -- 12 KB-equivalents per 8 MFMAs, the
+// transposed reads at half rate -- is busier than the matrix pipe); costs a workgroup of occupancy (2 per CU).
+template <typename T, int QB>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn_d64_kernel(const pd_attn_d64_args a) {
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using X = D64<T>;
   constexpr int KT = 64, KP = X::KP, VP = X::VP, ES = E::BYTES;
   constexpr int KBYTES = KT * KP, VBYTES = KT * VP;
   constexpr int PIECES = KT * 64 / 8 / 256;            // 8-element pieces per thread per tensor (2)
+  constexpr int QPW = 32 * QB, QPB = 4 * QPW;          // queries per wave / workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][K tile | V tile]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int nqb = (a.Nq + 127) / 128;
+  const int nqb = (a.Nq + QPB - 1) / QPB;
   const int total = nqb * a.heads * a.B;
   int item = blockIdx.x;
   if ((total & 7) == 0) item = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);     // query blocks of one head share an XCD / L2
@@ -42,27 +47,33 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_d64_kernel(c
   const T* vp = (const T*)a.v + (size_t)b * a.Nkv * a.kv_stride + head * 64;
 
   // Q^T fragments (B operand): lane (query, h), k-step ks: d = 16 ks + 8 h + j, pre-scaled
-  const int query = qb * 128 + wave * 32 + r, qc = min(query, a.Nq - 1);
   const float qscale = 0.125f * 1.4426950408889634f;
-  Frag qf[4];
+  int query[QB];
+  Frag qf[QB][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    float v[8];
-    E::unpack(E::load(qp + (size_t)qc * a.q_stride + 16 * ks + 8 * h), v);
+  for (int j = 0; j < QB; ++j) {
+    query[j] = qb * QPB + wave * QPW + j * 32 + r;
+    const int qc = min(query[j], a.Nq - 1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= qscale;
-    qf[ks] = E::pack(v);
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+      E::unpack(E::load(qp + (size_t)qc * a.q_stride + 16 * ks + 8 * h), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= qscale;
+      qf[j][ks] = E::pack(v);
+    }
   }
-  f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);      // O^T row tiles d 0..31, 32..63
   // Deferred-rescale online softmax (as pd_attn_d8): `m` is a REFERENCE maximum (log2 domain) shared by both lane halves of a
   // query, p = exp2(s - m).  It is only raised when some score of the sub-tile exceeds m + RESCALE_THR (p <= 2^THR
   // otherwise: harmless in fp32 / bf16), so the accumulator rescale (32 multiplies), the cross-half exchange and the second
   // exp2 leave the common path; the first sub-tile always takes the exact maximum.  The decision is wave-uniform.
-  constexpr float RESCALE_THR = 16.0f;
   // -m rides in the C operand of the first QK^T MFMA (a register tile that only changes on a rescale), so the scores leave
   // the matrix pipe ready for exp2.
-  float m = 0.f, l = 0.f;                            // l: this lane half's share of the row sum
-  f32x16 negm = (f32x16)(0.f);
+  constexpr float RESCALE_THR = 16.0f;
+  f32x16 o0[QB], o1[QB], negm[QB];                   // O^T row tiles d 0..31, 32..63
+  float m[QB], l[QB];                                // l: this lane half's share of the row sum
+#pragma unroll
+  for (int j = 0; j < QB; ++j) { o0[j] = (f32x16)(0.f); o1[j] = (f32x16)(0.f); negm[j] = (f32x16)(0.f); m[j] = 0.f; l[j] = 0.f; }
   bool first = true;
 
   Frag stk[PIECES], stv[PIECES];
@@ -98,47 +109,66 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_d64_kernel(c
 #pragma unroll
     for (int sub = 0; sub < KT / 32; ++sub) {
       if (k0 + sub * 32 < a.Nkv) {                    // workgroup-uniform
-        f32x16 s = E::mma(E::load(kb + k_lane + sub * 32 * KP), qf[0], negm);     // s = S - m
+        f32x16 s[QB];
 #pragma unroll
-        for (int ks = 1; ks < 4; ++ks)
-          s = E::mma(E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES), qf[ks], s);
+        for (int ks = 0; ks < 4; ++ks) {
+          const Frag kf = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
+#pragma unroll
+          for (int j = 0; j < QB; ++j) s[j] = E::mma(kf, qf[j][ks], ks == 0 ? negm[j] : s[j]);     // s = S - m
+        }
         if (k0 + sub * 32 + 32 > a.Nkv) {              // keys beyond the context length
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Nkv) s[i] = -INFINITY;
-        }
-        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);   // v_max3_f32 chain
+          for (int j = 0; j < QB; ++j)
 #pragma unroll
-        for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s[i]), s[i + 1]);
-        tmax = fmaxf(tmax, s[15]);
-        if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR) != 0) {
-          const float tq = fmaxf(tmax, __shfl_xor(tmax, 32));   // finite: every sub-tile visited holds at least one real key
-          const float delta = first ? tq : fmaxf(0.f, tq);      // how far the reference moves up (first: to the exact maximum)
-          const float alpha = __builtin_amdgcn_exp2f(-delta);   // first: l = o = 0, any finite factor will do
-          m += delta;
+            for (int i = 0; i < 16; ++i)
+              if (k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Nkv) s[j][i] = -INFINITY;
+        }
+        float tmax[QB];
+        bool need = first;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+          float t = fmaxf(fmaxf(s[j][0], s[j][1]), s[j][2]);   // v_max3_f32 chain
+#pragma unroll
+          for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, s[j][i]), s[j][i + 1]);
+          tmax[j] = fmaxf(t, s[j][15]);
+          need = need || tmax[j] > RESCALE_THR;
+        }
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+          for (int j = 0; j < QB; ++j) {
+            const float tq = fmaxf(tmax[j], __shfl_xor(tmax[j], 32));   // finite: every sub-tile visited holds at least one real key
+            const float delta = first ? tq : fmaxf(0.f, tq);      // how far the reference moves up (first: to the exact maximum)
+            const float alpha = __builtin_amdgcn_exp2f(-delta);   // first: l = o = 0, any finite factor will do
+            m[j] += delta;
+            l[j] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[j][i] *= alpha; o1[j][i] *= alpha; s[j][i] -= delta; }
+            negm[j] = (f32x16)(-m[j]);
+          }
           first = false;
-          l *= alpha;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; s[i] -= delta; }
-          negm = (f32x16)(-m);
         }
-        {
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
           f32x2 acc2 = (f32x2)(0.f);
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {              // packed fp32 add: one VALU slot per score pair
             f32x2 d;
-            d.x = __builtin_amdgcn_exp2f(s[i]); d.y = __builtin_amdgcn_exp2f(s[i + 1]);
-            s[i] = d.x; s[i + 1] = d.y;
+            d.x = __builtin_amdgcn_exp2f(s[j][i]); d.y = __builtin_amdgcn_exp2f(s[j][i + 1]);
+            s[j][i] = d.x; s[j][i + 1] = d.y;
             acc2 += d;
           }
-          l += acc2.x + acc2.y;
+          l[j] += acc2.x + acc2.y;
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          const Frag pf = X::pack_p(s, st);
           const unsigned char* vs = vb + v_lane + (sub * 32 + 16 * st) * VP;
-          o0 = E::mma(X::load_vt(vs), pf, o0);
-          o1 = E::mma(X::load_vt(vs + 32 * ES), pf, o1);
+          const Frag v0 = X::load_vt(vs), v1 = X::load_vt(vs + 32 * ES);
+#pragma unroll
+          for (int j = 0; j < QB; ++j) {
+            const Frag pf = X::pack_p(s[j], st);
+            o0[j] = E::mma(v0, pf, o0[j]);
+            o1[j] = E::mma(v1, pf, o1[j]);
+          }
         }
       }
     }
@@ -148,15 +178,18 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_d64_kernel(c
     }
     __syncthreads();
   }
-  l += __shfl_xor(l, 32);
-  if (query < a.Nq) {
-    const float inv = 1.0f / l;
-    if (a.lse && h == 0) a.lse[((size_t)b * a.heads + head) * a.Nq + query] = m + __log2f(l);     // log2 domain, scale included
-    T* dst = (T*)a.out + ((size_t)b * a.Nq + query) * a.out_stride + head * 64 + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {                      // register 4g + i <-> d = 8g + 4h + i (+32 for the second row tile)
-      store4(dst + 8 * g, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-      store4(dst + 32 + 8 * g, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+  for (int j = 0; j < QB; ++j) {
+    l[j] += __shfl_xor(l[j], 32);
+    if (query[j] < a.Nq) {
+      const float inv = 1.0f / l[j];
+      if (a.lse && h == 0) a.lse[((size_t)b * a.heads + head) * a.Nq + query[j]] = m[j] + __log2f(l[j]);     // log2 domain, scale included
+      T* dst = (T*)a.out + ((size_t)b * a.Nq + query[j]) * a.out_stride + head * 64 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                      // register 4g + i <-> d = 8g + 4h + i (+32 for the second row tile)
+        store4(dst + 8 * g, o0[j][4 * g] * inv, o0[j][4 * g + 1] * inv, o0[j][4 * g + 2] * inv, o0[j][4 * g + 3] * inv);
+        store4(dst + 32 + 8 * g, o1[j][4 * g] * inv, o1[j][4 * g + 1] * inv, o1[j][4 * g + 2] * inv, o1[j][4 * g + 3] * inv);
+      }
     }
   }
 }
@@ -228,10 +261,10 @@ __global__ __launch_bounds__(256) void geglu_kernel(const pd_geglu_args a) {
   }
 }
 
-template <typename T>
+template <typename T, int QB>
 static int launch_attn_d64(const pd_attn_d64_args* a, hipStream_t st) {
   constexpr int LDS = 2 * 64 * (D64<T>::KP + D64<T>::VP);
-  auto kern = attn_d64_kernel<T>;
+  auto kern = attn_d64_kernel<T, QB>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -240,7 +273,8 @@ static int launch_attn_d64(const pd_attn_d64_args* a, hipStream_t st) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(((a->Nq + 127) / 128) * a->heads * a->B), dim3(256), LDS, st, *a);
+  constexpr int QPB = 128 * QB;
+  hipLaunchKernelGGL(kern, dim3(((a->Nq + QPB - 1) / QPB) * a->heads * a->B), dim3(256), LDS, st, *a);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
@@ -256,8 +290,14 @@ extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
   PD_CHECK(a->q_stride >= a->heads * 64 && a->kv_stride >= a->heads * 64 && a->out_stride >= a->heads * 64 && a->q_stride % 8 == 0 &&
                a->kv_stride % 8 == 0 && a->out_stride % 8 == 0, PD_ERR_SHAPE, "pd_attn_d64: strides must cover heads*64 channels and be multiples of 8");
   PD_CHECK((long long)((a->Nq + 127) / 128) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d64: grid too large");
-  if (a->dtype == PD_F32) return launch_attn_d64<float>(a, (hipStream_t)stream);
-  if (a->dtype == PD_BF16) return launch_attn_d64<bf16_t>(a, (hipStream_t)stream);
+  if (a->dtype == PD_F32) return launch_attn_d64<float, 1>(a, (hipStream_t)stream);
+  if (a->dtype == PD_BF16) {
+    // two query fragments per wave once that still fills the chip (256 CUs x 2 resident workgroups) and the key sequence is
+    // long enough for the LDS traffic to matter
+    static const bool qb1_only = getenv("PD_ATTN64_QB1") != nullptr;      // diagnostic: same-box A/B
+    const bool wide = !qb1_only && a->Nkv >= 512 && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
+    return wide ? launch_attn_d64<bf16_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<bf16_t, 1>(a, (hipStream_t)stream);
+  }
   set_error("pd_attn_d64: bad dtype");
   return PD_ERR_ARG;
 }

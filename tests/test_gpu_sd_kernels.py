@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [(2, 2, 256, 256), (1, 5, 1024, 1024), (2, 3, 200, 77), (1, 1, 16, 16), (2, 2, 130, 4), (1, 20, 64, 64)])
+@pytest.mark.parametrize("cfg", [(2, 2, 256, 256), (1, 5, 1024, 1024), (2, 3, 200, 77), (1, 1, 16, 16), (2, 2, 130, 4), (1, 20, 64, 64),
+                                 (16, 16, 1024, 1024), (16, 16, 1100, 1000)])     # the last two: 64 queries per wave in bf16
 def test_attention_d64(env, mode, cfg):
     L, lib, _, dev = env
     code, tdt = DT[mode]
@@ -73,13 +74,13 @@ def test_geglu(env, mode):
 
 
 # ---- backward kernels of the Transformer2D blocks: against autograd over plain PyTorch fp32 ---------------------------------
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_attention_d64_deferred_rescale(env, mode):
+@pytest.mark.parametrize("mode,shape", [("f32", (2, 3, 320)), ("bf16", (2, 3, 320)), ("bf16", (16, 16, 1024))])   # last: 64 queries per wave
+def test_attention_d64_deferred_rescale(env, mode, shape):
     """Scores that jump far above the running reference maximum late in the key sequence (and a first tile far BELOW the
     rest) force the rescale branch of the deferred-rescale online softmax; checked against fp64 softmax, lse included."""
     L, lib, _, dev = env
     code, tdt = DT[mode]
-    B, heads, N = 2, 3, 320
+    B, heads, N = shape
     Cc = heads * 64
     g = torch.Generator().manual_seed(43)
     q = torch.randn(B, N, Cc, generator=g)
