@@ -99,7 +99,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
   auto issue = [&](int chunk) {
     const unsigned cb = (unsigned)(chunk * CK * ES);
 #pragma unroll
+#ifdef PD_LIN_ABL_X          /* diagnostic build: no activation traffic (prices the X stream) */
+    for (int i = 0; i < NIT; ++i) stage[i] = Stage<T>::load(rsx, OOB_OFF + 0 * cb);
+#else
     for (int i = 0; i < NIT; ++i) stage[i] = Stage<T>::load(rsx, soff[i] == OOB_OFF ? OOB_OFF : soff[i] + cb);
+#endif
     if (affine) {
       const int kc = min(chunk * CK, p.K - 8 - (tid & 7) * 8);       // a trailing half chunk's upper sub-blocks are never read
       const float* ps = p.scale + aff_row + kc;
@@ -164,7 +168,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
         if (ks < nks) {
           const int gn = min(g0 + ks + AD, last_kstep);   // clamped at the end
 #pragma unroll
+#ifdef PD_LIN_ABL_W          /* diagnostic build: every weight fragment load hits fragment 0 (prices the weight stream) */
+          for (int c = 0; c < NC; ++c) aring[(ks + AD) % AR][c] = E::load(wb[c] + (size_t)(gn & 0) * 512);
+#else
           for (int c = 0; c < NC; ++c) aring[(ks + AD) % AR][c] = E::load(wb[c] + (size_t)gn * 512);
+#endif
           const Frag b0 = E::load(buf + b_lane + ks * 16 * ES), b1 = E::load(buf + b_lane + 32 * PITCH + ks * 16 * ES);
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
