@@ -43,7 +43,7 @@ def test_attention_d64(env, mode, cfg):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [(37, 64), (1000, 320), (513, 1280), (4, 2048)])
+@pytest.mark.parametrize("cfg", [(37, 64), (1000, 320), (300, 640), (513, 1280), (4, 2048)])
 def test_layernorm(env, mode, cfg):
     L, lib, _, dev = env
     code, tdt = DT[mode]
@@ -147,7 +147,7 @@ def test_attention_d64_backward(env, mode, cfg):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [(37, 64), (5000, 320), (513, 1280), (4, 2048)])
+@pytest.mark.parametrize("cfg", [(37, 64), (5000, 320), (300, 640), (513, 1280), (4, 2048)])     # 1 / 1 / 2 / 3 / 4 pieces per lane
 @pytest.mark.parametrize("with_res", [False, True])
 def test_layernorm_backward(env, mode, cfg, with_res):
     L, lib, _, dev = env
