@@ -241,6 +241,9 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
     const int g0 = chunk * KSTEPS;
     Frag bc[NF];                           // activation fragments of the current k-step (3 waves per SIMD cover the LDS latency)
     int piece = 0;
+#ifndef PD_NO_IGLP
+    __builtin_amdgcn_iglp_opt(0);          // interleave the region's LDS reads / staging VALU work with the MFMAs (same-box A/B: -1 % per forward)
+#endif
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if constexpr (ACTIVE) {
