@@ -247,6 +247,9 @@ class DDIBGraph:
         B, S = self.B, self.S
         dev = self.device
         self.lib = L.lib()
+        if B > unet.max_batch(H, W):
+            raise ValueError(f"batch_size {B} exceeds what one launch plan holds at {H}x{W} ({unet.max_batch(H, W)} images: tensors are "
+                             f"addressed with 32-bit byte offsets); replay several DDIBGraph runners (shard_batches) instead")
         self.plan = unet.new_plan(B, H, W, dev) if private_plan else unet.plan_for(B, H, W, dev)
         cin = unet.config.in_channels
         # schedulers (host tables)
@@ -383,6 +386,8 @@ class CFGForwardStartGraph:
         W = width or (ss if isinstance(ss, int) else ss[1])
         self.B, self.S = B, S = batch_size, num_inference_steps
         self.lib = L.lib()
+        if B > unet.max_batch(H, W):
+            raise ValueError(f"batch_size {B} exceeds what one launch plan holds at {H}x{W} ({unet.max_batch(H, W)} images)")
         self.plan = unet.plan_for(B, H, W, dev)
         cin = unet.config.in_channels
         sch = pipe.scheduler

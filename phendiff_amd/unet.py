@@ -269,6 +269,17 @@ class CustomCondUNet2DModel(nn.Module):
             if ts.numel() == 1:
                 ts = ts.expand(B)
             ts = ts.contiguous()
+        mb = self.max_batch(sample.shape[2], sample.shape[3])
+        if B > mb:      # the kernels address one tensor with 32-bit byte offsets (< 2 GiB): larger batches run in even slices
+            outs = []
+            n_sl = -(-B // mb)
+            step = -(-B // n_sl)
+            for b0 in range(0, B, step):
+                sl = slice(b0, min(B, b0 + step))
+                outs.append(self.forward(sample[sl], ts[sl], class_labels[sl] if class_labels is not None else None,
+                                         class_emb[sl] if class_emb is not None else None, return_dict=False)[0])
+            out = torch.cat(outs, 0)
+            return UNet2DOutput(sample=out) if return_dict else (out,)
         plan = self.plan_for(B, sample.shape[2], sample.shape[3], dev)
         x = sample.contiguous().to(torch.float32)
         labels = class_labels.to(device=dev, dtype=torch.int64).contiguous() if class_labels is not None else None
@@ -281,6 +292,15 @@ class CustomCondUNet2DModel(nn.Module):
         if not return_dict:
             return (out,)
         return UNet2DOutput(sample=out)
+
+    def max_batch(self, H, W) -> int:
+        """Largest batch one launch plan can hold: its widest materialised activation at full resolution (the last upsampler's
+        output, block_out_channels[1] channels; channel concats are never materialised; the fp32 NCHW input / output) must stay
+        below 2 GiB."""
+        esz = 2 if self.compute_dtype == "bf16" else 4
+        boc = self.config.block_out_channels
+        per_image = H * W * max(max(boc[0], boc[min(1, len(boc) - 1)]) * esz, 4 * max(self.config.in_channels, self.config.out_channels))
+        return max(1, (2 ** 31 - 2 ** 20) // per_image)
 
     def new_plan(self, B, H, W, device):
         """A plan with its OWN activation buffers (for trajectories replayed concurrently on different streams)."""

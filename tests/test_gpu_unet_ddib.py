@@ -335,3 +335,22 @@ def test_full_size_trajectory_bf16_vs_f32_engine():
     assert rel(outs["bf16"][1], outs["f32"][1]) < 6e-2          # inverted latents after 50 steps
     assert rel(outs["bf16"][0], outs["f32"][0]) < 6e-2          # images after 100 steps
     assert float(outs["bf16"][0].min()) >= 0.0 and float(outs["bf16"][0].max()) <= 1.0
+
+
+def test_forward_slices_batches_beyond_the_2gib_tensor_limit(monkeypatch):
+    """A batch whose widest activation would pass 2 GiB runs in even slices (the kernels use 32-bit byte offsets); per-sample
+    results do not depend on the slicing (bitwise)."""
+    import phendiff_amd as P
+    torch.manual_seed(0)
+    m = P.CustomCondUNet2DModel(compute_dtype="bf16", **dict(P.UNET_CONFIGS["super_small"], sample_size=32)).to("cuda:0")
+    assert m.max_batch(256, 256) == 127 and m.max_batch(32, 32) > 4096
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(7, 3, 32, 32, generator=g).cuda()
+    ts = torch.tensor([5, 900, 33, 2999, 1500, 7, 64]).cuda()
+    labels = torch.tensor([0, 1, 1, 0, 1, 0, 0]).cuda()
+    whole = m(x, ts, labels).sample.clone()
+    monkeypatch.setattr(type(m), "max_batch", lambda self, H, W: 3)
+    sliced = m(x, ts, labels).sample
+    assert sliced.shape == whole.shape and torch.equal(sliced, whole)
+    emb = torch.randn(7, m.time_embed_dim, generator=g).cuda()
+    assert torch.equal(m(x, 400, class_emb=emb, return_dict=False)[0][4:], m(x[4:], 400, class_emb=emb[4:]).sample)
