@@ -66,6 +66,6 @@ def test_argument_validation_without_gpu():
     assert lib.pd_attn_wide(C.byref(L.AttnWideArgs(dtype=1, B=1, heads=1, D=512, Nq=0, Nkv=4)), None) == -2
     assert lib.pd_attn_d64_bwd(C.byref(L.AttnD64BwdArgs(dtype=1, B=1, heads=1, Nq=4, Nkv=4)), None) == -1
     assert lib.pd_layernorm_bwd(C.byref(L.LayerNormBwdArgs(dtype=1, rows=4, C=12)), None) == -1
-    assert lib.pd_layernorm_bwd_blocks(10) == 3 and lib.pd_layernorm_bwd_blocks(1 << 20) == 1024
+    assert lib.pd_layernorm_bwd_blocks(10) == 3 and lib.pd_layernorm_bwd_blocks(1 << 20) == 2048
     with pytest.raises(L.PhenDiffHipError):
         L.check(-1, "x")
