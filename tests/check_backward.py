@@ -1,4 +1,5 @@
-"""Per-parameter gradient error of the HIP UNet backward against torch.autograd over the CPU oracle (diagnostic)."""
+"""Per-parameter gradient error of the HIP UNet backward against torch.autograd over the CPU oracle (diagnostic checker: lives
+under tests/ because only the tests, smoke() and the bench CPU baseline may use the oracle).  python tests/check_backward.py"""
 import sys
 import os
 import torch
