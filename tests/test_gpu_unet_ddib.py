@@ -337,6 +337,33 @@ def test_full_size_trajectory_bf16_vs_f32_engine():
     assert float(outs["bf16"][0].min()) >= 0.0 and float(outs["bf16"][0].max()) <= 1.0
 
 
+@pytest.mark.skipif(bool(os.environ.get("PD_SKIP_LONG_TESTS")), reason="one minute of CPU oracle on 16 cores (numbers of the last run: DESIGN.md section 2)")
+def test_full_size_full_length_trajectory_vs_oracle():
+    """The metric's workload end to end against the CPU oracle itself: 256x256, super_small, 50 inversion + 50 denoising
+    steps, one image -- the exact-fp32 engine (and the bf16 engine) against oracle `ddib_ref` on identical weights."""
+    import time
+    import phendiff_amd as P
+    from oracle import ConditionalDDIMPipelineRef, DDIMSchedulerRef, ddib_ref
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    r, m32 = make_pair("super_small", 256, "f32")
+    x, labels = synth_batch(1, 256)
+    cfg = P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]
+    t0 = time.time()
+    with torch.no_grad():
+        ref, ref_inv = ddib_ref(ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**cfg)), x, labels, 1 - labels, 50)
+    t_cpu = time.time() - t0
+    ref = torch.as_tensor(ref)
+    res, res_inv = {}, {}
+    for mode, m in (("f32", m32), ("bf16", make_pair("super_small", 256, "bf16")[1])):
+        pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**cfg))
+        out = P.DDIBGraph(pipe, batch_size=1, num_inference_steps=50).run(x.cuda(), labels.cuda(), (1 - labels).cuda())
+        torch.cuda.synchronize()
+        res[mode], res_inv[mode] = rel(out.images.cpu(), ref), rel(out.inverted.cpu(), ref_inv)
+    print(f"full-length oracle trajectory: {t_cpu:.1f} s on the CPU; rel-L2 of the final images: f32 engine {res['f32']:.2e}, "
+          f"bf16 engine {res['bf16']:.2e}; of the inverted latents after 50 steps: {res_inv['f32']:.2e} / {res_inv['bf16']:.2e}")
+    assert res["f32"] < 2e-3 and res["bf16"] < 8e-2
+
+
 def test_forward_slices_batches_beyond_the_2gib_tensor_limit(monkeypatch):
     """A batch whose widest activation would pass 2 GiB runs in even slices (the kernels use 32-bit byte offsets); per-sample
     results do not depend on the slicing (bitwise)."""
