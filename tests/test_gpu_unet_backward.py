@@ -47,7 +47,7 @@ def compare(ref, got, per_param_tol, global_tol):
 
 
 @pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 2e-4, 2e-5), ("bf16", 8e-2, 2e-2)])
-@pytest.mark.parametrize("size", [32, 64])
+@pytest.mark.parametrize("size", [32, 64, 128])          # 128 = BASELINE configs[1]'s image size
 def test_unet_backward_matches_autograd(mode, per_tol, glob_tol, size):
     from phendiff_amd.unet_train import UNetTrainer
     r, m = make_pair("super_small", size, mode)
