@@ -63,6 +63,35 @@ def test_sd_unet_forward(mode, tol, cfg, size):
     assert rel(m(x.cuda(), 500, ehs).sample, ref_s) < tol
 
 
+@pytest.mark.skipif(bool(__import__("os").environ.get("PD_SKIP_LONG_TESTS")), reason="builds the 866 M-parameter oracle on the CPU (~1 minute)")
+def test_sd21_unet_full_size_forward_vs_oracle():
+    """The real SD-2.1 UNet2DConditionModel configuration (865.9 M parameters: 320 / 640 / 1280 / 1280 channels, 5 / 10 / 20 / 20
+    heads of 64, 1024-wide context, 1280-wide time embedding with 22 720 projection outputs) at 64x64 latents, random init:
+    exact-fp32 and bf16 engines against the CPU oracle -- the widths at which the split time-embedding kernels, the fused
+    GEGLU GEMMs and the pre-applied GroupNorm path are actually taken."""
+    import os
+    import phendiff_amd as P
+    from oracle import class_emb_to_encoder_hidden_states as ehs_ref
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    r, emb, m, e2 = make_pair(P.SD21_UNET_CONFIG, "f32")
+    assert sum(p.numel() for p in r.parameters()) == 865_910_724
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    labels, ts = torch.tensor([1]), torch.tensor([621])
+    with torch.no_grad():
+        ref = r(x, ts, ehs_ref(emb(labels))).sample
+    ehs = P.class_emb_to_encoder_hidden_states(e2(labels.cuda()))
+    got = m(x.cuda(), ts.cuda(), ehs).sample
+    assert rel(got, ref) < 1e-4, rel(got, ref)
+    sd = r.state_dict()
+    del m
+    torch.cuda.empty_cache()
+    m16 = P.SDUNet2DConditionModel(compute_dtype="bf16", **P.SD21_UNET_CONFIG)
+    m16.load_state_dict(sd)
+    got16 = m16.to("cuda:0")(x.cuda(), ts.cuda(), ehs).sample
+    assert rel(got16, ref) < 4e-2, rel(got16, ref)
+
+
 def test_sd_unet_rejects_bad_calls():
     import phendiff_amd as P
     _, _, m, _ = make_pair(TINY, "f32")
