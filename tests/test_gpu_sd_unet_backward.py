@@ -58,6 +58,26 @@ def test_sd_unet_backward_matches_autograd(mode, per_tol, glob_tol, cfg, size):
     compare({n: 2 * g for n, g in ref.items()}, tr.grads, per_tol, glob_tol)
 
 
+@pytest.mark.skipif(bool(__import__("os").environ.get("PD_SKIP_LONG_TESTS")), reason="866 M-parameter oracle + autograd on the CPU (~1 minute)")
+def test_sd21_unet_full_size_backward_matches_autograd_bf16():
+    """BASELINE configs[3]'s model at its real widths: gradients of all 686 parameters of the SD-2.1 UNet (865.9 M) + the
+    CustomEmbedding table from the bf16 engine (the one the fine-tuning bench times) against torch.autograd over the CPU oracle,
+    2 samples at 32x32 latents."""
+    import os
+    import phendiff_amd as P
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    r, emb, m, e2 = make_pair(P.SD21_UNET_CONFIG, "bf16")
+    B = 2
+    sched, clean, noise, ts, labels, noisy, target = batch(B, 32)
+    loss_ref, ref = oracle_grads(r, emb, noisy, ts, target, labels)
+    tr = P.SDUNetTrainer(m, e2, sched, lr=1e-4, use_ema=False)
+    loss, _ = tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    assert len(ref) == 687
+    assert abs(float(loss) - float(loss_ref)) < 5e-3 * float(loss_ref)
+    compare(ref, tr.grads, 1e-1, 2.5e-2)
+
+
 def test_sd_unet_backward_unconditional_step_f32():
     """All-zero context (utils_training.py:465-471): the class table and the cross-attention key / value projections get no
     gradient; everything else does."""
