@@ -146,3 +146,35 @@ def test_sd_pipeline_eta_and_seeded_variance_noise():
     a = pipe(image=x.cuda(), class_labels=[1, 0], strength=0.5, num_inference_steps=4, generator=gens(), output_type="latent")
     b = pipe(image=x.cuda(), class_labels=[1, 0], strength=0.5, num_inference_steps=4, generator=gens(), output_type="latent")
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+@pytest.mark.skipif(bool(os.environ.get("PD_SKIP_LONG_TESTS")), reason="full-size SD stack on the CPU oracle (~2 minutes)")
+def test_sd_img2img_full_size_stack_vs_oracle():
+    """BASELINE configs[4] at its real sizes: the SD-2.1 UNet (865.9 M) + the SD VAE (83.7 M) + CustomEmbedding(2, 1024), one
+    512x512 image -> 64x64 latents, DDIB with 2 + 2 DDIM steps: exact-fp32 engine against the CPU oracle (random init)."""
+    import phendiff_amd as P
+    from oracle import (AutoencoderKLRef, CustomEmbeddingRef, DDIMSchedulerRef, SDImg2ImgPipelineRef, UNet2DConditionRef,
+                        sd_ddib_ref)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    torch.manual_seed(0)
+    r_unet = UNet2DConditionRef(**P.SD21_UNET_CONFIG).eval()
+    r_vae = AutoencoderKLRef(**P.SD_VAE_CONFIG).eval()
+    r_emb = CustomEmbeddingRef(2, 1024)
+    sched_cfg = P.SCHEDULER_CONFIGS["SD_orig_config"]
+    ref_pipe = SDImg2ImgPipelineRef(r_vae, r_unet, DDIMSchedulerRef(**sched_cfg), r_emb)
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1)
+    labels = torch.tensor([0])
+    want, inverted, latents = sd_ddib_ref(ref_pipe, x, labels, 1 - labels, 2, generator=torch.Generator().manual_seed(5))
+    unet = P.SDUNet2DConditionModel(compute_dtype="f32", **P.SD21_UNET_CONFIG)
+    unet.load_state_dict(r_unet.state_dict())
+    vae = P.AutoencoderKL(compute_dtype="f32", **P.SD_VAE_CONFIG)
+    vae.load_state_dict(r_vae.state_dict())
+    emb = P.CustomEmbedding(2, 1024)
+    emb.load_state_dict(r_emb.state_dict())
+    pipe = P.CustomStableDiffusionImg2ImgPipeline(vae.to("cuda:0"), unet.to("cuda:0"), P.DDIMScheduler(**sched_cfg), emb.to("cuda:0"))
+    lat, [cond] = P.LDM_preprocess(pipe, x.cuda(), [labels.cuda()], generator=torch.Generator().manual_seed(5))
+    assert lat.shape == (1, 4, 64, 64) and rel(lat, latents) < 1e-4
+    got = P.ddib(pipe, x.cuda(), labels.cuda(), (1 - labels).cuda(), 2, generator=torch.Generator().manual_seed(5))
+    assert got.shape == want.shape == (1, 512, 512, 3)
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-3
