@@ -180,16 +180,13 @@ def main_train(args, P, world, rank, dev, dist):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, ranks = reduce_elapsed(dist, elapsed, dev, B * args.steps)
     assert torch.isfinite(loss).all()
     value = world * B * args.steps / elapsed
     res = {
         "metric": "DDIM training images/sec (128x128 cond_unet_2d, bf16)", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", **ranks,
         "config": {"workload": f"configs[1]: {size}x{size} cond_unet_2d DDIM training, {args.model} UNet (random init, seed 0), "
                                f"3k_steps_clipping_rescaling / v_prediction, batch {B}/GPU (launch_script_DDIM.sh:52) on {world} GPU(s), "
                                "AdamW(.95,.999) + clip 1.0 + EMA, data-parallel gradient all-reduce overlapped with the backward",
@@ -238,7 +235,20 @@ def _sd_stack(P, args, dev, latent_only=False):
     return unet, vae, emb, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["SD_orig_config"])
 
 
-def _timed_steps(args, dev, dist, step):
+def reduce_elapsed(dist, elapsed, dev, units_per_rank):
+    """MAX of the ranks' elapsed time (the contract's clock) + what each rank did: per-rank units/s and the size of the process
+    group RCCL actually formed."""
+    if dist is None:
+        return elapsed, {"rccl_world_size": 1, "per_rank_units_per_s": [round(units_per_rank / elapsed, 4)]}
+    world = dist.get_world_size()
+    mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    times = [float(t.item()) for t in every]
+    return max(times), {"rccl_world_size": world, "per_rank_units_per_s": [round(units_per_rank / t, 4) for t in times]}
+
+
+def _timed_steps(args, dev, dist, step, units_per_rank):
     def barrier():
         torch.cuda.synchronize(dev)
         if dist is not None:
@@ -253,11 +263,8 @@ def _timed_steps(args, dev, dist, step):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed, out
+    elapsed, ranks = reduce_elapsed(dist, elapsed, dev, units_per_rank)
+    return elapsed, out, ranks
 
 
 def _back_to_back_ms(ops, stream, reps=5):
@@ -307,13 +314,13 @@ def main_sd_img2img(args, P, world, rank, dev, dist):
     x, labels = x.to(dev), labels.to(dev)
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     P.ddib(pipe, x, labels, 1 - labels, 1, generator=gen)          # builds every launch plan
-    elapsed, out = _timed_steps(args, dev, dist, lambda: P.ddib(pipe, x, labels, 1 - labels, S, generator=gen))
+    elapsed, out, ranks = _timed_steps(args, dev, dist, lambda: P.ddib(pipe, x, labels, 1 - labels, S, generator=gen), B * args.steps)
     assert out.shape == (B, size, size, 3)
     value = world * B * args.steps / elapsed
     res = {"metric": "SD img2img images/sec (VAE encode + 50-step DDIM invert + 50-step denoise + VAE decode, 512x512)",
            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": args.dtype, "data": "synthetic",
+           "dtype": args.dtype, "data": "synthetic", **ranks,
            "config": {"workload": f"configs[4]: custom_pipeline_stable_diffusion_img2img DDIB, {size}x{size} images ({size // 8}x{size // 8} "
                                   f"latents), {S}+{S} DDIM steps, SD-2.1 UNet (865.9 M) + SD VAE (83.7 M) + CustomEmbedding, random init, "
                                   f"SD_orig_config / v_prediction, {B} images/GPU/step sharded over {world} GPU(s), no collectives",
@@ -351,12 +358,12 @@ def main_sd_train(args, P, world, rank, dev, dist):
         count[0] += 1
         return tr.step(noisy, ts, clean, noise, labels, unconditional=(count[0] % 10 == 0))
 
-    elapsed, loss = _timed_steps(args, dev, dist, step)
+    elapsed, loss, ranks = _timed_steps(args, dev, dist, step, B * args.steps)
     assert torch.isfinite(loss).all()
     value = world * B * args.steps / elapsed
     res = {"metric": "SD-2.1 UNet fine-tuning samples/sec (64x64 latents = 512x512, bf16)", "value": round(value, 3), "unit": "samples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", **ranks,
            "config": {"workload": f"configs[3]: SD-2.1 UNet (865.9 M, random init) + CustomEmbedding fine-tune, {size}x{size} latents, "
                                   f"batch {B}/GPU on {world} GPU(s), SD_orig_config / v_prediction, AdamW(.95,.999) + clip 1.0 + EMA, "
                                   "data-parallel gradient all-reduce (64 MB buckets) overlapped with the backward",
@@ -375,6 +382,32 @@ def main_sd_train(args, P, world, rank, dev, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launcher_command(gpus, argv, port):
+    """The command line `python bench.py --gpus N ...` turns into: one process per GPU under torch.distributed.run, rendezvous on
+    127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    """Start `gpus` fresh ranks of this script and return their exit code.  Called before anything initialises the GPU in this
+    process (counting devices does not), and the ranks are child processes, never an exec of a GPU-touched one."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = launcher_command(gpus, argv, port)
+    if os.environ.get("PD_BENCH_PRINT_LAUNCH"):         # tests: show the command line instead of running it
+        print(json.dumps(cmd))
+        return 0
+    have = torch.cuda.device_count()
+    if have < gpus:
+        print(f"bench.py: --gpus {gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
 
 
 def main():
@@ -397,15 +430,18 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher (the reference's `accelerate launch --multi_gpu --num_processes N`,
+        # launch_script_DDIM.sh:19-34).  Nothing in this process has touched the GPU: the ranks are fresh children.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     import phendiff_amd as P
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -459,10 +495,7 @@ def main():
         multi.run(x, labels, target)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, ranks = reduce_elapsed(dist, elapsed, dev, B * args.steps)
     assert torch.isfinite(runner.images).all()
 
     images = world * B * args.steps
@@ -470,7 +503,7 @@ def main():
     res = {
         "metric": "img2img images/sec (50-step DDIM invert+denoise, 256x256)", "value": round(value, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", **ranks,
         "config": {"workload": f"configs[2]: {size}x{size} pipeline_conditional_ddim invert->class-swap->denoise, "
                                f"{S}+{S} DDIM steps, {args.model} UNet (random init, seed 0), 3k_steps_clipping_rescaling, "
                                f"{B} images/GPU/step sharded over {world} GPU(s), no collectives",

@@ -9,8 +9,36 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PD_LIB: diagnostic override (same-box A/B of two builds of the library); the default is the in-tree build
+# PD_LIB: diagnostic override (same-box A/B of two builds of the library, kept OUTSIDE the package under build_ab/); the default
+# -- and the only thing the driver ever loads -- is the in-tree build
 LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "libphendiff_hip.so")
+
+
+
+def source_hash() -> str:
+    """sha256 over the library's sources (csrc/*.hip, csrc/*.h, include/phendiff_hip.h, the build script): identifies the code
+    a build / a committed profile belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".sh")))
+    files.append(os.path.join(_HERE, "..", "include", "phendiff_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def library_is_current() -> bool:
+    """True when the loaded library's manifest names the sources in the tree (an in-tree build of this checkout)."""
+    import json
+    try:
+        with open(LIB_PATH + ".manifest.json") as f:
+            return json.load(f).get("sources_sha256") == source_hash()
+    except (OSError, ValueError):
+        return False
+
 
 PD_F32, PD_BF16 = 0, 1
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .schedulers import DDIMScheduler
+from .schedulers import DDIMScheduler, randn_tensor
 
 DEFAULT_NUM_INFERENCE_STEPS = 50
 
@@ -108,12 +108,7 @@ class ConditionalDDIMPipeline:
                 f"frac_diffusion_skipped must be a float (or int) between 0 and 1; got {frac_diffusion_skipped}."
 
     def _randn(self, shape, generator, device):
-        # diffusers randn_tensor: a CPU generator draws on the CPU then moves; a device generator draws on the device
-        if isinstance(generator, list):
-            parts = [self._randn((1,) + tuple(shape[1:]), g, device) for g in generator]
-            return torch.cat(parts, 0)
-        gdev = generator.device if generator is not None else device
-        return torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device)
+        return randn_tensor(shape, generator, device)
 
     @torch.no_grad()
     def __call__(self, class_labels: Optional[torch.Tensor], class_emb: Optional[torch.Tensor] = None,
@@ -163,7 +158,7 @@ class ConditionalDDIMPipeline:
                     zeros_emb = torch.zeros((batch_size, self.unet.time_embed_dim), device=device)
                 uncond = self.unet(sample=image, timestep=t, class_labels=None, class_emb=zeros_emb).sample
             image, _ = self.scheduler._device_step(
-                cond, t, image, eta, bool(use_clipped_model_output), generator if not isinstance(generator, list) else None,
+                cond, t, image, eta, bool(use_clipped_model_output), generator,
                 None, uncond_output=uncond, w=w, guidance_cfg=(guidance_eqn == "CFG"), want_x0=False)
         # :349-350 -- (image/2+.5).clamp(0,1), NCHW -> NHWC, one D2H copy
         B, Cc, H, W = image.shape

@@ -19,6 +19,18 @@ import torch
 from . import _lib as L
 
 
+
+def randn_tensor(shape, generator, device, dtype=torch.float32):
+    """diffusers ``randn_tensor``: a CPU generator draws on the CPU (then moves), a device generator on the device; a LIST of
+    generators draws one ``(1, ...)`` sample per generator (per-sample reproducibility) and concatenates."""
+    if isinstance(generator, (list, tuple)):
+        if len(generator) != shape[0]:
+            raise ValueError(f"list of {len(generator)} generators for a batch of {shape[0]}")
+        return torch.cat([randn_tensor((1,) + tuple(shape[1:]), g, device, dtype) for g in generator], 0)
+    gdev = generator.device if generator is not None else device
+    return torch.randn(tuple(shape), generator=generator, device=gdev, dtype=dtype).to(device)
+
+
 class SchedulerOutput(SimpleNamespace):
     """``DDIMSchedulerOutput`` stand-in: ``.prev_sample``, ``.pred_original_sample``."""
 
@@ -132,9 +144,7 @@ class _SchedulerBase:
         L.check(lib.pd_ddim_step(C.byref(a), st), "pd_ddim_step")
         if eta > 0:
             if variance_noise is None:
-                # diffusers randn_tensor: a CPU generator draws on the CPU (then moves), a device generator on the device
-                gdev = generator.device if generator is not None else mo.device
-                variance_noise = torch.randn(mo.shape, generator=generator, device=gdev, dtype=mo.dtype).to(mo.device)
+                variance_noise = randn_tensor(mo.shape, generator, mo.device, mo.dtype)
             prev = prev + sigma * variance_noise.to(device=mo.device, dtype=mo.dtype)
         return prev, x0
 

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib as L
 from .pipeline import numpy_to_pil
-from .schedulers import DDIMScheduler
+from .schedulers import DDIMScheduler, randn_tensor
 from .vae import VaeImageProcessor
 
 DEFAULT_NUM_INFERENCE_STEPS = 50
@@ -192,13 +192,8 @@ class CustomStableDiffusionImg2ImgPipeline:
 
     @staticmethod
     def _randn(shape, generator, device):
-        """diffusers ``randn_tensor``: a CPU generator draws on the CPU (then moves), a device generator on the device."""
-        if isinstance(generator, list):
-            return torch.cat([CustomStableDiffusionImg2ImgPipeline._randn((1,) + tuple(shape[1:]), g, device) for g in generator], 0)
-        gdev = generator.device if generator is not None else device
-        return torch.randn(tuple(shape), generator=generator, device=gdev, dtype=torch.float32).to(device)
+        return randn_tensor(shape, generator, device)
 
-    # ---- :385-445 --------------------------------------------------------------------------------------------------------
     def prepare_latents(self, image, timestep, batch_size, dtype, device, latent_shape, generator, add_forward_noise_to_image):
         if image is not None and not isinstance(image, (torch.Tensor, list)):
             raise ValueError(f"`image` has to be of type `torch.Tensor`, `PIL.Image.Image`, list, or `None`, but is {type(image)}")
@@ -265,7 +260,7 @@ class CustomStableDiffusionImg2ImgPipeline:
                                        add_forward_noise_to_image=add_forward_noise_to_image)
         latents = latents.contiguous()
         extra = self.prepare_extra_step_kwargs(generator, eta)
-        step_gen = generator if not isinstance(generator, list) else None
+        step_gen = generator
         B = latents.shape[0]
         two = torch.empty((2 * B,) + tuple(latents.shape[1:]), dtype=torch.float32, device=device) if do_cfg else None
         num_warmup_steps = len(timesteps) - num_inference_steps * self.scheduler.order

@@ -347,8 +347,8 @@ class SDUNetTrainer(UNetTrainer):
     + EMA -> re-pack.  Call ``step(noisy_latents, timesteps, clean_latents, noise, class_labels, unconditional=False)``."""
 
     def __init__(self, model: SDUNet2DConditionModel, class_embedding: CustomEmbedding, scheduler, lr: float, *, device=None,
-                 train_class_embedding: bool = True, use_ema: bool = True, max_grad_norm: Optional[float] = 1.0, **adamw):
-        from .training import DiffusionLoss, FlatAdamWEMA
+                 train_class_embedding: bool = True, use_ema: bool = True, max_grad_norm: Optional[float] = 1.0, group=None, **adamw):
+        from .training import DiffusionLoss, FlatAdamWEMA, broadcast_from_rank0_
         self.model, self.class_embedding, self.scheduler = model, class_embedding, scheduler
         dev = device or model.device
         if torch.device(dev).type != "cuda":
@@ -358,7 +358,11 @@ class SDUNetTrainer(UNetTrainer):
             order = order + [(EMB_NAME, class_embedding.inner_module.weight)]
         self.opt = FlatAdamWEMA([p for _, p in order], lr, use_ema=use_ema, max_grad_norm=max_grad_norm, **adamw)
         if train_class_embedding:
-            self.opt.set_tail(class_embedding.inner_module.weight.numel())
+            self.opt.set_tail(class_embedding.inner_module.weight.numel(), (EMB_NAME,))
+        # DDP's wrap-time broadcast (train.py:311-326): rank 0's parameters everywhere; the EMA shadow starts from them
+        broadcast_from_rank0_(self.opt.flat, group)
+        if self.opt.ema is not None:
+            self.opt.ema.copy_(self.opt.flat)
         self.params = {n: p.data for n, p in order}
         self.grads = {n: p.grad for n, p in order}
         model.invalidate()
@@ -369,20 +373,37 @@ class SDUNetTrainer(UNetTrainer):
         self._repack = None
         self._uncond = False
 
+    def checkpoint_modules(self):
+        """accelerate's numbering of the prepared models (train.py:318-326): unet 0, vae 1 (frozen, not the trainer's), class
+        embedding 2 -- flat names of the embedding carry the ``class_embedding.`` prefix."""
+        mods = [(0, self.model, "")]
+        if EMB_NAME in self.params:
+            mods.append((2, self.class_embedding, "class_embedding."))
+        return mods
+
     def _optimizer_step(self, lr):
         # an unconditional step leaves the CustomEmbedding without a gradient: torch's AdamW skips it (EMA still steps)
         self.opt.step(lr, tail_active=not self._uncond)
 
+    def _make_packed(self):
+        return _SDPackedWeights(self.model, self.device)
+
+    def _make_train_weights(self):
+        return SDTrainWeights(self.model, self.device, self.model._weights.tdt)
+
+    def _make_repacker(self):
+        return _SDRepacker(self.model, self.model._weights, self._tw)
+
+    def _make_plan(self, key):
+        m = self.model
+        return SDUNetTrainPlan(m, m._weights, self._tw, *key, self.device, self.params, self.grads)
+
     def plan_for(self, B, H, W, tokens=77):
+        self._bind_weights()
         key = (B, H, W, tokens)
         p = self._plans.get(key)
         if p is None:
-            m = self.model
-            if m._weights is None:
-                m._weights = _SDPackedWeights(m, self.device)
-            if self._tw is None:
-                self._tw = SDTrainWeights(m, self.device, m._weights.tdt)
-            p = SDUNetTrainPlan(m, m._weights, self._tw, B, H, W, tokens, self.device, self.params, self.grads)
+            p = self._make_plan(key)
             self._plans[key] = p
         return p
 
@@ -416,11 +437,3 @@ class SDUNetTrainer(UNetTrainer):
         self._uncond = bool(unconditional)
         return super().step(noisy, timesteps, clean, noise, class_labels=class_labels, class_emb=None, lr=lr, group=group,
                             overlap=overlap, bucket_bytes=bucket_bytes)
-
-    def refresh_weights(self):
-        m = self.model
-        if m._weights is None or self._tw is None:
-            return
-        if self._repack is None:
-            self._repack = _SDRepacker(m, m._weights, self._tw)
-        self._repack.run(torch.cuda.current_stream(self.device).cuda_stream)

@@ -6,7 +6,9 @@ writes under ``<run>/checkpoints/step_<n>`` (``utils_misc.py:322-347``) and read
     step_<n>/optimizer.bin            torch.optim.AdamW.state_dict()        (parameters indexed in unet.parameters() order)
     step_<n>/scheduler.bin            LambdaLR.state_dict()                 (cosine schedule with warm-up, train.py:298-303)
     step_<n>/random_states_<rank>.pkl python / numpy / torch / torch.cuda RNG states
-    step_<n>/custom_checkpoint_0.pkl  diffusers EMAModel.state_dict()       (accelerate's slot for registered objects; the
+    step_<n>/pytorch_model_2.bin      class_embedding.state_dict()          (StableDiffusion runs: accelerate numbers the prepared
+                                      models unet, vae, class_embedding -- train.py:318-326; the frozen VAE is not the trainer's)
+    step_<n>/custom_checkpoint_<k>.pkl diffusers EMAModel.state_dict() per trained module (accelerate's slot for registered objects; the
                                       reference does not register its EMA -- writing it costs nothing and makes a resumed run
                                       continue the same EMA trajectory; a folder without it loads fine)
 
@@ -121,15 +123,42 @@ def restore_random_states(st: dict):
             pass
 
 
+def _checkpoint_modules(trainer):
+    """[(file index, module, flat-name prefix)] in the order accelerate numbers the prepared models (``pytorch_model.bin``,
+    ``pytorch_model_1.bin``, ...; train.py:311-326).  A trainer with more than the UNet says so itself."""
+    f = getattr(trainer, "checkpoint_modules", None)
+    return f() if f is not None else [(0, trainer.model, "")]
+
+
+def _model_file(i: int) -> str:
+    return "pytorch_model.bin" if i == 0 else f"pytorch_model_{i}.bin"
+
+
+def _optimizer_names(trainer, mods):
+    """Parameter names in the order torch's optimizer indexes them (``params_to_optimize``, train.py:268-272: the trained
+    modules' ``parameters()`` one after the other), restricted to what the trainer actually optimises."""
+    names = []
+    for _, mod, prefix in mods:
+        names += [prefix + n for n, _ in mod.named_parameters() if prefix + n in trainer.params]
+    missing = [n for n in trainer.params if n not in set(names)]
+    if missing:
+        raise KeyError(f"trained parameters without a checkpoint module: {missing[:5]}")
+    return names
+
+
 def save_state(trainer, output_dir: str, rank: int = 0, base_lr: Optional[float] = None, lr_step: Optional[int] = None,
                current_lr: Optional[float] = None):
-    """``accelerator.save_state(output_dir)`` for a :class:`phendiff_amd.unet_train.UNetTrainer`."""
+    """``accelerator.save_state(output_dir)`` for a :class:`phendiff_amd.unet_train.UNetTrainer` / ``SDUNetTrainer``: every
+    trained module's weights, the Adam moments of EVERY optimised parameter (the ``CustomEmbedding`` included, with its own step
+    count) and one EMA file per trained module."""
     os.makedirs(output_dir, exist_ok=True)
-    m, opt = trainer.model, trainer.opt
-    pnames = [n for n, _ in m.named_parameters()]
+    opt = trainer.opt
+    mods = _checkpoint_modules(trainer)
+    pnames = _optimizer_names(trainer, mods)
     fnames = list(trainer.params)
     sizes = {n: trainer.params[n].shape for n in fnames}
-    torch.save({k: v.detach().cpu() for k, v in m.state_dict().items()}, os.path.join(output_dir, "pytorch_model.bin"))
+    for i, mod, _ in mods:
+        torch.save({k: v.detach().cpu() for k, v in mod.state_dict().items()}, os.path.join(output_dir, _model_file(i)))
     torch.save(optimizer_state_dict(pnames, fnames, sizes, opt.exp_avg, opt.exp_avg_sq, opt.t, opt.lr, opt.betas, opt.eps, opt.wd,
                                     {n: opt.t_tail for n in getattr(opt, "tail_names", ())}),
                os.path.join(output_dir, "optimizer.bin"))
@@ -138,25 +167,32 @@ def save_state(trainer, output_dir: str, rank: int = 0, base_lr: Optional[float]
     with open(os.path.join(output_dir, f"random_states_{rank}.pkl"), "wb") as f:
         pickle.dump(random_states(), f)
     if opt.ema is not None:
-        torch.save(ema_state_dict(opt.ema, fnames, pnames, sizes, opt.t, **{k: v for k, v in opt.ema_kwargs.items()}),
-                   os.path.join(output_dir, "custom_checkpoint_0.pkl"))
+        for slot, (_, mod, prefix) in enumerate(mods):       # one EMAModel per trained module (train.py:224-241)
+            mnames = [prefix + n for n, _ in mod.named_parameters() if prefix + n in trainer.params]
+            torch.save(ema_state_dict(opt.ema, fnames, mnames, sizes, opt.t, **{k: v for k, v in opt.ema_kwargs.items()}),
+                       os.path.join(output_dir, f"custom_checkpoint_{slot}.pkl"))
 
 
 def load_state(trainer, input_dir: str, rank: int = 0) -> dict:
-    """``accelerator.load_state(input_dir)``: parameters, Adam moments + step, RNG states and (when present) the EMA shadow.
-    Returns the saved LR-scheduler state (the caller owns the schedule: ``training.cosine_lr_factor``)."""
-    m, opt = trainer.model, trainer.opt
-    pnames = [n for n, _ in m.named_parameters()]
+    """``accelerator.load_state(input_dir)``: parameters, Adam moments + step counts, RNG states and (when present) the EMA
+    shadows.  Returns the saved LR-scheduler state (the caller owns the schedule: ``training.cosine_lr_factor``)."""
+    opt = trainer.opt
+    mods = _checkpoint_modules(trainer)
+    pnames = _optimizer_names(trainer, mods)
     fnames = list(trainer.params)
     sizes = {n: trainer.params[n].shape for n in fnames}
-    sd = torch.load(os.path.join(input_dir, "pytorch_model.bin"), map_location="cpu")
-    own = dict(m.named_parameters())
-    missing = [k for k in own if k not in sd]
-    if missing:
-        raise KeyError(f"checkpoint misses parameters: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
-    with torch.no_grad():
-        for k, p in own.items():
-            p.data.copy_(sd[k].to(p.device, p.dtype))            # in place: the flat buffer and every plan stay valid
+    for i, mod, _ in mods:
+        path = os.path.join(input_dir, _model_file(i))
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: the checkpoint lacks the weights of {type(mod).__name__}")
+        sd = torch.load(path, map_location="cpu")
+        own = dict(mod.named_parameters())
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"{_model_file(i)} misses parameters: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        with torch.no_grad():
+            for k, p in own.items():
+                p.data.copy_(sd[k].to(p.device, p.dtype))        # in place: the flat buffer and every plan stay valid
     osd = torch.load(os.path.join(input_dir, "optimizer.bin"), map_location="cpu")
     steps = {}
     opt.t = load_optimizer_state_dict(osd, pnames, fnames, sizes, opt.exp_avg, opt.exp_avg_sq, steps)
@@ -164,19 +200,26 @@ def load_state(trainer, input_dir: str, rank: int = 0) -> dict:
         opt.t_tail = max([steps.get(n, 0) for n in opt.tail_names])
     g = osd["param_groups"][0]
     opt.lr, opt.betas, opt.eps, opt.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
-    ema_path = os.path.join(input_dir, "custom_checkpoint_0.pkl")
     if opt.ema is not None:
-        if os.path.exists(ema_path):
-            esd = torch.load(ema_path, map_location="cpu")
-            off = {}
-            o = 0
-            for n in fnames:
-                off[n] = o
-                o += trainer.params[n].numel()
-            for n, t in zip(pnames, esd["shadow_params"]):
-                opt.ema[off[n]:off[n] + t.numel()].copy_(t.reshape(-1).to(opt.ema.device, torch.float32))
-        else:
-            opt.ema.copy_(opt.flat)                              # the reference's behaviour: EMA restarts from the weights
+        off, o = {}, 0
+        for n in fnames:
+            off[n] = o
+            o += trainer.params[n].numel()
+        for slot, (_, mod, prefix) in enumerate(mods):
+            mnames = [prefix + n for n, _ in mod.named_parameters() if prefix + n in trainer.params]
+            ema_path = os.path.join(input_dir, f"custom_checkpoint_{slot}.pkl")
+            if os.path.exists(ema_path):
+                esd = torch.load(ema_path, map_location="cpu")
+                # the engine derives the EMA decay from the optimizer's step count: a shadow saved at another count would
+                # silently continue on a different decay schedule
+                if int(esd.get("optimization_step", opt.t)) != opt.t:
+                    raise ValueError(f"{ema_path}: EMA optimization_step {esd['optimization_step']} != optimizer step {opt.t}")
+                for n, t in zip(mnames, esd["shadow_params"]):
+                    opt.ema[off[n]:off[n] + t.numel()].copy_(t.reshape(-1).to(opt.ema.device, torch.float32))
+            else:                                                # the reference's behaviour: EMA restarts from the weights
+                for n in mnames:
+                    k = trainer.params[n].numel()
+                    opt.ema[off[n]:off[n] + k].copy_(opt.flat[off[n]:off[n] + k])
     rs = os.path.join(input_dir, f"random_states_{rank}.pkl")
     if os.path.exists(rs):
         with open(rs, "rb") as f:
@@ -193,7 +236,8 @@ def save_checkpoint(trainer, chckpt_save_path: str, global_step: int, checkpoint
     if is_main_process:
         save_state(trainer, folder, **kw)
         if checkpoints_total_limit is not None:
-            dirs = sorted(os.listdir(chckpt_save_path), key=lambda x: int(x.split("_")[1]))
+            dirs = sorted((d for d in os.listdir(chckpt_save_path) if d.startswith("step_") and d[5:].isdigit()),
+                          key=lambda x: int(x.split("_")[1]))
             for d in dirs[:-checkpoints_total_limit] if len(dirs) > checkpoints_total_limit else []:
                 shutil.rmtree(os.path.join(chckpt_save_path, d))
     return folder
@@ -203,7 +247,8 @@ def latest_checkpoint(chckpt_save_path: str) -> Optional[str]:
     """``resume_from_checkpoint == "latest"`` (utils_training.py:66-77): the ``step_<n>`` folder with the largest n."""
     if not os.path.isdir(chckpt_save_path):
         return None
-    dirs: List[str] = sorted((d for d in os.listdir(chckpt_save_path) if d.startswith("step_")), key=lambda x: int(x.split("_")[1]))
+    dirs: List[str] = sorted((d for d in os.listdir(chckpt_save_path) if d.startswith("step_") and d[5:].isdigit()),
+                             key=lambda x: int(x.split("_")[1]))
     return os.path.join(chckpt_save_path, dirs[-1]) if dirs else None
 
 

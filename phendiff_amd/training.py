@@ -179,6 +179,17 @@ class FlatAdamWEMA:
             launch(off, n, 1, ema_only=1)
 
 
+def broadcast_from_rank0_(flat: torch.Tensor, group=None, src: int = 0) -> torch.Tensor:
+    """What wrapping a model in ``DistributedDataParallel`` does first (``accelerator.prepare``, train.py:311-326): every rank
+    takes rank 0's parameters, so ranks that were initialised or loaded differently cannot diverge silently.  One collective over
+    the flat fp32 buffer (every parameter is a view of it).  No-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return flat
+    dist.broadcast(flat, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return flat
+
+
 def allreduce_mean_(flat_grad: torch.Tensor, group=None, bucket_bytes: int = 256 << 20):
     """Data-parallel gradient averaging over one flat buffer: what DDP's bucketed all-reduce computes for
     ``accelerator.backward`` (utils_training.py:436, train.py:311-326), as a few LARGE asynchronous all-reduces (RCCL over

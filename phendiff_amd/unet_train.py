@@ -618,8 +618,8 @@ class UNetTrainer:
     forward -> loss (+ d loss / d out) -> backward -> [gradient all-reduce] -> clip + AdamW + EMA -> re-pack weights."""
 
     def __init__(self, model: CustomCondUNet2DModel, scheduler, lr: float, *, device=None, use_ema: bool = True,
-                 max_grad_norm: Optional[float] = 1.0, **adamw):
-        from .training import DiffusionLoss, FlatAdamWEMA
+                 max_grad_norm: Optional[float] = 1.0, group=None, **adamw):
+        from .training import DiffusionLoss, FlatAdamWEMA, broadcast_from_rank0_
         self.model, self.scheduler = model, scheduler
         dev = device or model.device
         if torch.device(dev).type != "cuda":
@@ -629,6 +629,10 @@ class UNetTrainer:
         if order[-1][0] == "class_embedding.weight":
             self.opt.set_tail(order[-1][1].numel(), ("class_embedding.weight",))
         self._cond = True
+        # DDP's wrap-time broadcast (train.py:311-326): rank 0's parameters everywhere; the EMA shadow starts from them
+        broadcast_from_rank0_(self.opt.flat, group)
+        if self.opt.ema is not None:
+            self.opt.ema.copy_(self.opt.flat)
         self.params = {n: p.data for n, p in order}
         self.grads = {n: p.grad for n, p in order}
         model.invalidate()
@@ -638,16 +642,48 @@ class UNetTrainer:
         self._tw = None
         self._repack = None
 
+    # kernel-layout weight copies: the model owns the inference set (``model._weights``), the trainer the gradient set and the
+    # re-packer.  ``model.to()`` / ``.cuda()`` / ``load_state_dict()`` / ``pipeline.to()`` drop ``model._weights`` (``invalidate``)
+    # and a later inference forward rebuilds it as a NEW object: everything the trainer cached is bound to the old one.
+    def _make_packed(self):
+        return _PackedWeights(self.model, self.device)
+
+    def _make_train_weights(self):
+        return TrainWeights(self.model, self.device, self.model._weights.tdt)
+
+    def _make_repacker(self):
+        return _Repacker(self.model, self.model._weights, self._tw)
+
+    def _make_plan(self, key):
+        m = self.model
+        return UNetTrainPlan(m, m._weights, self._tw, *key, self.device, self.params, self.grads)
+
+    def _bind_weights(self) -> bool:
+        """Make the trainer's caches refer to the model's CURRENT packed weights; returns True when they had to be rebuilt
+        (plans dropped, gradient-layout weights and re-packer rebuilt)."""
+        m = self.model
+        if m._weights is not None and m._weights is getattr(self, "_bound_w", None):
+            return False
+        for n, p in m.named_parameters():
+            t = self.params.get(n)
+            if t is not None and p.data_ptr() != t.data_ptr():
+                raise L.PhenDiffHipError(f"parameter {n} no longer aliases the trainer's flat buffer (the model was converted or "
+                                         "moved after the trainer was built): build a new trainer")
+        if m._weights is None:
+            m._weights = self._make_packed()
+        self._tw = self._make_train_weights()
+        self._repack = None
+        self._plans = {}
+        self._bucket_key = None
+        self._bound_w = m._weights
+        return True
+
     def plan_for(self, B, H, W):
+        self._bind_weights()
         key = (B, H, W)
         p = self._plans.get(key)
         if p is None:
-            m = self.model
-            if m._weights is None:
-                m._weights = _PackedWeights(m, self.device)
-            if self._tw is None:
-                self._tw = TrainWeights(m, self.device, m._weights.tdt)
-            p = UNetTrainPlan(m, m._weights, self._tw, B, H, W, self.device, self.params, self.grads)
+            p = self._make_plan(key)
             self._plans[key] = p
         return p
 
@@ -738,10 +774,13 @@ class UNetTrainer:
         return load_state(self, input_dir, **kw)
 
     def refresh_weights(self):
-        """Parameters changed in place: rebuild the kernel-layout copies (same device buffers, plans stay valid)."""
+        """Parameters changed in place: rebuild the kernel-layout copies (same device buffers, plans stay valid).  If the model
+        dropped or replaced its packed weights since (``invalidate``), rebind first -- the replacement may have been packed
+        from older parameters, so it is re-packed as well."""
         m = self.model
-        if m._weights is None or self._tw is None:
-            return
+        if m._weights is None and getattr(self, "_bound_w", None) is None:
+            return                                   # nothing packed yet: the first plan packs the current parameters
+        self._bind_weights()
         if self._repack is None:
-            self._repack = _Repacker(m, m._weights, self._tw)
+            self._repack = self._make_repacker()
         self._repack.run(torch.cuda.current_stream(self.device).cuda_stream)

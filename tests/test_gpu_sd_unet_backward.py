@@ -135,3 +135,40 @@ def test_sd_training_step_bf16_reduces_loss_and_overlapped_path():
     names = list(tr.grads)
     assert all(n in plan.grad_ready for n in names)
     assert plan.grad_ready["class_embedding.inner_module.weight"] == len(plan.bwd_ops) - 1
+
+
+def test_sd_save_state_resume_continues_bitwise(tmp_path):
+    """accelerate-layout checkpoint of a StableDiffusion run (unet = pytorch_model.bin, class_embedding = pytorch_model_2.bin, one
+    optimizer over both, utils_misc.py:322-347): the CustomEmbedding's weights, Adam moments, its OWN step count (it is skipped on
+    unconditional steps) and EMA shadow survive, so a resumed run reproduces the uninterrupted one exactly."""
+    import os
+    import phendiff_amd as P
+    B, size = 2, 16
+    sched, clean, noise, ts, labels, noisy, _ = batch(B, size)
+    args = [t.cuda() for t in (noisy, ts, clean, noise, labels)]
+
+    def fresh():
+        _, _, m, e2 = make_pair(TINY, "bf16")
+        return P.SDUNetTrainer(m, e2, sched, lr=3e-4)
+    a = fresh()
+    uncond = [False, True, False]                      # step 2 leaves the embedding without a gradient
+    for u in uncond:
+        a.step(*args, unconditional=u)
+    assert a.opt.t == 3 and a.opt.t_tail == 2
+    folder = str(tmp_path / "step_3")
+    a.save_state(folder)
+    assert sorted(os.listdir(folder)) == ["custom_checkpoint_0.pkl", "custom_checkpoint_1.pkl", "optimizer.bin", "pytorch_model.bin",
+                                          "pytorch_model_2.bin", "random_states_0.pkl", "scheduler.bin"]
+    osd = torch.load(os.path.join(folder, "optimizer.bin"))
+    n_unet = sum(1 for _ in a.model.parameters())
+    assert len(osd["param_groups"][0]["params"]) == n_unet + 1 and float(osd["state"][n_unet]["step"]) == 2.0
+    rest = [float(a.step(*args, unconditional=u)) for u in (False, True, False)]
+    b = fresh()
+    with torch.no_grad():                               # a resumed run starts from different weights: the checkpoint must win
+        b.class_embedding.inner_module.weight.data.add_(1.0)
+    b.load_state(folder)
+    assert b.opt.t == 3 and b.opt.t_tail == 2
+    resumed = [float(b.step(*args, unconditional=u)) for u in (False, True, False)]
+    assert resumed == rest, (rest, resumed)
+    assert torch.equal(b.opt.ema, a.opt.ema) and torch.equal(b.opt.flat, a.opt.flat)
+    assert torch.equal(b.opt.exp_avg, a.opt.exp_avg) and torch.equal(b.opt.exp_avg_sq, a.opt.exp_avg_sq)

@@ -317,3 +317,27 @@ def test_save_state_resume_continues_bitwise(tmp_path):
     resumed = [float(b.step(*args, class_labels=labels.cuda())) for _ in range(3)]
     assert resumed == rest, (first, rest, resumed)
     assert torch.equal(b.opt.ema, a.opt.ema) and torch.equal(b.opt.flat, a.opt.flat)
+
+
+def test_trainer_rebinds_after_the_model_dropped_its_packed_weights():
+    """``model.to()`` / ``pipeline.to()`` / ``load_state_dict()`` drop the model's kernel-layout weights (``invalidate``); an inference
+    forward then packs a NEW set.  The trainer must notice: its plans, gradient-layout weights and re-packer were bound to the old
+    object, and ``refresh_weights`` would otherwise leave inference (pipelines, EMA evaluation) on stale weights."""
+    import phendiff_amd as P
+    sched, clean, noise, ts, labels, noisy, _ = batch(2, 32)
+    args = [t.cuda() for t in (noisy, ts, clean, noise)]
+
+    def run(disturb):
+        _, m = make_pair("super_small", 32, "bf16")
+        tr = P.UNetTrainer(m, sched, lr=3e-3)
+        losses = [float(tr.step(*args, class_labels=labels.cuda()))]
+        if disturb:
+            m.to("cuda")                                        # same device: parameters keep aliasing the flat buffer
+            assert m._weights is None
+            m(noisy.cuda(), ts.cuda(), class_labels=labels.cuda())     # inference packs a new set from the current parameters
+        losses += [float(tr.step(*args, class_labels=labels.cuda())) for _ in range(2)]
+        out = m(noisy.cuda(), ts.cuda(), class_labels=labels.cuda()).sample.clone()
+        return losses, out
+    l0, o0 = run(False)
+    l1, o1 = run(True)
+    assert l0 == l1 and torch.equal(o0, o1)

@@ -83,6 +83,49 @@ def test_dp_gradient_average_equals_large_batch_gradient():
     assert torch.allclose(flat, ref, atol=1e-6)
 
 
+def _bcast_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                      # ranks that were initialised differently ...
+    flat = torch.randn(1000)
+    mine = flat.clone()
+    T.broadcast_from_rank0_(flat)                      # ... all continue from rank 0's parameters (DDP wrap, train.py:311-326)
+    out.put((rank, mine, flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_parameter_broadcast_at_wrap_time():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (a, b)) for r, a, b in (out.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    assert not torch.equal(got[0][0], got[1][0])                       # they did start apart
+    assert torch.equal(got[0][1], got[0][0]) and torch.equal(got[1][1], got[0][0])
+    x = torch.ones(3)
+    assert T.broadcast_from_rank0_(x) is x                             # no process group: no-op
+
+
+def test_randn_tensor_draws_per_sample_from_a_list_of_generators():
+    """diffusers randn_tensor semantics used by scheduler.step(eta > 0) and the pipelines: one (1, ...) draw per generator."""
+    from phendiff_amd.schedulers import randn_tensor
+    gens = [torch.Generator().manual_seed(s) for s in (5, 6, 7)]
+    got = randn_tensor((3, 2, 4, 4), gens, "cpu")
+    want = torch.cat([torch.randn((1, 2, 4, 4), generator=torch.Generator().manual_seed(s)) for s in (5, 6, 7)], 0)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        randn_tensor((2, 2, 4, 4), gens, "cpu")
+    one = randn_tensor((3, 2), torch.Generator().manual_seed(1), "cpu")
+    assert torch.equal(one, torch.randn((3, 2), generator=torch.Generator().manual_seed(1)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("pt", ["epsilon", "sample", "v_prediction"])
 def test_diffusion_loss_and_gradient(pt):
