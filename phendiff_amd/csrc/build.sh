@@ -11,7 +11,7 @@ mkdir -p "$HERE/build"
 pids=()
 SRCS="conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels vae_kernels sd_bwd_kernels linear_gemm"
 for f in $SRCS; do
-  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_stage.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_d64.h" -nt "$HERE/build/$f.o" ] \
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_stage.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_d64.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/pd_conv.h" -nt "$HERE/build/$f.o" ] \
      || [ "$HERE/../../include/phendiff_hip.h" -nt "$HERE/build/$f.o" ]; then
     X=""
     # attention (forward d = 8, backward d = 64): keep MFMA accumulators in VGPRs (the softmax / its derivative work on them;

@@ -17,31 +17,10 @@
 #include <stdio.h>
 #include "pd_common.h"
 #include "pd_stage.h"
+#include "pd_conv.h"
 
 namespace pd {
 
-struct ConvP {
-  int B, Hin, Win, Hout, Wout;
-  int C0, C1, Cout, Cout_pad;
-  int pad, upsample, silu, out_mode, heads;
-  int tiles_x, tiles_y, tiles_x_shift, n_co_tiles, nchunks;
-  unsigned bytes0, bytes1;
-  const void* x0; const void* x1;
-  const float* scale; const float* shift;
-  const void* w;
-  const float* bias;
-  const float* temb; int temb_stride;
-  const void* residual;
-  void* y;
-  float* stats;        // [B][tiles][Cout][2] per-tile channel (sum, sumsq) of the stored output, or null
-  // fused 1x1 "tail": extra K chunks over [t0 | t1] (centre tap only, no GroupNorm transform) appended after the main
-  // chunks -- ResnetBlock2D.conv_shortcut folded into conv2
-  int n_main, n_tail, Ct0, Ct1;
-  unsigned tbytes0, tbytes1;
-  const void* t0; const void* t1;
-  int im2col3;         // source is NCHW fp32 with C0r <= 3..4 real channels: 3x3 taps gathered into 32 virtual channels
-  int C0r;
-};
 
 
 // Ablation switches for diagnostic builds (scripts/ablate_conv.sh); never defined in the shipped library.

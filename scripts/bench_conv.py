@@ -5,6 +5,7 @@ import argparse, ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from phendiff_amd import _lib as L
+if os.environ.get("PD_LIB"): L.LIB_PATH = os.environ["PD_LIB"]
 from phendiff_amd.packing import pack_conv_weight
 ap = argparse.ArgumentParser()
 for k, d in dict(batch=32, hw=256, cin=64, c1=0, cout=64, ks=3, stride=1, up=0, gn=1, res=0, iters=20, mode=0).items():
