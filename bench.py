@@ -30,7 +30,7 @@ import torch  # noqa: E402
 FWD_GFLOP_PER_IMAGE = 376.0
 FWD_ACT_MB_PER_IMAGE_BF16 = 691.8
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md (F16 = BF16 rate)
 
 
 def synth_batch(B, size, seed):
@@ -422,7 +422,8 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="image size (default 256; train: 128)")
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--model", default="super_small")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"],
+                    help="engine mode; fp16 = the reference's --mixed_precision fp16 (inference workloads only: img2img, sd_img2img)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many concurrently replayed "
                     "trajectories (separate HIP streams); measured: no gain (DESIGN.md section 6, scripts/bench_concurrent.py)")
@@ -449,6 +450,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.dtype == "fp16" and args.workload in ("train", "sd_train"):
+        print("bench.py: fp16 is an inference mode of this engine (training runs bf16: fp32 exponent range, no GradScaler)", file=sys.stderr)
+        sys.exit(2)
     if args.workload == "train":
         return main_train(args, P, world, rank, dev, dist)
     if args.workload == "sd_img2img":
@@ -512,7 +516,7 @@ def main():
     }
     # whole-step roofline numbers the north_star asks for (per GPU): algorithmic activation bytes / flops per image
     per_gpu = value / world
-    esz = 1.0 if args.dtype == "bf16" else 2.0
+    esz = 2.0 if args.dtype == "f32" else 1.0
     if args.model == "super_small" and size == 256:
         res["step_rooflines"] = {
             "hbm_frac": round(per_gpu * 2 * S * FWD_ACT_MB_PER_IMAGE_BF16 * esz / 1000.0 / PEAK_HBM_GBS, 4),

@@ -30,7 +30,10 @@ extern "C" {
 #define PD_ABI_VERSION 1
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
-typedef enum { PD_F32 = 0, PD_BF16 = 1 } pd_dtype;
+/* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
+ * PD_F16 (the reference's `--mixed_precision fp16`, args_parser.py:381-390) is an INFERENCE mode: the backward / optimizer entry
+ * points (pd_conv_wgrad, pd_*_bwd, pd_token_wgrad, ...) return PD_ERR_UNSUPPORTED for it. */
+typedef enum { PD_F32 = 0, PD_BF16 = 1, PD_F16 = 2 } pd_dtype;
 typedef enum { PD_PRED_EPSILON = 0, PD_PRED_SAMPLE = 1, PD_PRED_V = 2 } pd_pred_type;
 
 int pd_abi_version(void);

@@ -40,7 +40,7 @@ def library_is_current() -> bool:
         return False
 
 
-PD_F32, PD_BF16 = 0, 1
+PD_F32, PD_BF16, PD_F16 = 0, 1, 2
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
 ABI_VERSION = 1

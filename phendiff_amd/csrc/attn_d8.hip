@@ -9,6 +9,7 @@
 // Workgroup = 4 waves = 128 queries; K and V^T tiles of 256 keys are staged through double-buffered LDS (V transposed on
 // the way, next tile's global loads in flight during the current tile's math, one barrier per tile).
 #include <stdlib.h>
+#include <type_traits>
 #include "pd_common.h"
 
 namespace pd {
@@ -16,7 +17,6 @@ namespace pd {
 constexpr int KT = 256;   // keys per LDS tile (double-buffered: one barrier per tile)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <typename T> struct AttnOps;
 
 // max over each row of 16 lanes with DPP-modified VALU ops (no LDS crossbar traffic): xor 1, xor 2, mirror within 8, mirror within 16
 __device__ __forceinline__ float row16_max(float x) {
@@ -29,41 +29,63 @@ __device__ __forceinline__ float row16_max(float x) {
   return x;
 }
 
-template <> struct AttnOps<bf16_t> {
+// primary template: the 16-bit element types (bf16, fp16); exact fp32 is the specialisation below
+template <typename T> struct AttnOps {
+  // deferred-rescale threshold (log2 domain): p = 2^(s - m) <= 2^THR must stay finite in the storage type (fp16: < 65504)
+  static constexpr float RESCALE_THR = sizeof(T) == 2 && !std::is_same<T, bf16_t>::value ? 14.0f : 16.0f;
   static constexpr int VT_PITCH = (KT + 8) * 2;   // bytes per V^T row (pad -> rows on distinct banks)
   struct QF { s16x8 v; };
-  static __device__ __forceinline__ QF load_q(const bf16_t* q, int h, float scale) {
+  static __device__ __forceinline__ QF load_q(const T* q, int h, float scale) {
     QF f; f.v = (s16x8)(0);
     if (h == 0) {
       s16x8 raw = *(const s16x8*)q;
+      {
+        float x[8];
+        typename Elem<T>::Frag fr; fr.v = raw;
+        Elem<T>::unpack(fr, x);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f.v[j] = (short)f2bf(bf2f((bf16_t)raw[j]) * scale);
+        for (int j = 0; j < 8; ++j) x[j] *= scale;
+        f.v = Elem<T>::pack(x).v;
+      }
     }
     return f;
   }
   static __device__ __forceinline__ float q_norm2(const QF& q) {
-    float t = 0.f;
+    float x[8], t = 0.f;
+    typename Elem<T>::Frag fr; fr.v = q.v;
+    Elem<T>::unpack(fr, x);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float v = bf2f((bf16_t)q.v[j]); t += v * v; }
+    for (int j = 0; j < 8; ++j) t += x[j] * x[j];
     return t;
   }
   static __device__ __forceinline__ float dot(const QF& x, const QF& y) {   // this lane's share of sum_d x_d y_d
-    float t = 0.f;
+    float a[8], b[8], t = 0.f;
+    typename Elem<T>::Frag fa, fb; fa.v = x.v; fb.v = y.v;
+    Elem<T>::unpack(fa, a); Elem<T>::unpack(fb, b);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t += bf2f((bf16_t)x.v[j]) * bf2f((bf16_t)y.v[j]);
+    for (int j = 0; j < 8; ++j) t += a[j] * b[j];
     return t;
   }
   // |k|^2 of a staged key row: four v_dot2c_f32_bf16 on the packed pairs (no unpacking)
-  static __device__ __forceinline__ float k_norm2(const Elem<bf16_t>::Frag& k) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ float k_norm2(const typename Elem<T>::Frag& k) {
     const u32x4 w = __builtin_bit_cast(u32x4, k.v);
     float n2 = 0.f;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const bf2 pr = __builtin_bit_cast(bf2, w[j]); n2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, n2, false); }
+      for (int j = 0; j < 4; ++j) { const bf2 pr = __builtin_bit_cast(bf2, w[j]); n2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, n2, false); }
+    } else {
+      // fp16: plain fp32 arithmetic on the unpacked values (v_dot2_f32_f16 through __builtin_amdgcn_fdot2 returned norms that
+      // under-estimated |k|^2 on gfx950, which made the score bound below invalid: p = 2^(s - m) overflowed fp16)
+      float x[8];
+      Elem<T>::unpack(k, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) n2 += x[j] * x[j];
+    }
     return n2;
   }
   // V row -> column vp of the 8 V^T rows: the bf16 halves are stored as they are (ds_write_b16 / _d16_hi), no conversion
-  static __device__ __forceinline__ void store_vt(unsigned char* vl, int vp, const Elem<bf16_t>::Frag& v) {
+  static __device__ __forceinline__ void store_vt(unsigned char* vl, int vp, const typename Elem<T>::Frag& v) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) *(unsigned short*)(vl + d * VT_PITCH + vp * 2) = (unsigned short)v.v[d];
   }
@@ -78,8 +100,7 @@ template <> struct AttnOps<bf16_t> {
   struct VF { u32x4 v[2]; };
   static __device__ __forceinline__ KF load_k(const unsigned char* ka) { KF f; f.v = *(const s16x8*)ka; return f; }
   static __device__ __forceinline__ f32x16 qk(const KF& a, const QF& q, const f32x16& c) {
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, q.v), c, 0, 0, 0);
+    return Elem<T>::mma16(a.v, q.v, c);
   }
   static __device__ __forceinline__ VF load_v(const unsigned char* vrow, int key0) {
     VF f;
@@ -93,21 +114,21 @@ template <> struct AttnOps<bf16_t> {
   static __device__ __forceinline__ int vlane_off(int h) { return h * 16; }
   // O^T += A . P^T for one 32-key sub-tile; p = exponentiated tile (fp32 accumulator layout)
   static __device__ __forceinline__ f32x16 pv(const VF& a, const f32x16& p, f32x16 o) {
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // B fragment: element j <-> key 16s + 8(j>>2) + 4h + (j&3) == accumulator register 8s + j
       uint32_t bw[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bw[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+      for (int j = 0; j < 4; ++j) bw[j] = Pack16<T>::pack(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
       u32x4 bv = {bw[0], bw[1], bw[2], bw[3]};
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v[s]), __builtin_bit_cast(bf16x8, bv), o, 0, 0, 0);
+      o = Elem<T>::mma16(__builtin_bit_cast(s16x8, a.v[s]), __builtin_bit_cast(s16x8, bv), o);
     }
     return o;
   }
 };
 
 template <> struct AttnOps<float> {
+  static constexpr float RESCALE_THR = 16.0f;
   static constexpr int VT_PITCH = (KT + 4) * 4;
   struct QF { f32x4 v; };
   static __device__ __forceinline__ QF load_q(const float* q, int h, float scale) {
@@ -200,7 +221,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
 #ifdef PD_ABL_THR
   constexpr float RESCALE_THR = 1e30f;   // ablation only: never take the exact-max path after the first tile
 #else
-  constexpr float RESCALE_THR = 16.0f;
+  constexpr float RESCALE_THR = Ops::RESCALE_THR;
 #endif
   int query[QB];
   typename Ops::QF qf[QB];
@@ -596,6 +617,11 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
     if (qbw == 2) hipLaunchKernelGGL((attn_kernel<bf16_t, 2, 4>), grid, dim3(256), 0, st, *a);
     else if (wide) hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, *a);
     else hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 4>), grid, dim3(256), 0, st, *a);
+  } else if (a->dtype == PD_F16) {
+    PD_CHECK(a->lse == nullptr, PD_ERR_UNSUPPORTED, "pd_attn_d8: fp16 is an inference mode (no log-sum-exp output for a backward)");
+    if (qbw == 2) hipLaunchKernelGGL((attn_kernel<half_t, 2, 4>), grid, dim3(256), 0, st, *a);
+    else if (wide) hipLaunchKernelGGL((attn_kernel<half_t, 1, 8>), grid, dim3(512), 0, st, *a);
+    else hipLaunchKernelGGL((attn_kernel<half_t, 1, 4>), grid, dim3(256), 0, st, *a);
   } else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

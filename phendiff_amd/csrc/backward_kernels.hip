@@ -469,6 +469,7 @@ extern "C" int pd_nchw_to_nhwc(const pd_nchw_to_nhwc_args* a, void* stream) {
   const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_nchw_to_nhwc: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

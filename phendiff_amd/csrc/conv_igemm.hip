@@ -419,12 +419,12 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
       if (p.out_mode == PD_OUT_NHWC) {
         if (p.residual) {
           const u32x4 rr = *(const u32x4*)((const T*)p.residual + opix * p.Cout + co);
-          if (E::BYTES == 2) {
+          if constexpr (E::BYTES == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float lo = __uint_as_float(v[j] << 16) + __uint_as_float(rr[j] << 16);
-              const float hi = __uint_as_float(v[j] & 0xffff0000u) + __uint_as_float(rr[j] & 0xffff0000u);
-              v[j] = pack2bf(lo, hi);
+              float lo, hi, rl, rh;
+              Pack16<T>::unpack(v[j], lo, hi); Pack16<T>::unpack(rr[j], rl, rh);
+              v[j] = Pack16<T>::pack(lo + rl, hi + rh);
             }
           } else {
 #pragma unroll
@@ -433,10 +433,11 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
         }
         *(u32x4*)((T*)p.y + opix * p.Cout + co) = v;
         if (p.stats) {
-          if (E::BYTES == 2) {
+          if constexpr (E::BYTES == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+              float lo, hi;
+              Pack16<T>::unpack(v[j], lo, hi);
               ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
             }
           } else {
@@ -556,7 +557,7 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
 extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   using namespace pd;
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_conv: null args");
-  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16, PD_ERR_ARG, "pd_conv: bad dtype %d", a->dtype);
+  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16 || a->dtype == PD_F16, PD_ERR_ARG, "pd_conv: bad dtype %d", a->dtype);
   PD_CHECK(a->B > 0 && a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0, PD_ERR_SHAPE, "pd_conv: bad spatial shape");
   PD_CHECK(a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0, PD_ERR_SHAPE,
            "pd_conv: C0=%d C1=%d must be multiples of 32", a->C0, a->C1);
@@ -613,6 +614,7 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   p.stats = a->stats_out; p.im2col3 = a->im2col3 ? 1 : 0; p.C0r = a->im2col3;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PD_F32) return dispatch_conv<float>(p, a->ksize, a->stride, st);
+  if (a->dtype == PD_F16) return dispatch_conv<half_t>(p, a->ksize, a->stride, st);
   return dispatch_conv<bf16_t>(p, a->ksize, a->stride, st);
 }
 

@@ -284,9 +284,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
         if constexpr (ES == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(v[j] << 16) + __uint_as_float(rr[j] << 16);
-            const float hi = __uint_as_float(v[j] & 0xffff0000u) + __uint_as_float(rr[j] & 0xffff0000u);
-            v[j] = pack2bf(lo, hi);
+            float lo, hi, rl, rh;
+            Pack16<T>::unpack(v[j], lo, hi); Pack16<T>::unpack(rr[j], rl, rh);
+            v[j] = Pack16<T>::pack(lo + rl, hi + rh);
           }
         } else {
 #pragma unroll
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
         if constexpr (ES == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+            float lo, hi;
+            Pack16<T>::unpack(v[j], lo, hi);
             ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
           }
         } else {
@@ -500,7 +501,7 @@ using namespace pd;
 
 extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_linear: null args");
-  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16, PD_ERR_ARG, "pd_linear: bad dtype %d", a->dtype);
+  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16 || a->dtype == PD_F16, PD_ERR_ARG, "pd_linear: bad dtype %d", a->dtype);
   PD_CHECK(a->M > 0 && a->K > 0 && a->K % 32 == 0 && a->N > 0 && a->N % 8 == 0 && a->N_pad >= a->N && a->N_pad % 32 == 0, PD_ERR_SHAPE,
            "pd_linear: M=%lld K=%d (multiple of 32) N=%d (multiple of 8) N_pad=%d (multiple of 32)", a->M, a->K, a->N, a->N_pad);
   PD_CHECK(a->x_stride >= a->K && a->x_stride % 8 == 0, PD_ERR_SHAPE, "pd_linear: x_stride must cover K and be a multiple of 8");
@@ -531,6 +532,10 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a->stats_out == nullptr || (a->rows_per_sample > 0 && a->rows_per_sample % 128 == 0 && a->M % a->rows_per_sample == 0 && a->qkv_heads == 0),
            PD_ERR_SHAPE, "pd_linear: stats_out needs rows_per_sample %% 128 == 0 and dense output");
   p.stats = a->stats_out;
+  if (a->dtype == PD_F16) {
+    if (glu) return launch_linear<half_t, 2, true>(p, (hipStream_t)stream);
+    return narrow ? launch_linear<half_t, 1>(p, (hipStream_t)stream) : launch_linear<half_t, 2>(p, (hipStream_t)stream);
+  }
   if (glu) return a->dtype == PD_F32 ? launch_linear<float, 2, true>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2, true>(p, (hipStream_t)stream);
   if (a->dtype == PD_F32) return narrow ? launch_linear<float, 1>(p, (hipStream_t)stream) : launch_linear<float, 2>(p, (hipStream_t)stream);
   return narrow ? launch_linear<bf16_t, 1>(p, (hipStream_t)stream) : launch_linear<bf16_t, 2>(p, (hipStream_t)stream);

@@ -11,6 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;  // raw bf16 bits
+struct half_t { unsigned short bits; };   // raw IEEE fp16 bits: a distinct type, so templates can tell the two 16-bit formats apart
 
 void set_error(const char* fmt, ...);
 
@@ -43,6 +44,28 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   bf2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
+
+// ---- two 16-bit storage values in one dword <-> two fp32 (round-to-nearest-even), for either 16-bit element type
+template <typename T> struct Pack16;
+template <> struct Pack16<bf16_t> {
+  static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) {
+    lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) { return pack2bf(lo, hi); }
+};
+template <> struct Pack16<half_t> {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) {
+    const h2 v = __builtin_bit_cast(h2, w);
+    lo = (float)v.x; hi = (float)v.y;
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    const h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+};
+__device__ __forceinline__ float h2f(half_t v) { return (float)__builtin_bit_cast(_Float16, v.bits); }
+__device__ __forceinline__ half_t f2h(float f) { half_t h; h.bits = __builtin_bit_cast(unsigned short, (_Float16)f); return h; }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 // throughput form: v_exp_f32 + v_rcp_f32 (1 ulp each), 5 VALU ops instead of ~15 for the IEEE division
@@ -108,12 +131,42 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ Frag zero() { Frag f; f.v = (s16x8)(0); return f; }
   static __device__ __forceinline__ Frag load(const void* p) { Frag f; f.v = *(const s16x8*)p; return f; }
   static __device__ __forceinline__ void store(void* p, const Frag& f) { *(s16x8*)p = f.v; }
-  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return mma16(a.v, b.v, c); }
+  static __device__ __forceinline__ f32x16 mma16(s16x8 a, s16x8 b, f32x16 c) {      // D += A[32 x 16] . B[16 x 32] on raw 16-bit lanes
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
   static __device__ __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+};
+
+template <> struct Elem<half_t> {
+  static constexpr int BYTES = 2;
+  struct Frag { s16x8 v; };        // 8 fp16
+  static __device__ __forceinline__ void unpack(const Frag& f, float (&o)[8]) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 h = __builtin_bit_cast(h8, f.v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+  }
+  static __device__ __forceinline__ Frag pack(const float (&o)[8]) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (_Float16)o[i];
+    Frag f; f.v = __builtin_bit_cast(s16x8, h);
+    return f;
+  }
+  static __device__ __forceinline__ Frag zero() { Frag f; f.v = (s16x8)(0); return f; }
+  static __device__ __forceinline__ Frag load(const void* p) { Frag f; f.v = *(const s16x8*)p; return f; }
+  static __device__ __forceinline__ void store(void* p, const Frag& f) { *(s16x8*)p = f.v; }
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return mma16(a.v, b.v, c); }
+  static __device__ __forceinline__ f32x16 mma16(s16x8 a, s16x8 b, f32x16 c) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float to_f(half_t v) { return h2f(v); }
+  static __device__ __forceinline__ half_t from_f(float v) { return f2h(v); }
 };
 
 // store 4 consecutive output elements
@@ -123,6 +176,14 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
   uint2 v; v.x = pack2bf(a, b); v.y = pack2bf(c, d);
   *(uint2*)p = v;
+}
+__device__ __forceinline__ void store4(half_t* p, float a, float b, float c, float d) {
+  uint2 v; v.x = Pack16<half_t>::pack(a, b); v.y = Pack16<half_t>::pack(c, d);
+  *(uint2*)p = v;
+}
+__device__ __forceinline__ void load4(const half_t* p, float (&o)[4]) {
+  const uint2 v = *(const uint2*)p;
+  Pack16<half_t>::unpack(v.x, o[0], o[1]); Pack16<half_t>::unpack(v.y, o[2], o[3]);
 }
 __device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
   f32x4 v = *(const f32x4*)p; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];

@@ -7,10 +7,9 @@
 
 namespace pd {
 
-template <typename T> struct D64;
-template <> struct D64<bf16_t> {
+template <typename T> struct D64 {          // primary: 16-bit element types (bf16, fp16); fp32 below
   static constexpr int KP = 128 + 16, VP = 128 + 64;      // row pitches: conflict-free ds_read_b128 rows / 4-row transposed blocks
-  typedef Elem<bf16_t>::Frag Frag;
+  typedef typename Elem<T>::Frag Frag;
   static __device__ __forceinline__ int vt_lane_off(int lane) {      // block row q <-> key 4h + q, columns 16*cg + 4*pp of a 32-d row tile
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     return (4 * (g >> 1) + q) * VP + (16 * (g & 1) + 4 * pp) * 2;
@@ -27,7 +26,7 @@ template <> struct D64<bf16_t> {
   static __device__ __forceinline__ Frag pack_p(const f32x16& p, int s) {
     uint32_t w[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+    for (int j = 0; j < 4; ++j) w[j] = Pack16<T>::pack(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
     Frag f; f.v = __builtin_bit_cast(s16x8, (u32x4){w[0], w[1], w[2], w[3]});
     return f;
   }

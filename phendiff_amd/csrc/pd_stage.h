@@ -10,8 +10,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB_OFF = 0xC0000000u;   // > any tensor we accept (< 2 GiB): buffer loads return 0
 
-template <typename T> struct Stage;
-template <> struct Stage<bf16_t> {
+// primary template: the 16-bit element types (bf16, fp16); fp32 is the specialisation below
+template <typename T> struct Stage {
   struct R { u32x4 v; };
   static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
     R r; r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); return r;
@@ -24,10 +24,12 @@ template <> struct Stage<bf16_t> {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x2 x;                                     // packed fp32 math: one VALU slot per channel pair
-        x.x = __uint_as_float(in.v[j] << 16); x.y = __uint_as_float(in.v[j] & 0xffff0000u);
+        float xl, xh;
+        Pack16<T>::unpack(in.v[j], xl, xh);
+        x.x = xl; x.y = xh;
         if (affine) x = x * (f32x2){sc[2 * j], sc[2 * j + 1]} + (f32x2){sh[2 * j], sh[2 * j + 1]};
         if (silu) x = silu_fast2(x);
-        o[j] = pack2bf(x.x, x.y);
+        o[j] = Pack16<T>::pack(x.x, x.y);
       }
       if (!valid) o = (u32x4)(0u);
     }
@@ -61,20 +63,19 @@ template <> struct Stage<float> {
 // ---- MFMA operand fragments whose 8 elements are 8 consecutive ROWS of an LDS image at one column (a transposed read):
 // bf16 via ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3; lane i receives column i),
 // fp32 (validation) via eight ds_read_b32.  Used by the weight-gradient GEMM (K = pixels) and the d = 64 attention (V^T).
-template <typename T> struct FragLd;
-template <> struct FragLd<bf16_t> {
+template <typename T> struct FragLd {       // primary: 16-bit element types
   // lane base address: pixel 8h+q, channels 16*cg + 4*pp (see file header); second read 4 pixels further
   static __device__ __forceinline__ unsigned lane_off(int lane, int pitch) {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     return (unsigned)((8 * (g >> 1) + q) * pitch + (16 * (g & 1) + 4 * pp) * 2);
   }
   template <int PITCH>
-  static __device__ __forceinline__ Elem<bf16_t>::Frag load(const unsigned char* base) {
+  static __device__ __forceinline__ typename Elem<T>::Frag load(const unsigned char* base) {
     typedef short v4s __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4s* lp;
     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base));
     const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + 4 * PITCH));
-    Elem<bf16_t>::Frag f;
+    typename Elem<T>::Frag f;
     f.v = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return f;
   }

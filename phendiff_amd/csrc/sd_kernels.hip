@@ -298,6 +298,11 @@ extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
     const bool wide = !qb1_only && a->Nkv >= 512 && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
     return wide ? launch_attn_d64<bf16_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<bf16_t, 1>(a, (hipStream_t)stream);
   }
+  if (a->dtype == PD_F16) {
+    PD_CHECK(a->lse == nullptr, PD_ERR_UNSUPPORTED, "pd_attn_d64: fp16 is an inference mode (no log-sum-exp output for a backward)");
+    const bool wide = a->Nkv >= 512 && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
+    return wide ? launch_attn_d64<half_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<half_t, 1>(a, (hipStream_t)stream);
+  }
   set_error("pd_attn_d64: bad dtype");
   return PD_ERR_ARG;
 }
@@ -308,6 +313,7 @@ extern "C" int pd_layernorm(const pd_layernorm_args* a, void* stream) {
   const unsigned grid = (unsigned)((a->rows + 3) / 4);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_layernorm: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -319,6 +325,7 @@ extern "C" int pd_geglu(const pd_geglu_args* a, void* stream) {
   const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(geglu_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(geglu_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(geglu_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_geglu: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

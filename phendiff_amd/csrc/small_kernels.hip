@@ -434,6 +434,7 @@ extern "C" int pd_conv_in(const pd_conv_in_args* a, void* stream) {
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(conv_in_kernel<float>, dim3(grid), dim3(256), sm, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(conv_in_kernel<bf16_t>, dim3(grid), dim3(256), sm, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(conv_in_kernel<half_t>, dim3(grid), dim3(256), sm, (hipStream_t)stream, *a);
   else { set_error("pd_conv_in: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -449,6 +450,7 @@ extern "C" int pd_gn_stats(const pd_gn_stats_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PD_F32) hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(gn_partial_kernel<half_t>, dim3(a->B * a->splits), dim3(256), 0, st, *a);
   else { set_error("pd_gn_stats: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->B), dim3(256), 0, st, *a);

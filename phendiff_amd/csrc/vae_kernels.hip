@@ -17,9 +17,8 @@
 
 namespace pd {
 
-template <typename T, int PITCH> struct WideX;
-template <int PITCH> struct WideX<bf16_t, PITCH> {
-  typedef Elem<bf16_t>::Frag Frag;
+template <typename T, int PITCH> struct WideX {      // primary: 16-bit element types (bf16, fp16); fp32 below
+  typedef typename Elem<T>::Frag Frag;
   static __device__ __forceinline__ int vt_lane_off(int lane) {      // block row q <-> key 4h + q, columns 16*cg + 4*pp of a 32-d row tile
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     return (4 * (g >> 1) + q) * PITCH + (16 * (g & 1) + 4 * pp) * 2;
@@ -36,7 +35,7 @@ template <int PITCH> struct WideX<bf16_t, PITCH> {
   static __device__ __forceinline__ Frag pack_p(const f32x16& p, int s) {
     uint32_t w[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+    for (int j = 0; j < 4; ++j) w[j] = Pack16<T>::pack(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
     Frag f; f.v = __builtin_bit_cast(s16x8, (u32x4){w[0], w[1], w[2], w[3]});
     return f;
   }
@@ -256,6 +255,7 @@ extern "C" int pd_gn_apply(const pd_gn_apply_args* a, void* stream) {
   const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_gn_apply: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -280,6 +280,7 @@ extern "C" int pd_attn_wide(const pd_attn_wide_args* a, void* stream) {
   PD_CHECK((long long)((a->Nq + 31) / 32) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_wide: grid too large");
   if (a->dtype == PD_F32) return dispatch_attn_wide<float>(a, (hipStream_t)stream);
   if (a->dtype == PD_BF16) return dispatch_attn_wide<bf16_t>(a, (hipStream_t)stream);
+  if (a->dtype == PD_F16) return dispatch_attn_wide<half_t>(a, (hipStream_t)stream);
   set_error("pd_attn_wide: bad dtype");
   return PD_ERR_ARG;
 }

@@ -451,6 +451,7 @@ extern "C" int pd_pack_weight(const pd_pack_weight_args* a, void* stream) {
   const size_t lds = (size_t)32 * (32 * a->ksize * a->ksize + 1) * sizeof(float);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(pack_weight_kernel<half_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);
   else { set_error("pd_pack_weight: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

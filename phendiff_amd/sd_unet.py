@@ -127,7 +127,7 @@ class SDUNet2DConditionModel(nn.Module):
         if c.cross_attention_dim % 32 or c.in_channels > 32:
             raise NotImplementedError("cross_attention_dim must be a multiple of 32; in_channels <= 32")
         if compute_dtype not in _DT:
-            raise ValueError("compute_dtype must be 'bf16' or 'f32'")
+            raise ValueError("compute_dtype must be 'bf16', 'fp16' or 'f32'")
         self.compute_dtype = compute_dtype
         g, eps, tdim = c.norm_num_groups, c.norm_eps, boc[0] * 4
         self.time_embed_dim = tdim
@@ -331,7 +331,7 @@ class SDUNetPlan(UNetPlan):
 
     # ---- emitters for the Transformer2DModel additions ---------------------------------------------------------------
     def _esz(self):
-        return 2 if self.code == L.PD_BF16 else 4
+        return 4 if self.code == L.PD_F32 else 2
 
     def _layernorm(self, x, ln):
         gamma, beta, eps = ln

@@ -59,6 +59,11 @@ class SDTrainWeights:
     """Input-gradient weights in ``pd_conv``'s packed layout (W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx])."""
 
     def __init__(self, m: SDUNet2DConditionModel, device, tdt):
+        if tdt == torch.float16:
+            # the reference trains fp16 under a GradScaler (accelerate, utils_training.py:436); the engine's reduced-precision
+            # TRAINING mode is bf16 (fp32 exponent range: no loss scaling), fp16 is built for inference plans only
+            raise NotImplementedError("compute_dtype='fp16' is an inference mode: build the model with 'bf16' (or 'f32') for the "
+                                      "backward / gradient-guidance plans")
         self.tdt, self.device = tdt, device
         pk = lambda w, cp=None: pack_conv_weight(dgrad_weight(w.detach().to(device=device, dtype=torch.float32)), tdt, cp)
         lin = lambda w: w.detach()[:, :, None, None]

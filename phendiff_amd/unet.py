@@ -21,7 +21,9 @@ import torch.nn as nn
 from . import _lib as L
 from .packing import pack_conv_weight
 
-_DT = {"f32": (L.PD_F32, torch.float32), "bf16": (L.PD_BF16, torch.bfloat16)}
+# compute_dtype -> (pd_dtype, storage dtype).  "fp16": the reference's `--mixed_precision fp16` (args_parser.py:381-390; img2img_comparison.py:57):
+# fp16 storage + MFMA, fp32 accumulate / statistics / softmax -- an inference mode here (training keeps bf16's fp32 range, no GradScaler)
+_DT = {"f32": (L.PD_F32, torch.float32), "bf16": (L.PD_BF16, torch.bfloat16), "fp16": (L.PD_F16, torch.float16)}
 
 
 class UNet2DOutput(SimpleNamespace):
@@ -148,7 +150,7 @@ class CustomCondUNet2DModel(nn.Module):
         if any(ch % 32 for ch in boc):
             raise NotImplementedError("block_out_channels must be multiples of 32 on the HIP path")
         if compute_dtype not in _DT:
-            raise ValueError("compute_dtype must be 'bf16' or 'f32'")
+            raise ValueError("compute_dtype must be 'bf16', 'fp16' or 'f32'")
         self.compute_dtype = compute_dtype
         self.sample_size = c.sample_size
         tdim = boc[0] * 4
@@ -297,7 +299,7 @@ class CustomCondUNet2DModel(nn.Module):
         """Largest batch one launch plan can hold: its widest materialised activation at full resolution (the last upsampler's
         output, block_out_channels[1] channels; channel concats are never materialised; the fp32 NCHW input / output) must stay
         below 2 GiB."""
-        esz = 2 if self.compute_dtype == "bf16" else 4
+        esz = 4 if self.compute_dtype == "f32" else 2
         boc = self.config.block_out_channels
         per_image = H * W * max(max(boc[0], boc[min(1, len(boc) - 1)]) * esz, 4 * max(self.config.in_channels, self.config.out_channels))
         return max(1, (2 ** 31 - 2 ** 20) // per_image)
@@ -516,7 +518,7 @@ class UNetPlan:
                        tail_C1=(tail[1].shape[3] if (tail and tail[1] is not None) else 0))
         if temb_off is not None:
             self._temb_ptr_fields.append((a, temb_off))
-        esz = 2 if self.code == L.PD_BF16 else 4
+        esz = 4 if self.code == L.PD_F32 else 2
         cin = c0 + c1
         flops = 2.0 * B * hout * wout * cout * cin * ksize * ksize
         tail_c = (tail[0].shape[3] + (tail[1].shape[3] if tail[1] is not None else 0)) if tail else 0
@@ -538,7 +540,7 @@ class UNetPlan:
         y = self._act(h, w, c0 + c1)
         a = L.GnApplyArgs(dtype=self.code, B=B, HW=h * w, C0=c0, C1=c1, silu=silu, x0=x0.data_ptr(), x1=L.ptr(x1),
                           scale=gn[0].data_ptr(), shift=gn[1].data_ptr(), y=y.data_ptr())
-        self.ops.append(_Op(self.lib.pd_gn_apply, a, "gn_apply", 0.0, 2.0 * y.numel() * (2 if self.code == L.PD_BF16 else 4)))
+        self.ops.append(_Op(self.lib.pd_gn_apply, a, "gn_apply", 0.0, 2.0 * y.numel() * (4 if self.code == L.PD_F32 else 2)))
         return y
 
     def _linear(self, x, wpk, bias, cout, residual=None, y=None, gn=None, stats=False, what="linear", glu=False):
@@ -549,7 +551,7 @@ class UNetPlan:
         B, h, w, K = x.shape
         if y is None:
             y = self._act(h, w, cout // 2 if glu else cout)
-        M, esz = B * h * w, (2 if self.code == L.PD_BF16 else 4)
+        M, esz = B * h * w, (4 if self.code == L.PD_F32 else 2)
         st = None
         if stats:
             T = (h * w) // 128
@@ -607,7 +609,7 @@ class UNetPlan:
             a = L.LinearArgs(dtype=self.code, M=M, K=ch, N=3 * ch, N_pad=3 * ch, x=x.data_ptr(), x_stride=ch, w_packed=e.wqkv.data_ptr(),
                              bias=e.bqkv.data_ptr(), residual=None, y=qkv.data_ptr(), scale=gn[0].data_ptr(), shift=gn[1].data_ptr(),
                              rows_per_sample=h * w, qkv_heads=e.heads)
-            esz_ = 2 if self.code == L.PD_BF16 else 4
+            esz_ = 4 if self.code == L.PD_F32 else 2
             self.ops.append(_Op(self.lib.pd_linear, a, "conv1x1", 2.0 * M * ch * 3 * ch, (M * ch * 4 + 3 * ch * ch) * esz_))
         else:
             qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, out_mode=L.PD_OUT_QKV_HEADS,
@@ -616,7 +618,7 @@ class UNetPlan:
         lse = self._f32(B, e.heads, h * w) if self.train else None
         a = L.AttnArgs(dtype=self.code, B=B, heads=e.heads, N=h * w, q=qkv[0].data_ptr(), k=qkv[1].data_ptr(),
                        v=qkv[2].data_ptr(), out=o.data_ptr(), lse=L.ptr(lse))
-        esz = 2 if self.code == L.PD_BF16 else 4
+        esz = 4 if self.code == L.PD_F32 else 2
         N = h * w
         self.ops.append(_Op(self.lib.pd_attn_d8, a, "attn_d8", 4.0 * B * e.heads * N * N * 8, 4.0 * B * N * ch * esz))
         if self._linear_ok(o):
@@ -641,7 +643,7 @@ class UNetPlan:
                                        im2col3=c.in_channels, src_shape=(B, H, W, 32))
         self.ops[-1].what = "conv_in"
         self.ops[-1].flops = 2.0 * B * H * W * boc[0] * c.in_channels * 9
-        self.ops[-1].bytes = B * H * W * (c.in_channels * 4 + boc[0] * (2 if self.code == L.PD_BF16 else 4))
+        self.ops[-1].bytes = B * H * W * (c.in_channels * 4 + boc[0] * (4 if self.code == L.PD_F32 else 2))
         self.tape.append(SimpleNamespace(kind="conv_in", out=a0))
         h = a0
         skips = [a0]

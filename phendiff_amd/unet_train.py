@@ -71,6 +71,11 @@ class TrainWeights:
     """Input-gradient ("dgrad") weights in ``pd_conv``'s packed layout: W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx]."""
 
     def __init__(self, m: CustomCondUNet2DModel, device, tdt):
+        if tdt == torch.float16:
+            # the reference trains fp16 under a GradScaler (accelerate, utils_training.py:436); the engine's reduced-precision
+            # TRAINING mode is bf16 (fp32 exponent range: no loss scaling), fp16 is built for inference plans only
+            raise NotImplementedError("compute_dtype='fp16' is an inference mode: build the model with 'bf16' (or 'f32') for the "
+                                      "backward / gradient-guidance plans")
         self.tdt, self.device = tdt, device
         pk = lambda w: pack_conv_weight(dgrad_weight(w.detach().to(device=device, dtype=torch.float32)), tdt)
         lin = lambda w: w.detach()[:, :, None, None]
@@ -209,7 +214,7 @@ class UNetTrainPlan(UNetPlan):
         return self.grads[name]
 
     def _esz(self):
-        return 2 if self.code == L.PD_BF16 else 4
+        return 4 if self.code == L.PD_F32 else 2
 
     def _bias_grad(self, dy, total, valid=None, per_sample=None, per_stride=None):
         if not self.param_grads:

@@ -163,7 +163,7 @@ class AutoencoderKL(nn.Module):
         if c.in_channels > 3 or c.latent_channels > 16:
             raise NotImplementedError("in_channels <= 3 (im2col conv_in), latent_channels <= 16")
         if compute_dtype not in _DT:
-            raise ValueError("compute_dtype must be 'bf16' or 'f32'")
+            raise ValueError("compute_dtype must be 'bf16', 'fp16' or 'f32'")
         self.compute_dtype = compute_dtype
         g = c.norm_num_groups
         self.encoder = _Encoder(c.in_channels, c.latent_channels, boc, c.layers_per_block, g)
@@ -235,7 +235,7 @@ class AutoencoderKL(nn.Module):
         """pd_conv addresses a source tensor with 32-bit byte offsets: the widest full-resolution activation of a chunk
         must stay below 2 GiB.  Encoder: block_out_channels[0] channels at H x W; decoder: the last up block's first ResNet
         reads block_out_channels[1] channels at full resolution (the previous stage's upsampled output)."""
-        esz = 2 if self.compute_dtype == "bf16" else 4
+        esz = 4 if self.compute_dtype == "f32" else 2
         boc = self.config.block_out_channels
         ch = boc[0] if kind == "enc" else max(boc[0], boc[min(1, len(boc) - 1)])
         return max(1, ((1 << 31) - 1) // (H * W * max(ch, 64) * esz))
@@ -352,7 +352,7 @@ class _VaePlan(UNetPlan):
         with ``residual_connection=True``, as UNetMidBlock2D builds it for the VAE)."""
         e = self.w.attns[name]
         B, h, w, ch = x.shape
-        N, esz = h * w, (2 if self.code == L.PD_BF16 else 4)
+        N, esz = h * w, (4 if self.code == L.PD_F32 else 2)
         d = ch // e.heads
         gn = self._gn(x, None, e.g, e.be, e.eps)
         qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, stats=False)

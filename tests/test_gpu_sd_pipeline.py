@@ -29,7 +29,8 @@ def make_pipe(mode):
     return ref, pipe
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+# measured maxima (profiles/r2_parity_errors.json): f32 3.1e-6, bf16 1.5e-2, fp16 1.8e-3
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2), ("fp16", 4e-3)])
 def test_sd_ddib_matches_golden(mode, tol):
     import phendiff_amd as P
     d = np.load(os.path.join(GOLDEN, "sd_tiny_32_s4.npz"))
@@ -43,10 +44,12 @@ def test_sd_ddib_matches_golden(mode, tol):
     assert rel(inv, torch.from_numpy(d["inverted"])) < tol
     out = P.ddib(pipe, x, labels, 1 - labels, 4, generator=torch.Generator().manual_seed(11))
     assert isinstance(out, np.ndarray) and out.shape == (4, 32, 32, 3)
-    assert np.linalg.norm(out - d["ddib_out"]) / np.linalg.norm(d["ddib_out"]) < tol
+    # the decoded images carry the VAE decoder's own 16-bit error on top of the latent trajectory's (measured: f32 7.6e-6, bf16 3.2e-2, fp16 4.0e-3)
+    assert rel(out, d["ddib_out"]) < {"f32": 2e-5, "bf16": 6e-2, "fp16": 8e-3}[mode]
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+# measured maxima (profiles/r2_parity_errors.json): f32 3.1e-6, bf16 1.5e-2, fp16 1.8e-3
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2), ("fp16", 4e-3)])
 def test_sd_cfg_forward_start_matches_golden(mode, tol):
     import phendiff_amd as P
     d = np.load(os.path.join(GOLDEN, "sd_tiny_32_s4.npz"))

@@ -35,7 +35,8 @@ def make_pair(cfg, mode, seed=0):
     return r, emb, m.to("cuda:0"), e2.to("cuda:0")
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 5e-5), ("bf16", 3e-2)])
+# measured maxima (profiles/r2_parity_errors.json): f32 2.8e-6, bf16 1.21e-2, fp16 1.48e-3
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 2.5e-2), ("fp16", 3e-3)])
 @pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32), (WIDE, 16)])
 def test_sd_unet_forward(mode, tol, cfg, size):
     import phendiff_amd as P

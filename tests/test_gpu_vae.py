@@ -12,7 +12,7 @@ from test_gpu_kernels import DT, bf16_round, env, rel, stream  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [(2, 1, 512, 256), (1, 1, 512, 1000), (2, 2, 128, 77), (1, 1, 256, 16), (1, 3, 256, 130), (1, 1, 512, 4096)])
 def test_attention_wide(env, mode, cfg):
     L, lib, _, dev = env
@@ -78,7 +78,8 @@ def make_pair(cfg, mode, seed=0):
     return r, m.to("cuda:0")
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 5e-5), ("bf16", 3e-2)])
+# measured maxima (profiles/r2_parity_errors.json): f32 7.1e-6, bf16 2.9e-2, fp16 3.5e-3
+@pytest.mark.parametrize("mode,tol", [("f32", 3e-5), ("bf16", 5e-2), ("fp16", 8e-3)])
 @pytest.mark.parametrize("name", list(CFGS))
 def test_vae_encode_decode(mode, tol, name):
     cfg, (H, W) = CFGS[name]
