@@ -18,6 +18,15 @@ UNET_CONFIGS = {
         mid_block_scale_factor=1, norm_eps=1e-05, norm_num_groups=32, num_class_embeds=2, out_channels=3,
         resnet_time_scale_shift="default", sample_size=128, time_embedding_type="positional",
         up_block_types=("AttnUpBlock2D", "UpBlock2D", "UpBlock2D")),
+    # models_configs/denoiser/orig_google_ddpm_model_denoiser.json (UNet2DModel of google/ddpm-celebahq-256) -- 113 673 219
+    # parameters: six levels, ONE attention head over all 512 channels (attention_head_dim null, cond_unet_2d.py:176-178,192-196),
+    # eps 1e-6, sin-before-cos embedding with freq_shift 1, pad-0 (asymmetric) downsamplers, no class table
+    "orig_google_ddpm_model_denoiser": dict(
+        act_fn="silu", attention_head_dim=None, block_out_channels=(128, 128, 256, 256, 512, 512), center_input_sample=False,
+        down_block_types=("DownBlock2D", "DownBlock2D", "DownBlock2D", "DownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
+        downsample_padding=0, flip_sin_to_cos=False, freq_shift=1, in_channels=3, layers_per_block=2, mid_block_scale_factor=1,
+        norm_eps=1e-06, norm_num_groups=32, out_channels=3, sample_size=256, time_embedding_type="positional",
+        up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D", "UpBlock2D", "UpBlock2D", "UpBlock2D")),
 }
 
 SCHEDULER_CONFIGS = {

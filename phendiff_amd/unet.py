@@ -598,7 +598,10 @@ class UNetPlan:
         e = self.w.attns[name]
         B, h, w, ch = x.shape
         if ch != e.heads * 8:
-            raise NotImplementedError(f"pd_attn_d8 implements head_dim 8 only (got {ch // e.heads})")
+            # attention_head_dim = None (one head over all channels: orig_google_ddpm_model_denoiser.json) or 64
+            if self.train:
+                raise NotImplementedError(f"the backward plan implements head_dim 8 only (got {ch // e.heads})")
+            return self._attn_nhwc(name, x)
         gn = self._gn(x, None, e.g, e.be, e.eps)
         if (h * w) % 128 == 0 and ch % 64 == 0:
             # fused q/k/v projection through the GEMM kernel (GroupNorm apply while staging, head-major output): a 1x1 pd_conv
@@ -626,6 +629,34 @@ class UNetPlan:
         else:
             out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
         self.tape.append(SimpleNamespace(kind="attn", name=name, x=x, qkv=qkv, o=o, out=out, lse=lse, gn=gn, e=e))
+        return out
+
+    def _attn_nhwc(self, name, x):
+        """GroupNorm -> fused q|k|v Linear (NHWC, no head-major copy) -> attention with head_dim 64 (``pd_attn_d64``) or one wide
+        head of 128 / 256 / 512 channels (``pd_attn_wide``) -> out Linear + residual: diffusers ``Attention`` with
+        ``residual_connection=True`` for every head_dim other than 8 (the VAE mid block; ``attention_head_dim = None``)."""
+        e = self.w.attns[name]
+        B, h, w, ch = x.shape
+        N, esz = h * w, (4 if self.code == L.PD_F32 else 2)
+        d = ch // e.heads
+        if d != 64 and d not in (128, 256, 512):
+            raise NotImplementedError(f"attention head_dim {d}: implemented are 8, 64 and one wide head of 128 / 256 / 512 channels")
+        gn = self._gn(x, None, e.g, e.be, e.eps)
+        qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, stats=False)
+        o = self._act(h, w, ch)
+        p = qkv.data_ptr()
+        if d == 64:
+            a = L.AttnD64Args(dtype=self.code, B=B, heads=e.heads, Nq=N, Nkv=N, q=p, q_stride=3 * ch, k=p + ch * esz,
+                              v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch)
+            fn, what = self.lib.pd_attn_d64, "attn_d64"
+        else:
+            a = L.AttnWideArgs(dtype=self.code, B=B, heads=e.heads, D=d, Nq=N, Nkv=N, scale=float(d) ** -0.5, q=p, q_stride=3 * ch,
+                               k=p + ch * esz, v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch)
+            fn, what = self.lib.pd_attn_wide, "attn_wide"
+        self.ops.append(_Op(fn, a, what, 4.0 * B * N * N * ch, 4.0 * B * N * ch * esz))
+        if self._linear_ok(o):
+            return self._linear(o, e.wo, e.bo, ch, residual=x, stats=True, what="conv1x1")
+        out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
         return out
 
     def _build(self):
@@ -691,6 +722,8 @@ class UNetPlan:
             out = torch.empty((rows, self.w.proj_dim), dtype=torch.float32, device=self.device)
         a = self.temb_args
         a.rows = rows
+        if self.w.class_table is None:      # no class conditioning: labels / class_emb are ignored (cond_unet_2d.py:297-309)
+            labels = class_emb = None
         a.timesteps, a.labels, a.class_emb = ts.data_ptr(), L.ptr(labels), L.ptr(class_emb)
         a.emb, a.proj = None, out.data_ptr()
         L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")

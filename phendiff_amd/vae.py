@@ -347,34 +347,9 @@ class _VaePlan(UNetPlan):
         self._cur = (None, None)
         self._build()
 
-    def _mid_attention(self, name, x):
-        """GroupNorm -> fused q|k|v Linear -> one head over all channels -> out Linear + residual (diffusers ``Attention``
-        with ``residual_connection=True``, as UNetMidBlock2D builds it for the VAE)."""
-        e = self.w.attns[name]
-        B, h, w, ch = x.shape
-        N, esz = h * w, (4 if self.code == L.PD_F32 else 2)
-        d = ch // e.heads
-        gn = self._gn(x, None, e.g, e.be, e.eps)
-        qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, stats=False)
-        o = self._act(h, w, ch)
-        p = qkv.data_ptr()
-        if d == 64:
-            a = L.AttnD64Args(dtype=self.code, B=B, heads=e.heads, Nq=N, Nkv=N, q=p, q_stride=3 * ch, k=p + ch * esz,
-                              v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch)
-            fn, what = self.lib.pd_attn_d64, "attn_d64"
-        else:
-            a = L.AttnWideArgs(dtype=self.code, B=B, heads=e.heads, D=d, Nq=N, Nkv=N, scale=float(d) ** -0.5, q=p, q_stride=3 * ch,
-                               k=p + ch * esz, v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch)
-            fn, what = self.lib.pd_attn_wide, "attn_wide"
-        self.ops.append(_Op(fn, a, what, 4.0 * B * N * N * ch, 4.0 * B * N * ch * esz))
-        if self._linear_ok(o):
-            return self._linear(o, e.wo, e.bo, ch, residual=x, stats=True, what="conv1x1")
-        out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
-        return out
-
     def _mid(self, prefix, h):
         h = self._resnet(f"{prefix}.mid_block.resnets.0", h)
-        h = self._mid_attention(f"{prefix}.mid_block.attentions.0", h)
+        h = self._attn_nhwc(f"{prefix}.mid_block.attentions.0", h)
         return self._resnet(f"{prefix}.mid_block.resnets.1", h)
 
     def run(self, x_ptr, out_ptr, stream):

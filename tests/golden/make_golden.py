@@ -90,9 +90,28 @@ def main():
     print("wrote golden fixtures to", HERE)
 
 
+def main_google():
+    """models_configs/denoiser/orig_google_ddpm_model_denoiser.json (113.7 M parameters: one 512-wide attention head, six
+    levels, eps 1e-6, freq_shift 1, pad-0 downsamplers, no class table): one UNet evaluation and a DDIB round trip (S = 2) at
+    64x64.  The model is unconditional: the class labels pass through `_inversion` / the pipeline unused (cond_unet_2d.py:297)."""
+    torch.manual_seed(0)
+    unet = CondUNet2DRef(**dict(UNET_CONFIGS["orig_google_ddpm"], sample_size=64)).eval()
+    pipe = ConditionalDDIMPipelineRef(unet, DDIMSchedulerRef(**SCHED_3K))
+    x, labels = synth_batch(2, 64)
+    with torch.no_grad():
+        eps = unet(x, 1500).sample
+    out, inverted = ddib_ref(pipe, x, labels, 1 - labels, 2)
+    np.savez_compressed(os.path.join(HERE, "ddib_google_ddpm_64_s2.npz"), images=x.numpy(), labels=labels.numpy(),
+                        inverted=inverted.numpy(), out_images=out, unet_out_t1500=eps.numpy())
+    print("wrote ddib_google_ddpm_64_s2.npz")
+
+
 if __name__ == "__main__":
     if "--sd" in sys.argv:
         main_sd()
+    elif "--google" in sys.argv:
+        main_google()
     else:
         main()
         main_sd()
+        main_google()

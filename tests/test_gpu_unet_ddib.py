@@ -70,6 +70,36 @@ def test_unet_forward_small_denoiser_f32():
     assert rel(got, ref) < 5e-5
 
 
+# models_configs/denoiser/orig_google_ddpm_model_denoiser.json on the HIP path: attention_head_dim = None (ONE head over 512
+# channels -> pd_attn_wide), six levels, eps 1e-6, freq_shift 1 / sin before cos, pad-0 downsamplers, no class table
+# (cond_unet_2d.py:132-153,176-197).  Same 2x-measured bounds as super_small.
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 2.5e-2), ("fp16", 3e-3)])
+def test_unet_forward_orig_google_ddpm(mode, tol):
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef, UNET_CONFIGS as REF_CONFIGS
+    torch.manual_seed(0)
+    r = CondUNet2DRef(**dict(REF_CONFIGS["orig_google_ddpm"], sample_size=64)).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype=mode, **dict(P.UNET_CONFIGS["orig_google_ddpm_model_denoiser"], sample_size=64))
+    assert sum(p.numel() for p in m.parameters()) == 113_673_219
+    m.load_state_dict(r.state_dict())
+    m = m.to("cuda:0")
+    x, _ = synth_batch(2, 64)
+    for t in (2999, 37):
+        with torch.no_grad():
+            ref = r(x, t).sample
+        got = m(x.cuda(), t).sample
+        assert got.shape == ref.shape and rel(got, ref) < tol, (mode, t, rel(got, ref))
+    if mode == "f32":           # committed oracle vectors (tests/golden/make_golden.py --google): forward + DDIB round trip, S = 2
+        d = np.load(os.path.join(GOLDEN, "ddib_google_ddpm_64_s2.npz"))
+        xg, labels = torch.from_numpy(d["images"]), torch.from_numpy(d["labels"])
+        assert rel(m(xg.cuda(), 1500).sample, d["unet_out_t1500"]) < tol
+        pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
+        graph = P.DDIBGraph(pipe, batch_size=2, num_inference_steps=2, height=64, width=64)
+        out = graph.run(xg.cuda(), labels.cuda(), (1 - labels).cuda())
+        torch.cuda.synchronize()
+        assert rel(out.inverted, d["inverted"]) < 2e-5 and rel(out.images, d["out_images"]) < 2e-5
+
+
 def test_unet_rejects_bad_calls():
     import phendiff_amd as P
     _, m = make_pair("super_small", 32, "f32")
