@@ -146,6 +146,90 @@ def cpu_baseline_train(model_name, size, state_dict, seconds_budget=30.0):
                       f"{size}x{size}, fp32, {threads} threads"}
 
 
+def _cpu_threads():
+    import torch.nn.functional as F
+    probe_x, probe_w = torch.randn(1, 64, 128, 128), torch.randn(64, 64, 3, 3)
+    best = (float("inf"), 1)
+    for nthr in sorted({c for c in (8, 16, 32, 64, usable_cores()) if c <= usable_cores()} or {1}):
+        torch.set_num_threads(nthr)
+        F.conv2d(probe_x, probe_w, padding=1)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            F.conv2d(probe_x, probe_w, padding=1)
+        dt = time.perf_counter() - t0
+        if dt < best[0] * 0.95:
+            best = (dt, nthr)
+    torch.set_num_threads(best[1])
+    return best[1]
+
+
+def cpu_baseline_sd_img2img(P, size, S):
+    """The oracle's latent-diffusion transfer on this box's host cores, bounded: ONE image through the full-size stack (SD-2.1
+    UNet 865.9 M + SD VAE, random init) -- one VAE encode, one inversion step, one denoising step, one VAE decode -- extrapolated
+    to S + S steps (per-step cost is step-independent)."""
+    from oracle import AutoencoderKLRef, CustomEmbeddingRef, DDIMSchedulerRef, SD21_UNET_CONFIG, SD_VAE_CONFIG, UNet2DConditionRef
+    from oracle import class_emb_to_encoder_hidden_states as ehs_ref
+    cores = _cpu_threads()
+    torch.manual_seed(0)
+    with torch.no_grad():
+        unet = UNet2DConditionRef(**SD21_UNET_CONFIG).eval()
+        vae = AutoencoderKLRef(**SD_VAE_CONFIG).eval()
+        emb = CustomEmbeddingRef(2, 1024)
+        x, labels = synth_batch(1, size, 1234)
+        t0 = time.perf_counter()
+        lat = vae.encode(x).latent_dist.sample() * 0.18215
+        t_enc = time.perf_counter() - t0
+        ehs = ehs_ref(emb(labels))
+        sched = DDIMSchedulerRef(**P.SCHEDULER_CONFIGS["SD_orig_config"])
+        sched.set_timesteps(S)
+        ts = sched.timesteps
+        steps = []
+        for k in range(2):
+            t0 = time.perf_counter()
+            out = unet(lat, ts[k], ehs).sample
+            lat = sched.step(out, ts[k], lat).prev_sample
+            steps.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        vae.decode(lat / 0.18215)
+        t_dec = time.perf_counter() - t0
+    t_step = min(steps)
+    total = t_enc + t_dec + 2 * S * t_step
+    return {"value": round(1.0 / total, 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU fp32 torch, {cores} threads), ONE {size}x{size} image through the full-size stack: VAE encode {t_enc:.2f} s, "
+                      f"one SD-UNet + scheduler step {t_step:.2f} s (best of 2), VAE decode {t_dec:.2f} s; extrapolated to {S}+{S} steps = {total:.0f} s"}
+
+
+def cpu_baseline_sd_train(P, size):
+    """One optimisation step of the oracle SD-2.1 UNet (+ CustomEmbedding) under torch.autograd + clip + AdamW at batch 1."""
+    from oracle import CustomEmbeddingRef, SD21_UNET_CONFIG, UNet2DConditionRef
+    from oracle import class_emb_to_encoder_hidden_states as ehs_ref
+    cores = _cpu_threads()
+    torch.manual_seed(0)
+    unet, emb = UNet2DConditionRef(**SD21_UNET_CONFIG), CustomEmbeddingRef(2, 1024)
+    params = list(unet.parameters()) + list(emb.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-5, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    g = torch.Generator().manual_seed(3)
+    lat, target = torch.randn(1, 4, size, size, generator=g), torch.randn(1, 4, size, size, generator=g)
+    labels, ts = torch.zeros(1, dtype=torch.long), torch.tensor([500])
+
+    def step():
+        out = unet(lat, ts, ehs_ref(emb(labels))).sample
+        loss = torch.nn.functional.mse_loss(out, target)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+    t0 = time.perf_counter()
+    step()
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    step()
+    dt = min(first, time.perf_counter() - t0)
+    return {"value": round(1.0 / dt, 5), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"2 optimisation steps (best taken) of the CPU oracle SD-2.1 UNet + CustomEmbedding (torch.autograd + clip_grad_norm_ + "
+                      f"AdamW) at batch 1, {size}x{size} latents, fp32, {cores} threads: {dt:.1f} s per step"}
+
+
 def main_train(args, P, world, rank, dev, dist):
     """configs[1]: DDIM training of cond_unet_2d at 128x128, bf16, data-parallel.  One step = sampling (noise, timesteps,
     add_noise) + forward + loss + backward + bucketed gradient all-reduce (N > 1) + clip/AdamW/EMA + weight re-pack."""
@@ -313,9 +397,22 @@ def main_sd_img2img(args, P, world, rank, dev, dist):
     x, labels = synth_batch(B, size, 1234 + rank)
     x, labels = x.to(dev), labels.to(dev)
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    P.ddib(pipe, x, labels, 1 - labels, 1, generator=gen)          # builds every launch plan
-    elapsed, out, ranks = _timed_steps(args, dev, dist, lambda: P.ddib(pipe, x, labels, 1 - labels, S, generator=gen), B * args.steps)
-    assert out.shape == (B, size, size, 3)
+    host_out = torch.empty((B, size, size, 3), dtype=torch.float32, pin_memory=True)
+    if args.no_graph:
+        def step():
+            host_out.copy_(torch.from_numpy(P.ddib(pipe, x, labels, 1 - labels, S, generator=gen)))
+            return host_out
+        P.ddib(pipe, x, labels, 1 - labels, 1, generator=gen)          # builds every launch plan
+    else:
+        # the whole transfer (VAE encode -> 2*S SD-UNet steps -> VAE decode, ~36 000 launches) as ONE hipGraph, bit-identical to
+        # the eager loop (tests/test_gpu_sd_pipeline.py); output lands in pinned host memory inside the timed region
+        graph = P.SDDDIBGraph(pipe, batch_size=B, num_inference_steps=S, height=size, width=size)
+
+        def step():
+            host_out.copy_(graph.run(x, labels, 1 - labels, generator=gen).images, non_blocking=True)
+            return host_out
+    elapsed, out, ranks = _timed_steps(args, dev, dist, step, B * args.steps)
+    assert out.shape == (B, size, size, 3) and torch.isfinite(out).all()
     value = world * B * args.steps / elapsed
     res = {"metric": "SD img2img images/sec (VAE encode + 50-step DDIM invert + 50-step denoise + VAE decode, 512x512)",
            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -324,12 +421,16 @@ def main_sd_img2img(args, P, world, rank, dev, dist):
            "config": {"workload": f"configs[4]: custom_pipeline_stable_diffusion_img2img DDIB, {size}x{size} images ({size // 8}x{size // 8} "
                                   f"latents), {S}+{S} DDIM steps, SD-2.1 UNet (865.9 M) + SD VAE (83.7 M) + CustomEmbedding, random init, "
                                   f"SD_orig_config / v_prediction, {B} images/GPU/step sharded over {world} GPU(s), no collectives",
-                      "batch_per_gpu": B, "global_batch": B * world, "inference_steps": S, "image_size": size}}
+                      "batch_per_gpu": B, "global_batch": B * world, "inference_steps": S, "image_size": size,
+                      "hipgraph": not args.no_graph}}
     if rank == 0 and not args.no_roofline:
         plan = next(p for k, p in unet._plans.items() if k[0] == B)
         prof = plan._profile_ops(plan.ops, torch.cuda.current_stream(dev).cuda_stream, reps=2)
         res["roofline"] = _plan_roofline(prof, args.dtype, "HIP events between consecutive launches of one SD-UNet forward (same plan "
                                                            "and buffers as the timed region; 2*S of them per step)")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_sd_img2img(P, size, S)
+        res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -377,6 +478,9 @@ def main_sd_train(args, P, world, rank, dev, dist):
                 prof[f"{title}.{k}"] = d
         torch.cuda.synchronize(dev)
         res["roofline"] = _plan_roofline(prof, args.dtype, "HIP events between consecutive launches of one forward + backward (same plan and buffers)")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_sd_train(P, size)
+        res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -428,6 +532,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many concurrently replayed "
                     "trajectories (separate HIP streams); measured: no gain (DESIGN.md section 6, scripts/bench_concurrent.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", dest="sweep", action="store_false", help="img2img: skip the B = 16 / 64 side measurements")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -491,16 +596,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    # the timed region runs from the device-resident input batch to the HOST output array (the reference's one D2H
+    # of B*H*W*3 floats per batch, pipeline_conditionial_ddim.py:349-350): pinned buffer, asynchronous copy behind each batch
+    host_out = torch.empty((B, size, size, 3), dtype=torch.float32, pin_memory=True)
+
+    def one_batch():
         multi.run(x, labels, target)
+        for i, r_ in enumerate(runners):
+            host_out[i * Bs:(i + 1) * Bs].copy_(r_.images, non_blocking=True)
+
+    for _ in range(args.warmup):
+        one_batch()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        multi.run(x, labels, target)
+        one_batch()
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed, ranks = reduce_elapsed(dist, elapsed, dev, B * args.steps)
-    assert torch.isfinite(runner.images).all()
+    assert torch.isfinite(host_out).all() and float(host_out.min()) >= 0.0 and float(host_out.max()) <= 1.0
 
     images = world * B * args.steps
     value = images / elapsed
@@ -523,6 +637,22 @@ def main():
             "mfma_frac": round(per_gpu * 2 * S * FWD_GFLOP_PER_IMAGE / 1000.0 / PEAK_MFMA_TFLOPS[args.dtype], 4),
             "note": "algorithmic bytes (691.8 MB bf16 act./forward/image) and FLOPs (376 GF/forward/image) x images/s/GPU "
                     "over 8 TB/s HBM and the dense MFMA peak"}
+    # The bar that replaces the north-star's ">= 40 % of the HBM roofline" (not reachable by design: the step is not HBM-bound at
+    # 16-bit storage and a third of it is the exp-bound d = 8 attention): the SERIAL floor of one UNet forward = each launch at
+    # the roofline that binds its kind, one after the other (nothing overlaps inside one trajectory) --
+    #   conv / linear FLOPs / dense MFMA peak  +  attention exponentials / v_exp_f32 issue peak  +  bandwidth-only bytes / 8 TB/s
+    fl = sum(op.flops for op in runner.plan.ops if op.what != "attn_d8")
+    nexp = sum(op.flops for op in runner.plan.ops if op.what == "attn_d8") / 32.0        # 4*B*heads*N^2*8 FLOPs -> B*heads*N^2 exps
+    bw = sum(op.bytes for op in runner.plan.ops if op.flops == 0)
+    floor_ms = 1e3 * (fl / (PEAK_MFMA_TFLOPS[args.dtype] * 1e12) + nexp / 19.66e12 + bw / (PEAK_HBM_GBS * 1e9))
+    fwd_ms = 1e3 * elapsed / args.steps / (2 * S) / args.streams
+    res.setdefault("step_rooflines", {}).update({
+        "serial_floor_ms": round(floor_ms, 3), "forward_ms": round(fwd_ms, 3), "serial_floor_frac": round(floor_ms / fwd_ms, 4),
+        "serial_floor_parts_ms": {"mfma": round(1e3 * fl / (PEAK_MFMA_TFLOPS[args.dtype] * 1e12), 3),
+                                  "attention_exp": round(1e3 * nexp / 19.66e12, 3), "hbm_only": round(1e3 * bw / (PEAK_HBM_GBS * 1e9), 3)},
+        "serial_floor_note": "per UNet forward at this batch: (conv + linear FLOPs) / dense MFMA peak + attention exponentials / "
+                             "19.66 T/s (v_exp_f32 issue at 2.4 GHz) + bytes of the FLOP-free launches / 8 TB/s; forward_ms = "
+                             "ms_per_step / (2 x inference_steps)"})
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel, timed live with HIP events on the launch stream (same inputs, same buffers)
@@ -543,29 +673,33 @@ def main():
             ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS[args.dtype], "TFLOP/s"
         else:
             ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r1_hbm_traffic.json: rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections); counters cannot be read from inside the process
-        traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
-            key = {"attn_d8": "attn_kernel<unsigned short", "conv3x3": "conv_kernel<unsigned short, 3, 1, 8, 32, true, false",
-                   "conv1x1": "conv_kernel<unsigned short, 1, 1, 8, 32, true, false"}.get(kind)
-            for name, v in tj["kernels"].items():
-                if key and key in name and B == 32 and args.dtype == "bf16" and size == 256:
-                    traffic, traffic_src = round(v["hbm_bytes_per_launch"]), "profiles/r1_hbm_traffic.json"
-        except (OSError, ValueError, KeyError):
-            pass
-        # matrix / vector pipe occupancy of the same kernel from the committed PMC pass (profiles/r1_mfma_busy.json:
-        # SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE with rocprofv3's MfmaUtil / VALUBusy formulas)
-        pipes = {}
-        try:
-            bj = json.load(open(os.path.join(ROOT, "profiles", "r1_mfma_busy.json")))
-            for name, v in bj["kernels"].items():
-                if key and key in name and B == 32 and args.dtype == "bf16" and size == 256:
-                    pipes = {"mfma_util_percent": v["MfmaUtil_percent"], "valu_busy_percent": v["VALUBusy_percent"],
-                             "pipes_source": "profiles/r1_mfma_busy.json"}
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM bytes / pipe occupancy per launch of that kernel come from committed rocprofv3 --pmc passes (counters cannot be read
+        # from inside the process): profiles/r2_hbm_traffic.json, r2_mfma_busy.json, written by scripts/collect_profiles.sh keyed
+        # by plan kind.  They are only quoted for the workload they were measured on AND while the library sources are the ones
+        # they were measured with (sources_sha256); otherwise traffic stays null and the line says why.
+        traffic, traffic_src, pipes, pmc_note = None, None, {}, None
+        from phendiff_amd._lib import source_hash
+        same_workload = B == 32 and args.dtype == "bf16" and size == 256 and args.model == "super_small"
+        for fname, field in (("r2_hbm_traffic.json", "traffic"), ("r2_mfma_busy.json", "pipes")):
+            try:
+                j = json.load(open(os.path.join(ROOT, "profiles", fname)))
+            except (OSError, ValueError):
+                pmc_note = f"profiles/{fname} missing"
+                continue
+            if j.get("sources_sha256") != source_hash():
+                pmc_note = f"profiles/{fname} was measured on other kernel sources (re-run scripts/collect_profiles.sh head)"
+                continue
+            v = j.get("by_kind", {}).get(kind)
+            if not same_workload or v is None:
+                pmc_note = pmc_note or f"profiles/{fname} has no entry for {kind} at this workload"
+                continue
+            if field == "traffic":
+                traffic, traffic_src = round(v["hbm_bytes_per_launch"]), f"profiles/{fname}"
+            else:
+                pipes = {"mfma_util_percent": v["MfmaUtil_percent"], "valu_busy_percent": v["VALUBusy_percent"],
+                         "pipes_source": f"profiles/{fname}"}
+        if pmc_note:
+            pipes["pmc_note"] = pmc_note
         extra = {}
         if kind == "attn_d8":
             # the d=8 attention is bound by the VALU/transcendental issue pipe, not by MFMA or HBM: report
@@ -588,6 +722,25 @@ def main():
                            "per_kernel_ms_per_forward": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
                            "per_kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["ms"] > 0},
                            "per_kernel_gbs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items() if v["ms"] > 0}}
+    if rank == 0 and world == 1 and args.sweep and not args.no_graph:
+        # batch sweep (one warm-up + one timed batch each; the headline batch is the timed region above)
+        sweep = {str(B): round(per_gpu, 3)}
+        for Bx in (16, 64):
+            if Bx == B or Bx > unet.max_batch(size, size):
+                continue
+            del_runner = P.DDIBGraph(pipe, batch_size=Bx, num_inference_steps=S)
+            xs, ls = synth_batch(Bx, size, 77)
+            xs, ls = xs.to(dev), ls.to(dev)
+            del_runner.run(xs, ls, 1 - ls)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            del_runner.run(xs, ls, 1 - ls)
+            torch.cuda.synchronize(dev)
+            sweep[str(Bx)] = round(Bx / (time.perf_counter() - t0), 3)
+            del del_runner
+        res["config"]["sweep"] = {"images_per_s_by_batch": sweep,
+                                  "note": f"B = 128 is not a single plan: tensors are addressed with 32-bit byte offsets, one launch plan holds "
+                                          f"<= {unet.max_batch(size, size)} images at {size}x{size} (larger batches run as several plans)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.model, size, S, state_dict)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -10,7 +10,7 @@ from .unet import CustomCondUNet2DModel, UNet2DOutput  # noqa: F401
 from .schedulers import DDIMScheduler, DDIMInverseScheduler  # noqa: F401
 from .pipeline import ConditionalDDIMPipeline, ImagePipelineOutput  # noqa: F401
 from .img2img import (inversion, ddib, inverted_regeneration, classifier_free_guidance_forward_start, DDIBGraph,  # noqa: F401
-                      CFGForwardStartGraph, shard_batches, swap_binary_labels, custom_guided_generation,
+                      CFGForwardStartGraph, SDDDIBGraph, shard_batches, swap_binary_labels, custom_guided_generation,
                       linear_interp_custom_guidance_inverted_start, encode_to_latents, decode_to_images, LDM_preprocess, tensor_to_PIL)
 from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401
 from . import training  # noqa: F401

@@ -15,6 +15,7 @@
 namespace pd {
 
 constexpr int KT = 256;   // keys per LDS tile (double-buffered: one barrier per tile)
+static_assert(KT == 256, "knmax is read as one f32x4 (KT / 64 slices)");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
   constexpr int VBYTES = 9 * Ops::VT_PITCH;          // rows 0..7 = V^T, row 8 = 1.0
   __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW + 16];   // + one all-zero 16-B slot
   __shared__ __attribute__((aligned(16))) unsigned char vlds[2][VBYTES];
-  __shared__ float knmax[2][KT / 32];                // max |k| over each 32-key sub-tile (Cauchy-Schwarz score bound)
+  __shared__ __attribute__((aligned(16))) float knmax[2][KT / 64];   // max |k| over each 64-key slice (one staging wave): Cauchy-Schwarz score bound
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
     E::store(klds[b2] + st * KROW, stk);
     float n2 = row16_max(Ops::k_norm2(stk));
     n2 = fmaxf(n2, __shfl_xor(n2, 16));
-    if ((st & 31) == 0) knmax[b2][st >> 5] = sqrtf(n2) * 1.00002f;
+    n2 = fmaxf(n2, __shfl_xor(n2, 32));
+    if ((st & 63) == 0) knmax[b2][st >> 6] = sqrtf(n2) * 1.00002f;
     Ops::store_vt(vlds[b2], Ops::vpos(st), stv);
   };
 
@@ -277,9 +279,8 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
     const unsigned char* vrow = vlds[cur] + vrow_off;
     // one bound for the whole 256-key tile: if even |q| * max|k| cannot push a score above m + THR, the 8 sub-tiles
     // run the check-free body (QK^T MFMA -> 16 x v_exp -> 8 x cvt_pk -> 2 PV MFMAs, nothing else)
-    float kn8 = knmax[cur][0];
-#pragma unroll
-    for (int i = 1; i < KT / 32; ++i) kn8 = fmaxf(kn8, knmax[cur][i]);
+    const f32x4 kn4 = *(const f32x4*)knmax[cur];             // KT / 64 = 4 slices: one 16-byte LDS read
+    const float kn8 = fmaxf(fmaxf(kn4[0], kn4[1]), fmaxf(kn4[2], kn4[3]));
     const bool full_tile = k0 + KT <= N;
     bool need = false;
 #pragma unroll
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
               if (key >= N) s[i] = -INFINITY;
             }
           }
-          const float bound = qn[j] * knmax[cur][sub] - m[j];   // upper bound of every s' of this lane in this sub-tile
+          const float bound = qn[j] * knmax[cur][sub >> 1] - m[j];   // upper bound of every s' of this lane in this sub-tile
           if (__builtin_amdgcn_ballot_w64(first[j] || bound > RESCALE_THR)) {   // wave-uniform
             float tmax = s[0];
 #pragma unroll
@@ -611,6 +612,19 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
   PD_CHECK((long long)((a->N + qpb - 1) / qpb) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8: grid too large");
   dim3 grid(((a->N + qpb - 1) / qpb) * a->heads * a->B);
   hipStream_t st = (hipStream_t)stream;
+  // diagnostic (scripts/bench_concurrent.py): extra dynamic LDS per workgroup caps the kernel's occupancy, so that another
+  // stream's MFMA-bound convolutions can co-reside on every CU beside this VALU-bound kernel
+  static const int lds_pad = getenv("PD_ATTN_LDS_PAD") ? atoi(getenv("PD_ATTN_LDS_PAD")) : 0;
+  if (lds_pad > 0 && a->dtype == PD_BF16 && wide) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)attn_kernel<bf16_t, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), lds_pad, st, *a);
+    PD_LAUNCH_CHECK();
+    return PD_OK;
+  }
   if (a->dtype == PD_F32) {
     hipLaunchKernelGGL((attn_kernel<float, 1, 4>), dim3(((a->N + 127) / 128) * a->heads * a->B), dim3(256), 0, st, *a);
   } else if (a->dtype == PD_BF16) {

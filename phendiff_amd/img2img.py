@@ -365,6 +365,127 @@ class DDIBGraph:
             pass
 
 
+class SDDDIBGraph:
+    """One hipGraph for the latent-diffusion DDIB transfer -- ``_ddib`` with a ``CustomStableDiffusionImg2ImgPipeline``
+    (utils_Img2Img.py:566-612; custom_pipeline_stable_diffusion_img2img.py:667-711): VAE encode -> posterior sample (x
+    ``scaling_factor``) -> S inversion steps under the original class -> class swap -> S denoising steps -> VAE decode ->
+    ``(x / 2 + .5).clamp(0, 1)`` NHWC.  ~360 launches x 2S steps are captured once and replayed per batch; the result is the eager
+    ``ddib(pipe, ...)`` bit for bit.  ``run(images, orig_labels, target_labels, generator=None, noise=None)``: the posterior noise is an
+    input (drawn from ``generator`` outside the graph, like ``latent_dist.sample(generator)``)."""
+
+    def __init__(self, pipe, batch_size: int, num_inference_steps: int, height: int, width: int, variant: str = "0.18.2",
+                 device=None, use_graph: bool = True):
+        from .schedulers import DDIMInverseScheduler as Inv
+        self.pipe = pipe
+        unet, vae = pipe.unet, pipe.vae
+        self.device = dev = torch.device(device) if device is not None else unet.device
+        self.B, self.S, self.H, self.W = B, S, H, W = batch_size, num_inference_steps, height, width
+        self.lib = L.lib()
+        sf = 1 << (len(vae.config.block_out_channels) - 1)
+        h, w = H // sf, W // sf
+        lc = vae.config.latent_channels
+        if B > vae._max_batch(H, W, "enc") or B > vae._max_batch(H, W, "dec"):
+            raise ValueError(f"batch_size {B} exceeds what one VAE launch plan holds at {H}x{W}; replay several runners instead")
+        self.enc, self.dec = vae._plan("enc", B, H, W, dev), vae._plan("dec", B, h, w, dev)
+        self.plan = unet.plan_for(B, h, w, 77, dev)
+        self.inv = Inv.from_config(pipe.scheduler.config, variant=variant)
+        self.inv.set_timesteps(S)
+        fwd = pipe.scheduler
+        fwd.set_timesteps(S, device=dev)
+        gen_ts, _ = pipe.get_timesteps(S, 1.0, dev)                     # strength = 1: all S steps (custom_pipeline...:375-382)
+        self.inv_ts, self.gen_ts = [int(t) for t in self.inv.timesteps], [int(t) for t in gen_ts]
+        nsteps = len(self.inv_ts) + len(self.gen_ts)
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self.x, self.moments, self.noise = f32(B, 3, H, W), f32(B, 2 * lc, h, w), f32(B, lc, h, w)
+        self.latents, self.model_out, self.inverted, self.dec_in = f32(B, lc, h, w), f32(B, lc, h, w), f32(B, lc, h, w), f32(B, lc, h, w)
+        self.decoded, self.images = f32(B, 3, H, W), f32(B, H, W, 3)
+        D = unet.config.cross_attention_dim
+        self.ehs_orig, self.ehs_target = f32(B, 77, D), f32(B, 77, D)
+        self.ts_rows = torch.tensor(self.inv_ts + self.gen_ts, dtype=torch.float32).repeat_interleave(B).to(dev)
+        self.scaling = float(vae.config.scaling_factor)
+        self.step_args = []
+        for sched, ts in ((self.inv, self.inv_ts), (fwd, self.gen_ts)):
+            c = sched.config
+            for t in ts:
+                sa, sb, sap, dirc, _ = sched.step_coefficients(t, 0.0)
+                self.step_args.append(L.DdimStepArgs(
+                    numel=self.latents.numel(), per_sample=self.latents[0].numel(), pred_type=L.PD_PRED[c.prediction_type],
+                    clip=int(bool(c.clip_sample)), clip_range=float(c.clip_sample_range), use_clipped_model_output=0,
+                    sqrt_a=sa, sqrt_b=sb, sqrt_ap=sap, dir_coef=dirc, sample=self.latents.data_ptr(),
+                    model_out=self.model_out.data_ptr(), uncond_out=None, w=None, w_per_sample=0, guidance_cfg=0,
+                    prev_sample=self.latents.data_ptr(), pred_x0=None))
+        self.sample_args = L.LatentSampleArgs(B=B, C=lc, HW=h * w, scale=self.scaling, moments=self.moments.data_ptr(),
+                                              noise=self.noise.data_ptr(), out=self.latents.data_ptr())
+        self.post_args = L.PostprocArgs(B=B, C=3, H=H, W=W, x=self.decoded.data_ptr(), out_f32=self.images.data_ptr(), out_u8=None)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph = C.c_void_p(None)
+        self.use_graph = use_graph
+        if use_graph:
+            torch.cuda.synchronize(dev)
+            L.check(self.lib.pd_graph_begin(self.stream.cuda_stream), "pd_graph_begin")
+            try:
+                with torch.cuda.stream(self.stream):
+                    self._enqueue(self.stream.cuda_stream)
+            finally:
+                rc = self.lib.pd_graph_end(self.stream.cuda_stream, C.byref(self.graph))
+            L.check(rc, "pd_graph_end")
+
+    def _enqueue(self, st):
+        """The trajectory as launches on the current stream (``st``); the three torch calls are plain device-to-device kernels
+        between pre-allocated buffers (capturable)."""
+        lib, plan, B = self.lib, self.plan, self.B
+        self.enc.run(self.x.data_ptr(), self.moments.data_ptr(), st)
+        L.check(lib.pd_latent_sample(C.byref(self.sample_args), st), "pd_latent_sample")
+        n_inv = len(self.inv_ts)
+        ta = plan.temb_args
+        for i, a in enumerate(self.step_args):
+            if i == 0 or i == n_inv:       # class conditioning of the phase: (B, 77, D) fp32 -> the plan's compute-dtype buffer
+                plan.ehs.view(B, 77, -1).copy_(self.ehs_orig if i == 0 else self.ehs_target)
+            ta.rows = B
+            ta.timesteps, ta.labels, ta.class_emb = self.ts_rows.data_ptr() + 4 * i * B, None, None
+            ta.emb, ta.proj = plan.temb_emb.data_ptr(), plan.temb_table.data_ptr()
+            L.check(lib.pd_temb(C.byref(ta), st), "pd_temb")
+            plan.run(self.latents.data_ptr(), plan.temb_table.data_ptr(), self.model_out.data_ptr(), st)
+            L.check(lib.pd_ddim_step(C.byref(a), st), "pd_ddim_step")
+            if i == n_inv - 1:
+                self.inverted.copy_(self.latents)
+        torch.div(self.latents, self.scaling, out=self.dec_in)        # vae.decode(latents / scaling_factor), custom_pipeline...:709
+        self.dec.run(self.dec_in.data_ptr(), self.decoded.data_ptr(), st)
+        L.check(lib.pd_postproc(C.byref(self.post_args), st), "pd_postproc")
+
+    @torch.no_grad()
+    def run(self, clean_images, orig_class_labels, target_class_labels, generator=None, noise=None):
+        from .schedulers import randn_tensor
+        from .sd_pipeline import hack_class_embedding
+        if clean_images.shape != self.x.shape:
+            raise ValueError(f"expected images of shape {tuple(self.x.shape)}, got {tuple(clean_images.shape)}")
+        pipe, dev = self.pipe, self.device
+        cur = torch.cuda.current_stream(dev)
+        if noise is None:
+            noise = randn_tensor(tuple(self.noise.shape), generator, dev)
+        eo = hack_class_embedding(pipe._encode_class(class_labels=orig_class_labels, device=dev, do_classifier_free_guidance=False))
+        et = hack_class_embedding(pipe._encode_class(class_labels=target_class_labels, device=dev, do_classifier_free_guidance=False))
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(clean_images, non_blocking=True)
+            self.noise.copy_(noise, non_blocking=True)
+            self.ehs_orig.copy_(eo)
+            self.ehs_target.copy_(et)
+            if self.use_graph:
+                L.check(self.lib.pd_graph_launch(self.graph, self.stream.cuda_stream), "pd_graph_launch")
+            else:
+                self._enqueue(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return self
+
+    def __del__(self):
+        try:
+            if self.graph:
+                self.lib.pd_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
 class CFGForwardStartGraph:
     """hipGraph form of the CFG forward-start transfer (utils_Img2Img.py:615-648 +
     pipeline_conditionial_ddim.py:248-347): ``add_noise`` to the first kept timestep, then per step a conditional

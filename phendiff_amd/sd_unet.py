@@ -220,6 +220,17 @@ class SDUNet2DConditionModel(nn.Module):
     def invalidate(self):
         self._plans, self._weights = {}, None
 
+    def plan_for(self, B, H, W, tokens, device):
+        """The launch plan (every buffer + pre-filled argument structs) of one UNet evaluation at this shape."""
+        key = (B, H, W, tokens, str(device), self.compute_dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            if self._weights is None:
+                self._weights = _SDPackedWeights(self, device)
+            plan = SDUNetPlan(self, self._weights, B, H, W, tokens, device)
+            self._plans[key] = plan
+        return plan
+
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, cross_attention_kwargs=None,
                 return_dict: bool = True):
         if not sample.is_cuda:
@@ -233,13 +244,7 @@ class SDUNet2DConditionModel(nn.Module):
         ehs = encoder_hidden_states
         if ehs.ndim != 3 or ehs.shape[0] != B or ehs.shape[2] != self.config.cross_attention_dim:
             raise ValueError(f"encoder_hidden_states must be (B, tokens, {self.config.cross_attention_dim}), got {tuple(ehs.shape)}")
-        key = (B, sample.shape[2], sample.shape[3], ehs.shape[1], str(dev), self.compute_dtype)
-        plan = self._plans.get(key)
-        if plan is None:
-            if self._weights is None:
-                self._weights = _SDPackedWeights(self, dev)
-            plan = SDUNetPlan(self, self._weights, B, sample.shape[2], sample.shape[3], ehs.shape[1], dev)
-            self._plans[key] = plan
+        plan = self.plan_for(B, sample.shape[2], sample.shape[3], ehs.shape[1], dev)
         x = sample.contiguous().to(torch.float32)
         stream = torch.cuda.current_stream(dev).cuda_stream
         out = torch.empty_like(x)

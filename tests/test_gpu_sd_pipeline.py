@@ -181,3 +181,26 @@ def test_sd_img2img_full_size_stack_vs_oracle():
     got = P.ddib(pipe, x.cuda(), labels.cuda(), (1 - labels).cuda(), 2, generator=torch.Generator().manual_seed(5))
     assert got.shape == want.shape == (1, 512, 512, 3)
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_sd_ddib_graph_replays_the_eager_transfer_bit_for_bit(mode):
+    """SDDDIBGraph (VAE encode -> sample -> S inversion + S denoising SD-UNet steps -> VAE decode -> post-processing in ONE hipGraph)
+    == the eager `ddib(pipe, ...)` (utils_Img2Img.py:566-612) on the same posterior noise; a second replay with other inputs reuses
+    the graph."""
+    import phendiff_amd as P
+    d = np.load(os.path.join(GOLDEN, "sd_tiny_32_s4.npz"))
+    _, pipe = make_pipe(mode)
+    x, labels = torch.from_numpy(d["images"]).cuda(), torch.from_numpy(d["labels"]).cuda()
+    eager = P.ddib(pipe, x, labels, 1 - labels, 4, generator=torch.Generator().manual_seed(11))
+    g = P.SDDDIBGraph(pipe, batch_size=4, num_inference_steps=4, height=32, width=32)
+    out = g.run(x, labels, 1 - labels, generator=torch.Generator().manual_seed(11))
+    torch.cuda.synchronize()
+    assert torch.equal(out.images.cpu(), torch.from_numpy(eager))
+    if mode == "f32":
+        assert rel(out.inverted, torch.from_numpy(d["inverted"])) < 2e-5 and rel(out.images, d["ddib_out"]) < 2e-5
+    x2 = (x.flip(0) * 0.9).contiguous()
+    eager2 = P.ddib(pipe, x2, 1 - labels, labels, 4, generator=torch.Generator().manual_seed(5))
+    out2 = g.run(x2, 1 - labels, labels, generator=torch.Generator().manual_seed(5))
+    torch.cuda.synchronize()
+    assert torch.equal(out2.images.cpu(), torch.from_numpy(eager2))
