@@ -181,6 +181,11 @@ typedef struct {
   const void* q; const void* k; const void* v;
   void* out;
   float* lse;   /* optional out [B][heads][N]: log2-domain log-sum-exp of the scaled scores (kept for pd_attn_d8_bwd), or NULL */
+  const float* kmax2;   /* optional [B][heads]: an upper bound of max_n |k[b][head][n]|^2 over the keys as stored (pd_linear
+                           kmax2_out produces it in the q/k/v projection's epilogue), or NULL.  With it (bf16 / fp16, large
+                           launches) the kernel needs no per-tile key norms: K / V tiles go global -> LDS by DMA
+                           (global_load_lds), V^T fragments come from transposed LDS reads.  Results are the same function
+                           of the inputs either way (softmax is invariant to the running reference maximum). */
 } pd_attn_args;
 int pd_attn_d8(const pd_attn_args* a, void* stream);
 
@@ -237,6 +242,11 @@ typedef struct {
   float* out;
 } pd_add_noise_args;
 int pd_add_noise(const pd_add_noise_args* a, void* stream);
+
+/* pd_zero: hipMemsetAsync(ptr, 0, bytes) on the stream -- a launch plan's way to reset what later launches max / add into
+ * (pd_linear kmax2_out); captured into a hipGraph like every other entry point. */
+typedef struct { void* ptr; size_t bytes; } pd_zero_args;
+int pd_zero(const pd_zero_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pd_postproc: (x/2 + 0.5).clamp(0,1), NCHW -> NHWC (pipeline_conditionial_ddim.py:349-350), optionally
@@ -460,6 +470,8 @@ typedef struct {
                                y = [M][N/2]; w_packed holds the projection's value rows (0 .. N/2) in the even and its gate rows
                                (N/2 .. N) in the odd 32-channel tiles (two pd_pack_weight calls with dst_ct_stride = two tiles);
                                bias stays in module order [N].  N % 64 == 0, no residual / statistics / head-major output */
+  float* kmax2_out;         /* NULL, or (qkv_heads > 0, bf16 / fp16) [B][heads] fp32, ZEROED by the caller before the launch:
+                               atomically maxed with |k[b][head][n]|^2 of every stored key row -- pd_attn_d8's kmax2 */
 } pd_linear_args;
 int pd_linear(const pd_linear_args* a, void* stream);
 

@@ -138,7 +138,7 @@ class Im2col3Args(C.Structure):
 
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("N", C.c_int),
-                ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp)]
+                ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp), ("kmax2", vp)]
 
 
 class AttnD64Args(C.Structure):
@@ -159,7 +159,7 @@ class GnApplyArgs(C.Structure):
 class LinearArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_longlong), ("K", C.c_int), ("N", C.c_int), ("N_pad", C.c_int), ("x", vp),
                 ("x_stride", C.c_int), ("w_packed", vp), ("bias", vp), ("residual", vp), ("y", vp), ("scale", vp), ("shift", vp),
-                ("rows_per_sample", C.c_int), ("qkv_heads", C.c_int), ("stats_out", vp), ("glu", C.c_int)]
+                ("rows_per_sample", C.c_int), ("qkv_heads", C.c_int), ("stats_out", vp), ("glu", C.c_int), ("kmax2_out", vp)]
 
 
 class AttnWideArgs(C.Structure):
@@ -247,6 +247,10 @@ class PostprocArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("x", vp), ("out_f32", vp), ("out_u8", vp)]
 
 
+class ZeroArgs(C.Structure):
+    _fields_ = [("ptr", vp), ("bytes", C.c_size_t)]
+
+
 # every symbol include/phendiff_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "pd_abi_version": (C.c_int, []),
@@ -260,6 +264,7 @@ SYMBOLS = {
     "pd_attn_d8": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "pd_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), vp]),
     "pd_add_noise": (C.c_int, [C.POINTER(AddNoiseArgs), vp]),
+    "pd_zero": (C.c_int, [C.POINTER(ZeroArgs), vp]),
     "pd_postproc": (C.c_int, [C.POINTER(PostprocArgs), vp]),
     "pd_gn_silu_bwd": (C.c_int, [C.POINTER(GnBwdArgs), vp]),
     "pd_pool2x2_sum": (C.c_int, [C.POINTER(Pool2x2Args), vp]),

@@ -30,6 +30,9 @@ __device__ __forceinline__ float row16_max(float x) {
   return x;
 }
 
+__device__ __forceinline__ unsigned short bits16(bf16_t v) { return v; }
+__device__ __forceinline__ unsigned short bits16(half_t v) { return v.bits; }
+
 // primary template: the 16-bit element types (bf16, fp16); exact fp32 is the specialisation below
 template <typename T> struct AttnOps {
   // deferred-rescale threshold (log2 domain): p = 2^(s - m) <= 2^THR must stay finite in the storage type (fp16: < 65504)
@@ -50,6 +53,27 @@ template <typename T> struct AttnOps {
       }
     }
     return f;
+  }
+  // The reference maximum m rides in the k-slots 8..10 of the QK^T MFMA that head_dim 8 leaves unused (B rows = -m split in
+  // three T-precision terms, A columns = the constants M_C0, 1, 1 of the shared LDS slot): s' = q.k - m_eff leaves the matrix
+  // pipe ready for exp2 with C = 0, i.e. without a 16-register block holding -m.  Returns m_eff, the value actually
+  // subtracted (|m_eff - m| <= 2^-20 |m|; any reference works as long as every consumer uses the same one).
+  static constexpr float M_C0 = std::is_same<T, bf16_t>::value ? 1.0f : 4096.0f;   // fp16: |m| up to ~1e8
+  static constexpr bool M_IN_C = false;
+  static __device__ __forceinline__ float set_m(QF& q, f32x16&, int h, float m) {
+    const T hi = Elem<T>::from_f(-m * (1.0f / M_C0));
+    const float r1 = fmaf(-M_C0, Elem<T>::to_f(hi), -m);
+    const T mid = Elem<T>::from_f(r1);
+    const float r2 = r1 - Elem<T>::to_f(mid);
+    const T lo = Elem<T>::from_f(r2);
+    if (h) { q.v[0] = (short)bits16(hi); q.v[1] = (short)bits16(mid); q.v[2] = (short)bits16(lo); }
+    return -(fmaf(M_C0, Elem<T>::to_f(hi), Elem<T>::to_f(mid)) + Elem<T>::to_f(lo));
+  }
+  static __device__ __forceinline__ void init_const_slot(unsigned char* slot) {   // k-slots 8..15 of every K row
+    T c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = Elem<T>::from_f(i == 0 ? M_C0 : i < 3 ? 1.0f : 0.0f);
+    *(s16x8*)slot = *(const s16x8*)c;
   }
   static __device__ __forceinline__ float q_norm2(const QF& q) {
     float x[8], t = 0.f;
@@ -93,15 +117,15 @@ template <typename T> struct AttnOps {
   // S^T = K . Q^T ; a = K tile fragment (lane: key r; h==0 holds d 0..7, h==1 zeros)
   static constexpr int KROW = 16;                 // bytes per K row in LDS
   static constexpr int KSTEP = 32 * KROW;         // bytes between consecutive 32-key sub-tiles
-  // lane's K-fragment address for sub-tile 0: h == 0 -> row r; h == 1 -> the shared all-zero slot after the tile
-  // (k-slots 8..15 of the 32x32x16 MFMA are unused at head_dim 8); kstep = 0 keeps h == 1 lanes on that slot
+  // lane's K-fragment address for sub-tile 0: h == 0 -> row r; h == 1 -> the shared constant slot after the tile
+  // (k-slots 8..15 of the 32x32x16 MFMA: see set_m); kstep = 0 keeps h == 1 lanes on that slot
   static __device__ __forceinline__ int kaddr(int r, int h) { return h ? KT * KROW : r * KROW; }
   static __device__ __forceinline__ int kstep(int h) { return h ? 0 : KSTEP; }
   struct KF { s16x8 v; };
   struct VF { u32x4 v[2]; };
   static __device__ __forceinline__ KF load_k(const unsigned char* ka) { KF f; f.v = *(const s16x8*)ka; return f; }
   static __device__ __forceinline__ f32x16 qk(const KF& a, const QF& q, const f32x16& c) {
-    return Elem<T>::mma16(a.v, q.v, c);
+    return Elem<T>::mma16(a.v, q.v, c);      // forward: c stays the zero it was initialised to (set_m never writes it)
   }
   static __device__ __forceinline__ VF load_v(const unsigned char* vrow, int key0) {
     VF f;
@@ -137,6 +161,9 @@ template <> struct AttnOps<float> {
     f.v *= scale;
     return f;
   }
+  static constexpr bool M_IN_C = true;   // exact fp32: all 8 k-slots are d; -m rides in the C operand
+  static __device__ __forceinline__ float set_m(QF&, f32x16& negm, int, float m) { negm = (f32x16)(-m); return m; }
+  static __device__ __forceinline__ void init_const_slot(unsigned char*) {}
   static __device__ __forceinline__ float q_norm2(const QF& q) {
     return q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3];
   }
@@ -190,9 +217,14 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
   constexpr int QPB = WPB * QPW;                     // queries per workgroup
   using E = Elem<T>;
   using Ops = AttnOps<T>;
+#ifdef PD_ABL_NOPIPE
+  constexpr bool PIPE = false;
+#else
+  constexpr bool PIPE = sizeof(T) == 2 && QB == 1;   // 16 more registers: the other forms would lose a wave per SIMD
+#endif
   constexpr int KROW = Ops::KROW;
   constexpr int VBYTES = 9 * Ops::VT_PITCH;          // rows 0..7 = V^T, row 8 = 1.0
-  __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW + 16];   // + one all-zero 16-B slot
+  __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW + 16];   // + one 16-B slot: k-slots 8..15 of every row
   __shared__ __attribute__((aligned(16))) unsigned char vlds[2][VBYTES];
   __shared__ __attribute__((aligned(16))) float knmax[2][KT / 64];   // max |k| over each 64-key slice (one staging wave): Cauchy-Schwarz score bound
 
@@ -216,7 +248,8 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
   // fold softmax scale 8^-1/2 and log2(e) into q: p = exp2(s' - m')
   const float qscale = 0.35355339059327373f * 1.4426950408889634f;
   // Deferred-rescale online softmax (per query block).  `m` is the reference maximum (log2 domain) shared by both lane
-  // halves of a query; -m rides in the C operand of the QK^T MFMA, so s' = S - m leaves the matrix pipe ready for exp2.
+  // halves of a query; -m rides in the QK^T MFMA itself (spare k-slots for the 16-bit types, the C operand for fp32: Ops::set_m),
+  // so s' = S - m leaves the matrix pipe ready for exp2.
   // m is only raised when some s' exceeds RESCALE_THR (p <= 2^THR otherwise).  A tile needs the exact row max only if
   // some score COULD exceed m + THR: s = q.k <= |q| * max|k| (Cauchy-Schwarz), checked once per 256-key tile.
 #ifdef PD_ABL_THR
@@ -239,10 +272,10 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
     o[j] = (f32x16)(0.f); negm[j] = (f32x16)(0.f); m[j] = 0.f; first[j] = true;
   }
 
-  // constant LDS content, written once: the shared zero K slot, all-ones row 8 of V^T (A rows 8..15 -> l)
+  // constant LDS content, written once: the shared K slot of k-slots 8..15, all-ones row 8 of V^T (A rows 8..15 -> l)
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
-    if (tid == 0) *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f);
+    if (tid == 0) { *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f); Ops::init_const_slot(klds[b2] + KT * KROW); }
     if (tid < KT) *(T*)(vlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(1.0f);
   }
   const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
@@ -263,11 +296,15 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
   auto commit = [&](int b2, int k0) {
     if (!mine(k0 / KT)) return;
     E::store(klds[b2] + st * KROW, stk);
+#ifndef PD_ABL_NONORM
     float n2 = row16_max(Ops::k_norm2(stk));
     n2 = fmaxf(n2, __shfl_xor(n2, 16));
     n2 = fmaxf(n2, __shfl_xor(n2, 32));
     if ((st & 63) == 0) knmax[b2][st >> 6] = sqrtf(n2) * 1.00002f;
+#endif
+#ifndef PD_ABL_NOVT
     Ops::store_vt(vlds[b2], Ops::vpos(st), stv);
+#endif
   };
 
   issue(0);
@@ -285,20 +322,48 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
     bool need = false;
 #pragma unroll
     for (int j = 0; j < QB; ++j) need = need || first[j] || (qn[j] * kn8 - m[j] > RESCALE_THR);
+#ifdef PD_ABL_NOCHECK   // ablation only
+    if (full_tile && (k0 > 0 || !__builtin_amdgcn_ballot_w64(need))) {
+#else
     if (full_tile && !__builtin_amdgcn_ballot_w64(need)) {
+#endif
       // check-free body: per sub-tile one K and one V^T fragment read feed all QB query blocks
+      if constexpr (PIPE) {
+        // software-pipelined: the QK^T MFMA of sub-tile i+1 (and the LDS reads of its successors) are issued before the
+        // exponentials of sub-tile i, so their latency hides under the wave's own v_exp stream instead of in a stall that
+        // other waves have to fill
+        typename Ops::KF kfn = Ops::load_k(kl + ka0);
+        typename Ops::VF vfn = Ops::load_v(vrow, 0);
+        f32x16 sn = Ops::qk(kfn, qf[0], negm[0]);
+        kfn = Ops::load_k(kl + ka0 + kst);
 #pragma unroll
-      for (int sub = 0; sub < KT / 32; ++sub) {
-        const typename Ops::KF kf = Ops::load_k(kl + ka0 + sub * kst);
-        const typename Ops::VF vf = Ops::load_v(vrow, sub * 32);
-        f32x16 s[QB];
+        for (int sub = 0; sub < KT / 32; ++sub) {
+          const typename Ops::VF vf = vfn;
+          f32x16 s = sn;
+          if (sub + 1 < KT / 32) {
+            sn = Ops::qk(kfn, qf[0], negm[0]);
+            if (sub + 2 < KT / 32) kfn = Ops::load_k(kl + ka0 + (sub + 2) * kst);
+            vfn = Ops::load_v(vrow, (sub + 1) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
-        for (int j = 0; j < QB; ++j) s[j] = Ops::qk(kf, qf[j], negm[j]);
+          for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+          o[0] = Ops::pv(vf, s, o[0]);
+        }
+      } else {
 #pragma unroll
-        for (int j = 0; j < QB; ++j) {
+        for (int sub = 0; sub < KT / 32; ++sub) {
+          const typename Ops::KF kf = Ops::load_k(kl + ka0 + sub * kst);
+          const typename Ops::VF vf = Ops::load_v(vrow, sub * 32);
+          f32x16 s[QB];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) s[j][i] = __builtin_amdgcn_exp2f(s[j][i]);
-          o[j] = Ops::pv(vf, s[j], o[j]);
+          for (int j = 0; j < QB; ++j) s[j] = Ops::qk(kf, qf[j], negm[j]);
+#pragma unroll
+          for (int j = 0; j < QB; ++j) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[j][i] = __builtin_amdgcn_exp2f(s[j][i]);
+            o[j] = Ops::pv(vf, s[j], o[j]);
+          }
         }
       }
     } else {
@@ -326,15 +391,15 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
             for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
             if (__builtin_amdgcn_ballot_w64(first[j] || tmax > RESCALE_THR)) {
               const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));           // finite: the first tile holds key 0
-              const float delta = first[j] ? t2 : fmaxf(t2, 0.f);
+              const float m_new = Ops::set_m(qf[j], negm[j], h, m[j] + (first[j] ? t2 : fmaxf(t2, 0.f)));
+              const float delta = m_new - m[j];             // what the scores of this and of later tiles lose
               const float sc = first[j] ? 1.f : __builtin_amdgcn_exp2f(-delta);
               // only rows 0..15 of O^T are meaningful (d 0..7 and the all-ones rows): registers 0..7
 #pragma unroll
               for (int i = 0; i < 8; ++i) o[j][i] *= sc;
 #pragma unroll
               for (int i = 0; i < 16; ++i) s[i] -= delta;
-              m[j] += delta;
-              negm[j] = (f32x16)(-m[j]);
+              m[j] = m_new;
               first[j] = false;
             }
           }
@@ -344,11 +409,15 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
         }
       }
     }
+#ifndef PD_ABL_NOSTAGE   // ablation only: the first two tiles' LDS content is reused, no staging, no barrier
     if (k0 + KT < N) {
       commit(cur ^ 1, k0 + KT);              // tile k0+KT: loaded during the previous tile's math
       if (k0 + 2 * KT < N) issue(k0 + 2 * KT);
     }
+#ifndef PD_ABL_NOBARRIER
     __syncthreads();
+#endif
+#endif
   }
 
 #pragma unroll
@@ -364,6 +433,179 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention with the staging taken off the vector pipe (16-bit types, 8 waves = 256 queries per workgroup, needs
+// pd_attn_args.kmax2).  In attn_kernel every staged key costs its thread two global loads, |k|^2, a 6-step cross-lane max,
+// a 16-byte and eight 2-byte LDS writes (V transposed on the way): 7 % of the kernel's time at N = 4096, on the VALU port
+// that bounds it.  Here
+//   * K and V tiles keep their global layout [key][8] in LDS, so a tile is eight 1-KiB global_load_lds pieces (one per wave,
+//     no registers, no VALU); the DMA of tile t+1 is issued before tile t's math and retired (vmcnt(0)) before the barrier
+//     that ends it,
+//   * the V^T fragments of O^T += [V^T; 1] . P^T come from transposed LDS reads (ds_read_b64_tr_b16): lane 4q+p of a
+//     16-lane group supplies key row q, d columns 4p..4p+3 (p < 2) or a block of ones (p >= 2: A rows 8..15 -> l),
+//   * the score bound uses the producer's max |k|^2 per (batch, head) instead of per-tile norms: once
+//     |q| * max|k| - m <= THR every later tile runs the check-free body with no LDS read in front of it.
+template <typename T>
+__global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  using Ops = AttnOps<T>;
+  constexpr int KROW = 16, TILE = KT * KROW;                                          // 4 KiB per operand tile
+  // one LDS array, addressed by byte offsets (plain integers keep every access a ds_* instruction):
+  //   K tiles [2][TILE] | V tiles [2][TILE] | ones [ONES] (1.0 everywhere, see voff below) | k-slots 8..15 of every K row (16 B)
+  constexpr int ONES = TILE + 256;                     // the ones lanes read up to 128 + 8 bytes past a tile-sized block
+  constexpr int K_OFF = 0, V_OFF = 2 * TILE, ONES_OFF = 4 * TILE, KCONST_OFF = 4 * TILE + ONES;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE + ONES + 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nqb = (a.N + 255) / 256;
+  const int total = nqb * a.heads * a.B;
+  int item = blockIdx.x;
+  if ((total & 7) == 0) item = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);   // XCD-aware remap, as attn_kernel
+  const int qb = item % nqb;
+  const int head = (item / nqb) % a.heads, b = item / (nqb * a.heads);
+  const int N = a.N;
+  const size_t bh = ((size_t)b * a.heads + head) * N;
+  const T* qp = (const T*)a.q + bh * 8;
+
+  const float qscale = 0.35355339059327373f * 1.4426950408889634f;
+  constexpr float RESCALE_THR = Ops::RESCALE_THR;
+  const int query = qb * 256 + wave * 32 + r;
+  typename Ops::QF qf = Ops::load_q(qp + (size_t)min(query, N - 1) * 8, h, qscale);
+  float qn = Ops::q_norm2(qf);
+  qn += __shfl_xor(qn, 32);
+  qn = sqrtf(qn) * 1.00001f + 1e-6f;
+  const float kn = sqrtf(a.kmax2[b * a.heads + head]) * 1.00002f;
+  const float qk_bound = qn * kn;                 // every scaled score of this query is <= qk_bound (Cauchy-Schwarz)
+  f32x16 o = (f32x16)(0.f), zero = (f32x16)(0.f);
+  float m = 0.f;
+  bool first = true;
+
+  // constant LDS content
+  if (tid == 0) Ops::init_const_slot(lds + KCONST_OFF);
+  if (tid < ONES / 16) {
+    T one8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one8[i] = Elem<T>::from_f(1.0f);
+    *(s16x8*)(lds + ONES_OFF + tid * 16) = *(const s16x8*)one8;
+  }
+  // K fragment offset in buffer 0: h == 0 -> row r of the sub-tile; h == 1 -> the constant slot (every sub-tile, both buffers)
+  const int koff = h ? KCONST_OFF : K_OFF + r * KROW;
+  const int kst = h ? 0 : 32 * KROW, kbuf = h ? 0 : TILE;
+  // V^T fragment offsets (transposed read; EXEC is all ones wherever they are used).  Key-row lanes sit on banks
+  // 16h + 32j .. +15, the ones lanes on 16h + 16 + 32j ..: no conflict inside a 32-lane half; lanes 16..31 of each half repeat
+  // lanes 0..15 (A rows 16..31 are never read back)
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int voff = tp < 2 ? V_OFF + (4 * h + tq) * KROW + 8 * tp : ONES_OFF + (16 * h + 16) * 4 + 8 * (tp & 1);
+  const int vbuf = tp < 2 ? TILE : 0;
+  auto load_v = [&](int base, int sub) {      // A operands of the two PV MFMAs of 32-key sub-tile `sub`
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lp;
+    typename Ops::VF f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // read j: k-slots 4j..4j+3 of this lane half = keys 32 sub + 16 s2 + 8 j + 4 h + (0..3)
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + base + (32 * sub + 16 * s2) * KROW));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + base + (32 * sub + 16 * s2 + 8) * KROW));
+      const s16x8 fr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      f.v[s2] = __builtin_bit_cast(u32x4, fr);
+    }
+    return f;
+  };
+
+  // staging: waves 0..3 copy the four 1-KiB pieces of the K tile, waves 4..7 those of the V tile (keys past N re-read the
+  // last row: their scores are masked below, their p = 0 multiplies finite values).  The DMA is inline asm: the compiler
+  // would order every later ds_read behind a global_load_lds it can see (vmcnt(0) in the middle of the tile).
+  const unsigned char* gsrc = (const unsigned char*)((const T*)(wave < 4 ? a.k : a.v) + bh * 8);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned sdst = __builtin_amdgcn_readfirstlane(lds_base + (wave < 4 ? K_OFF : V_OFF) + (wave & 3) * 1024);
+  auto stage = [&](int b2, int k0) {
+    const int key = min(k0 + (wave & 3) * 64 + lane, N - 1);
+    const unsigned char* src = gsrc + (size_t)key * 16;
+    const unsigned dst = sdst + b2 * TILE;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int k0 = 0, cur = 0; k0 < N; k0 += KT, cur ^= 1) {
+    if (k0 + KT < N) stage(cur ^ 1, k0 + KT);      // buffer cur^1 was last read before the barrier that ended the previous tile
+    const int kl = koff + cur * kbuf;
+    const int vb = voff + cur * vbuf;
+    const bool full_tile = k0 + KT <= N;
+    const bool need = first || (qk_bound - m > RESCALE_THR);
+    if (full_tile && !__builtin_amdgcn_ballot_w64(need)) {
+      // check-free body, software-pipelined as in attn_kernel
+      typename Ops::KF kfn = Ops::load_k(lds + kl);
+      typename Ops::VF vfn = load_v(vb, 0);
+      f32x16 sn = Ops::qk(kfn, qf, zero);
+      kfn = Ops::load_k(lds + kl + kst);
+#pragma unroll
+      for (int sub = 0; sub < KT / 32; ++sub) {
+        const typename Ops::VF vf = vfn;
+        f32x16 s = sn;
+        if (sub + 1 < KT / 32) {
+          sn = Ops::qk(kfn, qf, zero);
+          if (sub + 2 < KT / 32) kfn = Ops::load_k(lds + kl + (sub + 2) * kst);
+          vfn = load_v(vb, sub + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+        o = Ops::pv(vf, s, o);
+      }
+    } else {
+#pragma unroll 1
+      for (int sub = 0; sub < KT / 32; ++sub) {
+        const int kb = sub * 32;
+        if (k0 + kb >= N) break;
+        const typename Ops::KF kf = Ops::load_k(lds + kl + sub * kst);
+        const typename Ops::VF vf = load_v(vb, sub);
+        f32x16 s = Ops::qk(kf, qf, zero);
+        if (k0 + kb + 32 > N) {      // mask keys beyond N (accumulator register i <-> key (i&3) + 8(i>>2) + 4h)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = k0 + kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (key >= N) s[i] = -INFINITY;
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(first || qk_bound - m > RESCALE_THR)) {   // wave-uniform
+          float tmax = s[0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+          if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR)) {
+            const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));           // finite: the first tile holds key 0
+            const float m_new = Ops::set_m(qf, zero, h, m + (first ? t2 : fmaxf(t2, 0.f)));
+            const float delta = m_new - m;
+            const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] *= sc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] -= delta;
+            m = m_new;
+            first = false;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+        o = Ops::pv(vf, s, o);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA piece of the next tile has landed ...
+    __syncthreads();                                   // ... and so has everybody's; nobody still reads buffer `cur`
+  }
+
+  if (query < N) {
+    const float inv = 1.0f / o[4];
+    if (a.lse && h == 0) a.lse[bh + query] = m + __builtin_amdgcn_logf(o[4]);
+    T* dst = (T*)a.out + ((size_t)b * N + query) * (a.heads * 8) + head * 8 + 4 * h;
+    store4(dst, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward (autograd of F.scaled_dot_product_attention, AttnProcessor2_0).  P is recomputed from the forward's
@@ -622,6 +864,16 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
       attr_set = true;
     }
     hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), lds_pad, st, *a);
+    PD_LAUNCH_CHECK();
+    return PD_OK;
+  }
+  static const bool no_glds = getenv("PD_ATTN_NO_GLDS") != nullptr;      // diagnostic: same-box A/B
+  if (a->kmax2 && wide && !no_glds && a->dtype != PD_F32) {
+    if (a->dtype == PD_BF16) hipLaunchKernelGGL((attn_glds_kernel<bf16_t>), grid, dim3(512), 0, st, *a);
+    else if (a->dtype == PD_F16) {
+      PD_CHECK(a->lse == nullptr, PD_ERR_UNSUPPORTED, "pd_attn_d8: fp16 is an inference mode (no log-sum-exp output for a backward)");
+      hipLaunchKernelGGL((attn_glds_kernel<half_t>), grid, dim3(512), 0, st, *a);
+    } else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
     PD_LAUNCH_CHECK();
     return PD_OK;
   }

@@ -24,6 +24,7 @@ struct LinP {
   int rows_per_sample;                      // multiple of 128 when scale is set (a token tile never straddles samples)
   int qkv_heads, B;                         // > 0: head-major q / k / v output [3][B][heads][rows_per_sample][8] (N = 3 * heads * 8)
   float* stats;                             // optional [B][rows_per_sample / 128][N][2]: per-tile channel (sum, sum of squares) of y
+  float* kmax2;                             // optional (qkv_heads > 0, 16-bit) [B][heads]: atomic max of |k row|^2 as stored
 };
 
 // gelu(g) = g/2 (1 + erf(g / sqrt 2)), F.gelu's default (exact) form.  The bf16 engine takes erf from Abramowitz-Stegun 7.1.26
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
   float ssum[EPC], ssq[EPC];           // GroupNorm statistics of what is stored (the consumer's norm input), as pd_conv emits them
 #pragma unroll
   for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  long long kmax_nn = -1; float kmax_run = 0.f;   // running max |k|^2 of this thread's key rows (p.kmax2)
   if (co < NO) {
 #pragma unroll 4
     for (int it = 0; it < TM / TPI; ++it) {
@@ -310,10 +312,26 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
         const int Cq = p.qkv_heads * 8, which = co / Cq, cc = co - which * Cq;
         const long long nn = m / p.rows_per_sample, tok_s = m - nn * p.rows_per_sample;
         *(u32x4*)((T*)p.y + ((((size_t)which * p.B + nn) * p.qkv_heads + (cc >> 3)) * p.rows_per_sample + tok_s) * 8 + (cc & 7)) = v;
+        if constexpr (ES == 2) {
+          if (p.kmax2 && which == 1) {   // this piece IS one key row (8 values of one head): |k|^2 of the values as stored
+            float n2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float lo, hi; Pack16<T>::unpack(v[j], lo, hi); n2 = fmaf(lo, lo, fmaf(hi, hi, n2)); }
+            if (nn != kmax_nn) {           // a token tile may straddle samples: flush per sample
+              if (kmax_nn >= 0) atomicMax((unsigned*)p.kmax2 + kmax_nn * p.qkv_heads + (cc >> 3), __float_as_uint(kmax_run));
+              kmax_nn = nn; kmax_run = 0.f;
+            }
+            kmax_run = fmaxf(kmax_run, n2);
+          }
+        }
       } else {
         *(u32x4*)((T*)p.y + (size_t)m * NO + co) = v;
       }
     }
+  }
+  if constexpr (ES == 2) {
+    // non-negative floats order like their bit patterns: one unsigned atomic max per thread (<= 16 key rows each)
+    if (kmax_nn >= 0) atomicMax((unsigned*)p.kmax2 + kmax_nn * p.qkv_heads + ((co % (p.qkv_heads * 8)) >> 3), __float_as_uint(kmax_run));
   }
   if (p.stats) {       // kernel-uniform: per-thread partials -> LDS behind the output tile; (channel, sum | sumsq) threads add the
                        // TPI token rows in a fixed order (deterministic)
@@ -532,6 +550,9 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a->stats_out == nullptr || (a->rows_per_sample > 0 && a->rows_per_sample % 128 == 0 && a->M % a->rows_per_sample == 0 && a->qkv_heads == 0),
            PD_ERR_SHAPE, "pd_linear: stats_out needs rows_per_sample %% 128 == 0 and dense output");
   p.stats = a->stats_out;
+  PD_CHECK(a->kmax2_out == nullptr || (a->qkv_heads > 0 && a->dtype != PD_F32), PD_ERR_SHAPE,
+           "pd_linear: kmax2_out needs the head-major q/k/v output and a 16-bit dtype");
+  p.kmax2 = a->kmax2_out;
   if (a->dtype == PD_F16) {
     if (glu) return launch_linear<half_t, 2, true>(p, (hipStream_t)stream);
     return narrow ? launch_linear<half_t, 1>(p, (hipStream_t)stream) : launch_linear<half_t, 2>(p, (hipStream_t)stream);

@@ -502,6 +502,12 @@ extern "C" int pd_add_noise(const pd_add_noise_args* a, void* stream) {
   return PD_OK;
 }
 
+extern "C" int pd_zero(const pd_zero_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->ptr && a->bytes > 0, PD_ERR_ARG, "pd_zero: bad args");
+  PD_CHECK(hipMemsetAsync(a->ptr, 0, a->bytes, (hipStream_t)stream) == hipSuccess, PD_ERR_LAUNCH, "pd_zero: hipMemsetAsync failed");
+  return PD_OK;
+}
+
 extern "C" int pd_postproc(const pd_postproc_args* a, void* stream) {
   PD_CHECK(a != nullptr && a->B > 0 && a->C > 0 && a->H > 0 && a->W > 0 && a->x && (a->out_f32 || a->out_u8), PD_ERR_ARG, "pd_postproc: bad args");
   const size_t total = (size_t)a->B * a->H * a->W;

@@ -448,6 +448,7 @@ class UNetPlan:
         self.ops = []
         self.bufs = []          # keep every device buffer alive
         self.stats = {}         # id(NHWC activation) -> (per-tile channel sums [B][T][C][2], T) written by its producer
+        self._kmax_arena, self._kmax_used = None, 0   # max |k|^2 per (sample, head) of every d = 8 attention (zeroed once per forward)
         self.groups = c.norm_num_groups
         self.temb_args = None
         self._temb_ptr_fields = []
@@ -594,6 +595,22 @@ class UNetPlan:
         self.tape.append(SimpleNamespace(kind="resnet", name=name, x0=x0, x1=x1, h1=h1, out=out, gn1=gn1, gn2=gn2, e=e, z1=z1, z2=z2))
         return out
 
+    def _kmax_slot(self, n):
+        """Device address of ``n`` fp32 slots for a q/k/v projection's max |k|^2 (``pd_linear`` kmax2_out -> ``pd_attn_d8``
+        kmax2).  The slots of one forward share an arena that a single ``pd_zero`` launch, placed before its first user,
+        resets."""
+        ARENA = 1 << 15
+        if n > ARENA:
+            return None
+        if self._kmax_arena is None or self._kmax_used + n > ARENA:
+            self._kmax_arena = torch.zeros(ARENA, dtype=torch.float32, device=self.device)
+            self._kmax_used = 0
+            self.bufs.append(self._kmax_arena)
+            self.ops.append(_Op(self.lib.pd_zero, L.ZeroArgs(ptr=self._kmax_arena.data_ptr(), bytes=ARENA * 4), "zero", 0.0, ARENA * 4))
+        ptr = self._kmax_arena.data_ptr() + 4 * self._kmax_used
+        self._kmax_used += n
+        return ptr
+
     def _attn(self, name, x):
         e = self.w.attns[name]
         B, h, w, ch = x.shape
@@ -609,18 +626,20 @@ class UNetPlan:
             qkv = torch.empty((3, B, e.heads, h * w, 8), dtype=self.tdt, device=self.device)
             self.bufs.append(qkv)
             M = B * h * w
+            kmax2 = self._kmax_slot(B * e.heads) if self.code != L.PD_F32 else None
             a = L.LinearArgs(dtype=self.code, M=M, K=ch, N=3 * ch, N_pad=3 * ch, x=x.data_ptr(), x_stride=ch, w_packed=e.wqkv.data_ptr(),
                              bias=e.bqkv.data_ptr(), residual=None, y=qkv.data_ptr(), scale=gn[0].data_ptr(), shift=gn[1].data_ptr(),
-                             rows_per_sample=h * w, qkv_heads=e.heads)
+                             rows_per_sample=h * w, qkv_heads=e.heads, kmax2_out=kmax2)
             esz_ = 4 if self.code == L.PD_F32 else 2
             self.ops.append(_Op(self.lib.pd_linear, a, "conv1x1", 2.0 * M * ch * 3 * ch, (M * ch * 4 + 3 * ch * ch) * esz_))
         else:
+            kmax2 = None
             qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, out_mode=L.PD_OUT_QKV_HEADS,
                                 heads=e.heads)
         o = self._act(h, w, ch)
         lse = self._f32(B, e.heads, h * w) if self.train else None
         a = L.AttnArgs(dtype=self.code, B=B, heads=e.heads, N=h * w, q=qkv[0].data_ptr(), k=qkv[1].data_ptr(),
-                       v=qkv[2].data_ptr(), out=o.data_ptr(), lse=L.ptr(lse))
+                       v=qkv[2].data_ptr(), out=o.data_ptr(), lse=L.ptr(lse), kmax2=kmax2)
         esz = 4 if self.code == L.PD_F32 else 2
         N = h * w
         self.ops.append(_Op(self.lib.pd_attn_d8, a, "attn_d8", 4.0 * B * e.heads * N * N * 8, 4.0 * B * N * ch * esz))

@@ -252,6 +252,59 @@ def test_attention_rescale_8_wave_workgroups(env, mode):
     assert rel(out.float(), ref) < (8e-3 if mode == "bf16" else 1e-3)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(8, 32, 1024), (4, 32, 2100), (2, 64, 4096)])
+def test_attention_dma_staged_with_producer_key_bound(env, mode, cfg):
+    """pd_attn_args.kmax2 (max |k|^2 per (sample, head), what pd_linear's kmax2_out emits) selects the DMA-staged kernel:
+    K / V tiles by global_load_lds, V^T fragments by transposed LDS reads, no per-tile key norms.  Same function of the
+    inputs as the register-staged kernel: compared with SDPA at its tolerance and with that kernel's output."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, N = cfg
+    g = torch.Generator().manual_seed(27)
+    q, k, v = (bf16_round(torch.randn(B, heads, N, 8, generator=g) * 1.5, mode) for _ in range(3))
+    k[:, :, N - 100] = q[:, :, 5] * 6.0              # late spikes: the rescale path of the new kernel
+    k[:, 1, 300] = q[:, 1, N - 1] * 9.0
+    q, k = bf16_round(q, mode), bf16_round(k, mode)
+    Q, K, V = (t.to(tdt).to(dev).contiguous() for t in (q, k, v))
+    kmax2 = (K.float() ** 2).sum(-1).amax(-1).contiguous()          # [B][heads]
+    outs = []
+    for km in (kmax2, None):
+        out = torch.full((B, N, heads * 8), float("nan"), dtype=tdt, device=dev)
+        a = L.AttnArgs(dtype=code, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), out=out.data_ptr(), kmax2=L.ptr(km))
+        L.check(lib.pd_attn_d8(C.byref(a), stream()), "pd_attn_d8")
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu())
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, heads * 8)
+    assert torch.isfinite(outs[0]).all()
+    tol = 8e-3 if mode == "bf16" else 1e-3
+    assert rel(outs[0], ref) < tol
+    assert rel(outs[0], outs[1]) < tol            # the two kernels differ only in the reference maxima they pick
+
+
+def test_attention_dma_staged_loose_bound_and_lse(env):
+    """A bound far above the true max |k| (the slow path runs for every tile: exact maxima, rescales) and the log-sum-exp
+    output of the training forward."""
+    L, lib, _, dev = env
+    code, tdt = DT["bf16"]
+    B, heads, N = 4, 32, 1024
+    g = torch.Generator().manual_seed(28)
+    q, k, v = (bf16_round(torch.randn(B, heads, N, 8, generator=g), "bf16") for _ in range(3))
+    Q, K, V = (t.to(tdt).to(dev).contiguous() for t in (q, k, v))
+    kmax2 = torch.full((B, heads), 1e6, device=dev)
+    out = torch.empty((B, N, heads * 8), dtype=tdt, device=dev)
+    lse = torch.empty((B, heads, N), device=dev)
+    a = L.AttnArgs(dtype=code, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), out=out.data_ptr(),
+                   lse=lse.data_ptr(), kmax2=kmax2.data_ptr())
+    L.check(lib.pd_attn_d8(C.byref(a), stream()), "pd_attn_d8")
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, heads * 8)
+    assert rel(out.float(), ref) < 8e-3
+    s = (q @ k.transpose(-1, -2)) * (8 ** -0.5) * 1.4426950408889634
+    ref_lse = torch.logsumexp(s * 0.6931471805599453, -1) * 1.4426950408889634      # log2-domain
+    assert float((lse.cpu() - ref_lse).abs().max()) < 2e-2
+
+
 def test_conv_in(env):
     L, lib, _, dev = env
     g = torch.Generator().manual_seed(9)

@@ -300,7 +300,7 @@ def test_token_wgrad(env, mode, cfg, accumulate):
     assert torch.equal(dw2, dw)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
 def test_linear_gemm_groupnorm_prologue_and_head_major_output(env, mode):
     """pd_linear as the fused q/k/v projection of the pixel-UNet attention: x*scale[n] + shift[n] applied while staging, output
     written head-major [3][B][heads][tokens][8] (what pd_attn_d8 reads)."""
@@ -325,5 +325,16 @@ def test_linear_gemm_groupnorm_prologue_and_head_major_output(env, mode):
     L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
     torch.cuda.synchronize()
     assert rel(y.float(), ref) < (3e-6 if mode == "f32" else 4e-3)
+    kmax2 = torch.zeros(B, heads, device=dev)
+    a.kmax2_out = kmax2.data_ptr()
+    if mode == "f32":
+        assert lib.pd_linear(C.byref(a), stream()) == -2                      # the key bound is a 16-bit-engine feature
+    else:
+        # max |k|^2 per (sample, head) of the key rows AS STORED (pd_attn_d8's kmax2), exact up to fp32 summation order
+        L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+        torch.cuda.synchronize()
+        want = (y[1].float() ** 2).sum(-1).amax(-1)
+        assert torch.allclose(kmax2, want, rtol=1e-5, atol=0)
+    a.kmax2_out = None
     a.rows_per_sample = 200                                                   # not a multiple of 128: refused, not mis-addressed
     assert lib.pd_linear(C.byref(a), stream()) == -2
