@@ -262,6 +262,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
         store4((T*)(lds + tok * EP_PITCH) + (wc * NC + c) * 32 + 8 * g + 4 * h, acc[c][f][4 * g], acc[c][f][4 * g + 1], acc[c][f][4 * g + 2],
                acc[c][f][4 * g + 3]);
     }
+  __shared__ unsigned kmax_s[TN / 8];                  // p.kmax2: per-head maxima of this tile (one sample per tile), bit patterns
+  if (tid < TN / 8) kmax_s[tid] = 0u;
   __syncthreads();
   constexpr int EPC = 16 / ES;                         // channels per 16-byte piece
   constexpr int PPT = TNO / EPC;                       // pieces per token
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
             float n2 = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { float lo, hi; Pack16<T>::unpack(v[j], lo, hi); n2 = fmaf(lo, lo, fmaf(hi, hi, n2)); }
-            if (nn != kmax_nn) {           // a token tile may straddle samples: flush per sample
+            if (nn != kmax_nn) {           // a token tile may straddle samples (rows_per_sample % TM != 0): flush per sample
               if (kmax_nn >= 0) atomicMax((unsigned*)p.kmax2 + kmax_nn * p.qkv_heads + (cc >> 3), __float_as_uint(kmax_run));
               kmax_nn = nn; kmax_run = 0.f;
             }
@@ -330,8 +332,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
     }
   }
   if constexpr (ES == 2) {
-    // non-negative floats order like their bit patterns: one unsigned atomic max per thread (<= 16 key rows each)
-    if (kmax_nn >= 0) atomicMax((unsigned*)p.kmax2 + kmax_nn * p.qkv_heads + ((co % (p.qkv_heads * 8)) >> 3), __float_as_uint(kmax_run));
+    // non-negative floats order like their bit patterns: unsigned atomic max.  Tiles inside one sample (the usual case) fold
+    // their 256 threads through LDS first -- one global atomic per head and tile instead of one per thread (a per-thread
+    // form cost the q/k/v projection +60 us at 131 072 tokens: 256 atomics per address)
+    if (p.kmax2) {                                      // kernel-uniform
+      const bool one_sample = p.rows_per_sample % TM == 0;
+      if (!one_sample) {
+        if (kmax_nn >= 0) atomicMax((unsigned*)p.kmax2 + kmax_nn * p.qkv_heads + ((co % (p.qkv_heads * 8)) >> 3), __float_as_uint(kmax_run));
+      } else {
+        if (kmax_nn >= 0) atomicMax(&kmax_s[piece], __float_as_uint(kmax_run));
+        __syncthreads();
+        const int Cq = p.qkv_heads * 8, c0 = n0o + tid * 8;
+        if (tid < TNO / 8 && c0 < NO && c0 / Cq == 1 && kmax_s[tid] != 0u)
+          atomicMax((unsigned*)p.kmax2 + (m0 / p.rows_per_sample) * p.qkv_heads + ((c0 - Cq) >> 3), kmax_s[tid]);
+      }
+    }
   }
   if (p.stats) {       // kernel-uniform: per-thread partials -> LDS behind the output tile; (channel, sum | sumsq) threads add the
                        // TPI token rows in a fixed order (deterministic)
