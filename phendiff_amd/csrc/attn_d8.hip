@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
   constexpr bool PIPE = sizeof(T) == 2 && QB == 1;   // 16 more registers: the other forms would lose a wave per SIMD
 #endif
   constexpr int KROW = Ops::KROW;
-  constexpr int VBYTES = 9 * Ops::VT_PITCH;          // rows 0..7 = V^T, row 8 = 1.0
+  constexpr int VBYTES = 10 * Ops::VT_PITCH;         // rows 0..7 = V^T, row 8 = 1.0, row 9 = 0
   __shared__ __attribute__((aligned(16))) unsigned char klds[2][KT * KROW + 16];   // + one 16-B slot: k-slots 8..15 of every row
   __shared__ __attribute__((aligned(16))) unsigned char vlds[2][VBYTES];
   __shared__ __attribute__((aligned(16))) float knmax[2][KT / 64];   // max |k| over each 64-key slice (one staging wave): Cauchy-Schwarz score bound
@@ -276,9 +276,12 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
     if (tid == 0) { *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f); Ops::init_const_slot(klds[b2] + KT * KROW); }
-    if (tid < KT) *(T*)(vlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(1.0f);
+    if (tid < KT) { *(T*)(vlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(1.0f); *(T*)(vlds[b2] + 9 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f); }
   }
-  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
+  // A rows of O^T += A . P^T: 0..7 = V^T (d), 8 and 12 = ones (the two rows read back as l, lane halves h = 0 / 1); every other
+  // row reads the zero row -- the matrix pipe multiplies zeros instead of 22 rows of live data (the kernel runs power-limited:
+  // -3 % time on the DMA-staged kernel)
+  const int vrow_off = (r < 8 ? r : (r == 8 || r == 12) ? 8 : 9) * Ops::VT_PITCH + Ops::vlane_off(h);
   const int ka0 = Ops::kaddr(r, h), kst = Ops::kstep(h);
 
   // staging: thread (t & 255) owns K row t and V row t of a 256-key tile; with 8 waves the two halves of the workgroup take
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
   using Ops = AttnOps<T>;
   constexpr int KROW = 16, TILE = KT * KROW;                                          // 4 KiB per operand tile
   // one LDS array, addressed by byte offsets (plain integers keep every access a ds_* instruction):
-  //   K tiles [2][TILE] | V tiles [2][TILE] | ones [ONES] (1.0 everywhere, see voff below) | k-slots 8..15 of every K row (16 B)
+  //   K tiles [2][TILE] | V tiles [2][TILE] | constants [ONES] ([1 0 0 0 | 0 0 0 0] per 16 bytes, see voff below) | k-slots 8..15 of every K row (16 B)
   constexpr int ONES = TILE + 256;                     // the ones lanes read up to 128 + 8 bytes past a tile-sized block
   constexpr int K_OFF = 0, V_OFF = 2 * TILE, ONES_OFF = 4 * TILE, KCONST_OFF = 4 * TILE + ONES;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE + ONES + 16];
@@ -484,10 +487,10 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
 
   // constant LDS content
   if (tid == 0) Ops::init_const_slot(lds + KCONST_OFF);
-  if (tid < ONES / 16) {
+  if (tid < ONES / 16) {     // every 16 bytes: [1 0 0 0 | 0 0 0 0]
     T one8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) one8[i] = Elem<T>::from_f(1.0f);
+    for (int i = 0; i < 8; ++i) one8[i] = Elem<T>::from_f(i == 0 ? 1.0f : 0.0f);
     *(s16x8*)(lds + ONES_OFF + tid * 16) = *(const s16x8*)one8;
   }
   // K fragment offset in buffer 0: h == 0 -> row r of the sub-tile; h == 1 -> the constant slot (every sub-tile, both buffers)
@@ -497,8 +500,12 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
   // 16h + 32j .. +15, the ones lanes on 16h + 16 + 32j ..: no conflict inside a 32-lane half; lanes 16..31 of each half repeat
   // lanes 0..15 (A rows 16..31 are never read back)
   const int tq = (lane & 15) >> 2, tp = lane & 3;
-  const int voff = tp < 2 ? V_OFF + (4 * h + tq) * KROW + 8 * tp : ONES_OFF + (16 * h + 16) * 4 + 8 * (tp & 1);
-  const int vbuf = tp < 2 ? TILE : 0;
+  // Only A rows 0..7 (d), 8 and 12 (the two rows whose sums are read back as l) matter: columns 8 and 12 are 1, every other
+  // column of 8..15 and all of rows 16..31 (lanes 16..31 of each half) are 0 -- the matrix pipe multiplies zeros instead of
+  // 22 rows of live data (power, i.e. clock, on a kernel that runs DVFS-limited)
+  const bool vrow = (lane & 16) == 0 && tp < 2;
+  const int voff = vrow ? V_OFF + (4 * h + tq) * KROW + 8 * tp : ONES_OFF + (16 * h + 16) * 4 + ((lane & 16) ? 8 : 0);
+  const int vbuf = vrow ? TILE : 0;
   auto load_v = [&](int base, int sub) {      // A operands of the two PV MFMAs of 32-key sub-tile `sub`
     typedef short v4s __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4s* lp;
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pd_attn_bwd_args
     if (tid == 0) { *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f); *(f32x4*)(vlds[b2] + KT * KROW) = (f32x4)(0.f); }
     *(T*)(ktlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
   }
-  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
+  const int vrow_off = (r < 8 ? r : 8) * Ops::VT_PITCH + Ops::vlane_off(h);   // A rows 8..31: the zero row
   const int ka0 = Ops::kaddr(r, h), kst = Ops::kstep(h);
 
   typename E::Frag stk, stv;
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_arg
       *(T*)(dotlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
     }
   }
-  const int vrow_off = ((r & 8) ? 8 : (r & 7)) * Ops::VT_PITCH + Ops::vlane_off(h);
+  const int vrow_off = (r < 8 ? r : 8) * Ops::VT_PITCH + Ops::vlane_off(h);   // A rows 8..31: the zero row
   // K-row style addressing of the Q / dO row images; the bf16 zero slot sits after QT rows here
   const int ka0 = (sizeof(T) == 2 && h) ? QT * KROW : Ops::kaddr(r, h);
   const int kst = Ops::kstep(h);
