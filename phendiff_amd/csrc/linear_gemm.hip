@@ -268,7 +268,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
   constexpr int EPC = 16 / ES;                         // channels per 16-byte piece
   constexpr int PPT = TNO / EPC;                       // pieces per token
   constexpr int TPI = 256 / PPT;                       // tokens per iteration
-  const int piece = tid % PPT, trow = tid / PPT;
+  // dense output: a token's pieces on consecutive lanes (each token row is one contiguous run).  Head-major q/k/v output:
+  // consecutive TOKENS on consecutive lanes -- a (head, token) piece is 16 bytes and a head's tokens are contiguous, so 16
+  // lanes write one 256-byte run instead of 16 lanes writing 16 runs of 64 bytes
+  const bool tokmajor = p.qkv_heads > 0;               // kernel-uniform
+  const int piece = tokmajor ? tid / TPI : tid % PPT, trow = tokmajor ? tid % TPI : tid / PPT;
   const int NO = GLU ? p.N / 2 : p.N;                  // output row length
   const int n0o = GLU ? ct * TNO : n0;
   const int co = n0o + piece * EPC;
