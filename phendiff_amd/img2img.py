@@ -384,9 +384,11 @@ class SDDDIBGraph:
         sf = 1 << (len(vae.config.block_out_channels) - 1)
         h, w = H // sf, W // sf
         lc = vae.config.latent_channels
-        if B > vae._max_batch(H, W, "enc") or B > vae._max_batch(H, W, "dec"):
-            raise ValueError(f"batch_size {B} exceeds what one VAE launch plan holds at {H}x{W}; replay several runners instead")
-        self.enc, self.dec = vae._plan("enc", B, H, W, dev), vae._plan("dec", B, h, w, dev)
+        # the VAE runs in sub-batches of what one of its launch plans addresses (32-bit byte offsets), like vae.encode / .decode
+        def chunks(kind, ph, pw):
+            step = vae._max_batch(H, W, kind)
+            return [(b0, min(step, B - b0), vae._plan(kind, min(step, B - b0), ph, pw, dev)) for b0 in range(0, B, step)]
+        self.enc_chunks, self.dec_chunks = chunks("enc", H, W), chunks("dec", h, w)
         self.plan = unet.plan_for(B, h, w, 77, dev)
         self.inv = Inv.from_config(pipe.scheduler.config, variant=variant)
         self.inv.set_timesteps(S)
@@ -434,7 +436,8 @@ class SDDDIBGraph:
         """The trajectory as launches on the current stream (``st``); the three torch calls are plain device-to-device kernels
         between pre-allocated buffers (capturable)."""
         lib, plan, B = self.lib, self.plan, self.B
-        self.enc.run(self.x.data_ptr(), self.moments.data_ptr(), st)
+        for b0, nb, plan_ in self.enc_chunks:
+            plan_.run(self.x[b0:b0 + nb].data_ptr(), self.moments[b0:b0 + nb].data_ptr(), st)
         L.check(lib.pd_latent_sample(C.byref(self.sample_args), st), "pd_latent_sample")
         n_inv = len(self.inv_ts)
         ta = plan.temb_args
@@ -450,7 +453,8 @@ class SDDDIBGraph:
             if i == n_inv - 1:
                 self.inverted.copy_(self.latents)
         torch.div(self.latents, self.scaling, out=self.dec_in)        # vae.decode(latents / scaling_factor), custom_pipeline...:709
-        self.dec.run(self.dec_in.data_ptr(), self.decoded.data_ptr(), st)
+        for b0, nb, plan_ in self.dec_chunks:
+            plan_.run(self.dec_in[b0:b0 + nb].data_ptr(), self.decoded[b0:b0 + nb].data_ptr(), st)
         L.check(lib.pd_postproc(C.byref(self.post_args), st), "pd_postproc")
 
     @torch.no_grad()

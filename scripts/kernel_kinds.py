@@ -3,7 +3,7 @@
 import re
 
 RULES = [
-    (r"attn_kernel<", "attn_d8"),
+    (r"attn_kernel<|attn_glds_kernel<", "attn_d8"),                # register-staged and DMA-staged forms of pd_attn_d8
     (r"conv_kernel<[^,]+, 3, ", "conv3x3"),                  # every 3x3 instantiation (stride 1 / 2, with / without the fused shortcut tail)
     (r"conv_kernel<[^,]+, 1, |linear_kernel<", "conv1x1"),     # 1x1 convs (incl. conv_in's im2col form) and pd_linear: the plan's "conv1x1"
     (r"gn_finalize", "gn_finalize"),
