@@ -449,11 +449,15 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const pd_attn_args a) {
 //     16-lane group supplies key row q, d columns 4p..4p+3 (p < 2) or a block of ones (p >= 2: A rows 8..15 -> l),
 //   * the score bound uses the producer's max |k|^2 per (batch, head) instead of per-tile norms: once
 //     |q| * max|k| - m <= THR every later tile runs the check-free body with no LDS read in front of it.
+#ifndef PD_ATTN_DMA_KT
+#define PD_ATTN_DMA_KT 256
+#endif
 template <typename T>
 __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
   static_assert(sizeof(T) == 2, "16-bit element types");
   using Ops = AttnOps<T>;
-  constexpr int KROW = 16, TILE = KT * KROW;                                          // 4 KiB per operand tile
+  constexpr int KT = PD_ATTN_DMA_KT;                                                  // keys per LDS tile (one barrier per tile)
+  constexpr int KROW = 16, TILE = KT * KROW;
   // one LDS array, addressed by byte offsets (plain integers keep every access a ds_* instruction):
   //   K tiles [2][TILE] | V tiles [2][TILE] | constants [ONES] ([1 0 0 0 | 0 0 0 0] per 16 bytes, see voff below) | k-slots 8..15 of every K row (16 B)
   constexpr int ONES = TILE + 256;                     // the ones lanes read up to 128 + 8 bytes past a tile-sized block
@@ -487,11 +491,11 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
 
   // constant LDS content
   if (tid == 0) Ops::init_const_slot(lds + KCONST_OFF);
-  if (tid < ONES / 16) {     // every 16 bytes: [1 0 0 0 | 0 0 0 0]
+  for (int i16 = tid; i16 < ONES / 16; i16 += 512) {     // every 16 bytes: [1 0 0 0 | 0 0 0 0]
     T one8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) one8[i] = Elem<T>::from_f(i == 0 ? 1.0f : 0.0f);
-    *(s16x8*)(lds + ONES_OFF + tid * 16) = *(const s16x8*)one8;
+    *(s16x8*)(lds + ONES_OFF + i16 * 16) = *(const s16x8*)one8;
   }
   // K fragment offset in buffer 0: h == 0 -> row r of the sub-tile; h == 1 -> the constant slot (every sub-tile, both buffers)
   const int koff = h ? KCONST_OFF : K_OFF + r * KROW;
@@ -528,12 +532,15 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   const unsigned sdst = __builtin_amdgcn_readfirstlane(lds_base + (wave < 4 ? K_OFF : V_OFF) + (wave & 3) * 1024);
   auto stage = [&](int b2, int k0) {
-    const int key = min(k0 + (wave & 3) * 64 + lane, N - 1);
-    const unsigned char* src = gsrc + (size_t)key * 16;
-    const unsigned dst = sdst + b2 * TILE;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    #pragma unroll
+    for (int pc = 0; pc < KT / 256; ++pc) {       // KT / 64 pieces per operand tile, 4 waves per operand
+      const int key = min(k0 + ((wave & 3) + 4 * pc) * 64 + lane, N - 1);
+      const unsigned char* src = gsrc + (size_t)key * 16;
+      const unsigned dst = sdst + b2 * TILE + pc * 4096;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
   };
 
   stage(0, 0);

@@ -86,26 +86,28 @@ class ConditionalDDIMPipeline:
 
     numpy_to_pil = staticmethod(numpy_to_pil)
 
-    # ---- pipeline_conditionial_ddim.py:91-137 ----
+    # ---- argument contract (replaces `check_inputs`, pipeline_conditionial_ddim.py:91-137): the messages are the interface ----
     def check_inputs(self, class_labels=None, class_emb=None, w=None, generator=None, frac_diffusion_skipped=None,
                      start_image=None) -> None:
-        assert class_labels is None or (isinstance(class_labels, torch.Tensor) and class_labels.ndim == 1), \
-            "class_labels must be a 1D tensor of shape (batch_size,) if not None."
-        assert class_emb is None or (isinstance(class_emb, torch.Tensor) and class_emb.ndim == 2), \
-            "class_emb must be a 2D tensor of shape (batch_size, emb_dim) if not None."
-        assert class_labels is None or class_emb is None, "Cannot pass both class_labels and class_emb."
-        batch_size = class_labels.shape[0] if class_labels is not None else class_emb.shape[0]
-        assert isinstance(w, (float, int)) or w is None or (w.ndim == 1 and batch_size == w.shape[0]), \
+        def tensor_of_rank(x, rank):
+            return isinstance(x, torch.Tensor) and x.ndim == rank
+        asserts = (   # (holds?, message)
+            (class_labels is None or tensor_of_rank(class_labels, 1), "class_labels must be a 1D tensor of shape (batch_size,) if not None."),
+            (class_emb is None or tensor_of_rank(class_emb, 2), "class_emb must be a 2D tensor of shape (batch_size, emb_dim) if not None."),
+            (class_labels is None or class_emb is None, "Cannot pass both class_labels and class_emb."),
+        )
+        for holds, message in asserts:
+            assert holds, message
+        batch_size = (class_labels if class_labels is not None else class_emb).shape[0]
+        assert w is None or isinstance(w, (float, int)) or (w.ndim == 1 and w.shape[0] == batch_size), \
             "w must be a 1D tensor of shape (batch_size,) if not None and not a single int/float."
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
                              f" size of {batch_size} through class conditioning. Make sure the batch size matches the length of the generators.")
-        assert (frac_diffusion_skipped is not None and start_image is not None) or \
-            (frac_diffusion_skipped is None and start_image is None), \
+        assert (frac_diffusion_skipped is None) == (start_image is None), \
             "Either pass both frac_diffusion_skipped and start_image or none of them."
-        if frac_diffusion_skipped is not None:
-            assert isinstance(frac_diffusion_skipped, (float, int)) and 0 <= frac_diffusion_skipped <= 1, \
-                f"frac_diffusion_skipped must be a float (or int) between 0 and 1; got {frac_diffusion_skipped}."
+        assert frac_diffusion_skipped is None or (isinstance(frac_diffusion_skipped, (float, int)) and 0 <= frac_diffusion_skipped <= 1), \
+            f"frac_diffusion_skipped must be a float (or int) between 0 and 1; got {frac_diffusion_skipped}."
 
     def _randn(self, shape, generator, device):
         return randn_tensor(shape, generator, device)

@@ -124,28 +124,24 @@ class CustomStableDiffusionImg2ImgPipeline:
                        "class_embedding_dim": emb.embedding_dim}, f, indent=2)
         save_weights_file(self.class_embedding.state_dict(), folder, safe_serialization)
 
-    # ---- :221-281 ------------------------------------------------------------------------------------------------------
+    # ---- class conditioning rows (replaces `_encode_class`, custom_pipeline...:221-281) ------------------------------------
+    @staticmethod
+    def _label_rows(class_labels):
+        """int | list[int] | 1-D tensor -> int64 tensor [B] (None stays None)."""
+        if class_labels is None or isinstance(class_labels, torch.Tensor):
+            return None if class_labels is None else class_labels.long()
+        return torch.as_tensor([class_labels] if isinstance(class_labels, int) else class_labels).long()
+
     def _encode_class(self, class_labels, device, do_classifier_free_guidance, class_labels_embeds=None, lora_scale=None):
-        if class_labels is not None:
-            if isinstance(class_labels, int):
-                batch_size = 1
-                class_labels = torch.tensor([class_labels]).long()
-            elif isinstance(class_labels, list):
-                batch_size = len(class_labels)
-                class_labels = torch.tensor(class_labels).long()
-            elif isinstance(class_labels, torch.Tensor):
-                class_labels = class_labels.long()
-                batch_size = class_labels.shape[0]
-        else:
-            batch_size = class_labels_embeds.shape[0]
-        if class_labels_embeds is None:
-            table = self.class_embedding.inner_module.weight
-            class_labels_embeds = self.class_embedding(class_labels.to(table.device))
-        class_labels_embeds = class_labels_embeds.to(dtype=torch.float32, device=device)
-        if do_classifier_free_guidance:
-            uncond_embeds = torch.zeros((batch_size, self.unet.config.cross_attention_dim), device=device)
-            class_labels_embeds = torch.cat([uncond_embeds, class_labels_embeds])
-        return class_labels_embeds
+        rows = class_labels_embeds
+        if rows is None:
+            labels = self._label_rows(class_labels)
+            rows = self.class_embedding(labels.to(self.class_embedding.inner_module.weight.device))
+        rows = rows.to(dtype=torch.float32, device=device)
+        if not do_classifier_free_guidance:
+            return rows
+        # the unconditional half of a guided batch is the all-zero embedding, stacked in front
+        return torch.cat([rows.new_zeros((rows.shape[0], self.unet.config.cross_attention_dim)), rows])
 
     # ---- :283-303 --------------------------------------------------------------------------------------------------------
     def prepare_extra_step_kwargs(self, generator, eta):
@@ -157,38 +153,39 @@ class CustomStableDiffusionImg2ImgPipeline:
             kw["generator"] = generator
         return kw
 
-    # ---- :305-373 --------------------------------------------------------------------------------------------------------
+    # ---- argument contract (replaces `check_inputs`, custom_pipeline...:305-373): the messages are the interface --------------
     def check_inputs(self, class_labels, strength, callback_steps, class_labels_embeds, latent_shape, image, guidance_scale):
-        if image is None and latent_shape is None:
-            raise ValueError("Either `image` or `latent_shape` must be provided as input.")
-        if strength < 0 or strength > 1:
-            raise ValueError(f"The value of strength should be in [0, 1] but is {strength}")
+        have_labels, have_rows = class_labels is not None, class_labels_embeds is not None
+        rules = (   # (violated?, message), checked in order
+            (image is None and latent_shape is None, "Either `image` or `latent_shape` must be provided as input."),
+            (not 0 <= strength <= 1, f"The value of strength should be in [0, 1] but is {strength}"),
+            (not (isinstance(callback_steps, int) and callback_steps > 0),
+             f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}."),
+            (have_labels and have_rows,
+             "Cannot forward both `class_labels` and `class_labels_embeds`. Please make sure to only forward one of the two."),
+            (not have_labels and not have_rows,
+             "Provide either `class_labels` or `class_labels_embeds`. Cannot leave both `class_labels` and "
+             "`class_labels_embeds` undefined."),
+            (have_labels and not isinstance(class_labels, (int, list, torch.Tensor)),
+             f"`class_labels` has to be of type `int` or `list` or `torch.Tensor` but is {type(class_labels)}"),
+            (isinstance(class_labels, torch.Tensor) and class_labels.ndim != 1, "If a Tensor `class_labels` should be 1D"),
+            (guidance_scale is not None and not isinstance(guidance_scale, (float, int, torch.Tensor)),
+             f"`guidance_scale` has to be of type `int` or `float` or `Tensor` or `None` but is {type(guidance_scale)}"),
+        )
+        for violated, message in rules:
+            if violated:
+                raise ValueError(message)
+        assert not isinstance(guidance_scale, torch.Tensor) or guidance_scale.ndim == 1, "If a Tensor `guidance_scale` should be 1D"
         if image is None and strength != 1:
             warn("`image` is None so the generation will start from pure Gaussian noise, but `strength` is not set to 1 "
                  "so the denoising process will not run for the full denoising trajectory. This will produce images "
                  "that are not fully denoised.")
-        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
-            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
-        if class_labels is not None and class_labels_embeds is not None:
-            raise ValueError("Cannot forward both `class_labels` and `class_labels_embeds`. Please make sure to only forward one of the two.")
-        elif class_labels is None and class_labels_embeds is None:
-            raise ValueError("Provide either `class_labels` or `class_labels_embeds`. Cannot leave both `class_labels` and "
-                             "`class_labels_embeds` undefined.")
-        elif class_labels is not None and not isinstance(class_labels, (int, list, torch.Tensor)):
-            raise ValueError(f"`class_labels` has to be of type `int` or `list` or `torch.Tensor` but is {type(class_labels)}")
-        if isinstance(class_labels, torch.Tensor) and class_labels.ndim != 1:
-            raise ValueError("If a Tensor `class_labels` should be 1D")
-        if not isinstance(guidance_scale, (float, int, torch.Tensor)) and guidance_scale is not None:
-            raise ValueError(f"`guidance_scale` has to be of type `int` or `float` or `Tensor` or `None` but is {type(guidance_scale)}")
-        if isinstance(guidance_scale, torch.Tensor):
-            assert guidance_scale.ndim == 1, "If a Tensor `guidance_scale` should be 1D"
 
-    # ---- :375-383 --------------------------------------------------------------------------------------------------------
+    # ---- the last `strength` fraction of the schedule (replaces `get_timesteps`, custom_pipeline...:375-383) ---------------
     def get_timesteps(self, num_inference_steps, strength, device=None):
-        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
-        t_start = max(num_inference_steps - init_timestep, 0)
-        timesteps = self.scheduler.timesteps[t_start * self.scheduler.order:]
-        return timesteps, num_inference_steps - t_start
+        kept = min(int(num_inference_steps * strength), num_inference_steps)
+        first = max(num_inference_steps - kept, 0)
+        return self.scheduler.timesteps[first * self.scheduler.order:], num_inference_steps - first
 
     @staticmethod
     def _randn(shape, generator, device):
