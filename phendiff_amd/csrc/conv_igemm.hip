@@ -19,6 +19,9 @@
 #include "pd_stage.h"
 #include "pd_conv.h"
 
+#ifndef PD_S2_SINGLE
+#define PD_S2_SINGLE 1
+#endif
 namespace pd {
 
 
@@ -487,7 +490,9 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int IN_TH = (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
   constexpr int LDS_TILE = ((IN_TH * IN_TW * PITCH + 15) / 16) * 16;
-  constexpr bool DB = 2 * LDS_TILE <= 100 * 1024;       // double-buffer when two tiles fit comfortably
+  // double-buffer when two tiles fit comfortably -- and leave room for a second workgroup: the stride-2 halo tile (9 x 65 pixels)
+  // double-buffered is 84 KB = ONE workgroup (4 waves) per CU; single-buffered 47 KB admits two, which overlap each other
+  constexpr bool DB = 2 * LDS_TILE <= 100 * 1024 && !(STRIDE == 2 && PD_S2_SINGLE);
   constexpr int LDS_DB = ((IN_TH * IN_TW * (2 * 32 * Elem<T>::BYTES + 16) + 15) / 16) * 16;   // interleaved buffers, one shared pad
   constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 256 * 64;   // output tile + stats scratch [256][2*EPC] fp32
   constexpr int LDS_MAIN = DB ? LDS_DB : LDS_TILE;
