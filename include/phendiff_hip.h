@@ -351,6 +351,17 @@ typedef struct {
 } pd_pack_weight_args;
 int pd_pack_weight(const pd_pack_weight_args* a, void* stream);
 
+/* pd_pack_weight_batch: n pd_pack_weight jobs of ONE dtype as a single launch (an optimizer step re-packs ~130 weights of the
+ * pixel UNet, ~1400 of the SD UNet: 13 us of launch latency each).  jobs: DEVICE array of n descriptors (validated by the caller
+ * as pd_pack_weight would); starts: DEVICE int[n + 1], starts[j] = sum over i < j of (cout_pad/32)*(cin_pad/32), starts[n] =
+ * total_blocks; max_ksize: largest ksize among the jobs (sizes the LDS tile). */
+typedef struct {
+  int dtype; int n;
+  const pd_pack_weight_args* jobs; const int* starts;
+  int total_blocks; int max_ksize;
+} pd_pack_weight_batch_args;
+int pd_pack_weight_batch(const pd_pack_weight_batch_args* a, void* stream);
+
 /* pd_im2col3: out[n][y][x][ci*9+ky*3+kx] = x[n][ci][y+ky-1][x+kx-1] (zero padded; 27 of 32 channels used): the input of
  * conv_in seen as a 1x1 convolution, for its weight gradient (cond_unet_2d.py:127-129). x: NCHW fp32, C <= 3; out: NHWC dtype. */
 typedef struct { int dtype; int B, H, W, C; const float* x; void* out; } pd_im2col3_args;

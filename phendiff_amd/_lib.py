@@ -132,6 +132,10 @@ class PackWeightArgs(C.Structure):
                 ("dst_ct_stride", C.c_longlong)]
 
 
+class PackWeightBatchArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("n", C.c_int), ("jobs", vp), ("starts", vp), ("total_blocks", C.c_int), ("max_ksize", C.c_int)]
+
+
 class Im2col3Args(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("x", vp), ("out", vp)]
 
@@ -277,6 +281,7 @@ SYMBOLS = {
     "pd_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
+    "pd_pack_weight_batch": (C.c_int, [C.POINTER(PackWeightBatchArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
     "pd_attn_d64": (C.c_int, [C.POINTER(AttnD64Args), vp]),
     "pd_token_wgrad": (C.c_int, [C.POINTER(TokenWgradArgs), vp]),

@@ -296,13 +296,13 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ 
 // OIHW fp32 master weights -> pd_conv's packed fragment order [ct][chunk][tap][s][lane][j] (packing.py), optionally as the
 // input-gradient weights W'[ci][co][K-1-ky][K-1-kx]; thread = one 8-element lane fragment
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const pd_pack_weight_args a) {
+__device__ __forceinline__ void pack_weight_block(const pd_pack_weight_args& a, int block, float* tile) {
   // workgroup = one (32-co tile, 32-ci chunk) of the packed matrix, all taps: the 32 x 32 x taps source block is read as 32
   // contiguous runs (coalesced), staged in LDS, and every lane fragment is gathered from there
-  extern __shared__ float tile[];                      // [row o][col i * taps + t], row pitch 32*taps + 1
+  // tile: [row o][col i * taps + t], row pitch 32*taps + 1
   const int taps = a.ksize * a.ksize;
   const int chunks = a.cin_pad / 32;
-  const int ct = blockIdx.x / chunks, chunk = blockIdx.x - ct * chunks;
+  const int ct = block / chunks, chunk = block - ct * chunks;
   const int tid = threadIdx.x;
   const int run = 32 * taps, pitch = run + 1;
   // source block: forward rows o = co (ct), cols i = ci (chunk); input-gradient rows o = ci (chunk), cols i = co (ct)
@@ -328,6 +328,25 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const pd_pack_weight_a
     T* dst = (T*)a.dst + (size_t)ct * a.dst_ct_stride + ((((size_t)chunk * taps + tap) * 2 + sidx) * 64 + lane) * 8;
     Elem<T>::store(dst, Elem<T>::pack(v));
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const pd_pack_weight_args a) {
+  extern __shared__ float tile[];
+  pack_weight_block<T>(a, blockIdx.x, tile);
+}
+// every re-pack of an optimizer step as ONE launch: block b belongs to job j with starts[j] <= b < starts[j+1] (binary search
+// over <= a few hundred jobs), its descriptor is read from device memory
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const pd_pack_weight_args* jobs, const int* starts, int n) {
+  extern __shared__ float tile[];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n;                                  // invariant: starts[lo] <= b < starts[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (starts[mid] <= b) lo = mid; else hi = mid;
+  }
+  const pd_pack_weight_args a = jobs[lo];
+  pack_weight_block<T>(a, b - starts[lo], tile);
 }
 
 static int pick_splits(int ntiles, int ncombo) {
@@ -437,6 +456,20 @@ extern "C" int pd_im2col3(const pd_im2col3_args* a, void* stream) {
   if (a->dtype == PD_F32) hipLaunchKernelGGL(im2col3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (float*)a->out, a->B, a->H, a->W, a->C);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(im2col3_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (bf16_t*)a->out, a->B, a->H, a->W, a->C);
   else { set_error("pd_im2col3: bad dtype"); return PD_ERR_ARG; }
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+extern "C" int pd_pack_weight_batch(const pd_pack_weight_batch_args* a, void* stream) {
+  PD_CHECK(a != nullptr && a->jobs && a->starts && a->n > 0 && a->total_blocks > 0 && a->max_ksize >= 1, PD_ERR_ARG, "pd_pack_weight_batch: bad args");
+  const size_t lds = (size_t)32 * (32 * a->max_ksize * a->max_ksize + 1) * sizeof(float);
+  PD_CHECK(lds <= 64 * 1024, PD_ERR_SHAPE, "pd_pack_weight_batch: max_ksize %d", a->max_ksize);
+  const dim3 grid((unsigned)a->total_blocks);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == PD_F32) hipLaunchKernelGGL(pack_weight_batch_kernel<float>, grid, dim3(256), lds, st, a->jobs, a->starts, a->n);
+  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, grid, dim3(256), lds, st, a->jobs, a->starts, a->n);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(pack_weight_batch_kernel<half_t>, grid, dim3(256), lds, st, a->jobs, a->starts, a->n);
+  else { set_error("pd_pack_weight_batch: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

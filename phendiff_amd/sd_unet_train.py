@@ -22,7 +22,7 @@ from .packing import dgrad_weight, pack_conv_weight
 from .sd_unet import (CustomEmbedding, SDUNet2DConditionModel, SDUNetPlan, _SDPackedWeights, _Transformer2D,
                       class_emb_to_encoder_hidden_states)
 from .unet import _Resnet, _Sampler, _copy_into
-from .unet_train import UNetTrainer, UNetTrainPlan, _contiguous_after
+from .unet_train import UNetTrainer, UNetTrainPlan, _contiguous_after, run_pack_jobs
 
 EMB_NAME = "class_embedding.inner_module.weight"
 
@@ -259,6 +259,7 @@ class _SDRepacker:
     def __init__(self, m: SDUNet2DConditionModel, w: _SDPackedWeights, tw: SDTrainWeights):
         self.lib = L.lib()
         self.jobs, self.small = [], []
+        self.jobs_device = m.conv_in.weight.device
         code = w.code
 
         def job(dst, src, cout, cin, k, *, dgrad=0, cout_pad=None, cin_pad=None, ct_stride=None, dst_off=0):
@@ -335,11 +336,7 @@ class _SDRepacker:
                                    "after the parameters were moved into the flat training buffer)")
 
     def run(self, stream):
-        byref, check, fn = C.byref, L.check, self.lib.pd_pack_weight
-        for a in self.jobs:
-            rc = fn(byref(a), stream)
-            if rc:
-                check(rc, "pd_pack_weight")
+        run_pack_jobs(self.lib, self.jobs, stream, self.__dict__.setdefault("_batch", {}), self.jobs_device)
         with torch.no_grad():
             for f in self.small:
                 f()

@@ -529,6 +529,31 @@ def plan_grad_buckets(sizes: List[int], ready: List[int], bucket_elems: int) -> 
     return sorted(out, key=lambda b: b[2])
 
 
+def run_pack_jobs(lib, jobs, stream, cache, device):
+    """All ``pd_pack_weight`` jobs of an optimizer step as ONE ``pd_pack_weight_batch`` launch: the descriptors are uploaded
+    once (``cache``: a dict owned by the re-packer) next to the block-range table the kernel searches."""
+    if not jobs:
+        return
+    st = cache.get("batch")
+    if st is None:
+        n = len(jobs)
+        for a in jobs:     # what pd_pack_weight would refuse
+            if a.cout_pad % 32 or a.cin_pad % 32 or a.cout_pad < a.cout or a.cin_pad < a.cin or a.dtype != jobs[0].dtype:
+                raise L.PhenDiffHipError("pd_pack_weight_batch: inconsistent job descriptors")
+        raw = (L.PackWeightArgs * n)(*jobs)
+        dev = torch.device(device)
+        table = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(dev)
+        starts, tot = [0], 0
+        for a in jobs:
+            tot += (a.cout_pad // 32) * (a.cin_pad // 32)
+            starts.append(tot)
+        starts_t = torch.tensor(starts, dtype=torch.int32, device=dev)
+        args = L.PackWeightBatchArgs(dtype=jobs[0].dtype, n=n, jobs=table.data_ptr(), starts=starts_t.data_ptr(), total_blocks=tot,
+                                     max_ksize=max(a.ksize for a in jobs))
+        st = cache["batch"] = (args, table, starts_t)
+    L.check(lib.pd_pack_weight_batch(C.byref(st[0]), stream), "pd_pack_weight_batch")
+
+
 class _Repacker:
     """After an optimizer step: fp32 master parameters -> every kernel-layout copy the plans read (``_PackedWeights`` and
     ``TrainWeights`` tensors, IN PLACE), as ``pd_pack_weight`` launches plus a handful of small fp32 copies.  Parameters
@@ -538,6 +563,7 @@ class _Repacker:
     def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, tw: TrainWeights):
         self.lib = L.lib()
         self.jobs, self.small = [], []
+        self.jobs_device = m.conv_in.weight.device
         code = w.code
 
         def job(dst, src, cout, cin, k, *, dgrad=0, cout_pad=None, cin_pad=None, src_in=None, ct_stride=None, dst_off=0):
@@ -608,11 +634,7 @@ class _Repacker:
                                    "after the parameters were moved into the flat training buffer)")
 
     def run(self, stream):
-        byref, check, fn = C.byref, L.check, self.lib.pd_pack_weight
-        for a in self.jobs:
-            rc = fn(byref(a), stream)
-            if rc:
-                check(rc, "pd_pack_weight")
+        run_pack_jobs(self.lib, self.jobs, stream, self.__dict__.setdefault("_batch", {}), self.jobs_device)
         with torch.no_grad():
             for f in self.small:
                 f()

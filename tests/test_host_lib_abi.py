@@ -38,7 +38,8 @@ def test_struct_field_order_matches_header():
              "pd_ddim_step_args": L.DdimStepArgs, "pd_add_noise_args": L.AddNoiseArgs, "pd_postproc_args": L.PostprocArgs,
              "pd_attn_d64_args": L.AttnD64Args, "pd_attn_wide_args": L.AttnWideArgs, "pd_latent_sample_args": L.LatentSampleArgs,
              "pd_attn_d64_bwd_args": L.AttnD64BwdArgs, "pd_layernorm_bwd_args": L.LayerNormBwdArgs,
-             "pd_geglu_bwd_args": L.GegluBwdArgs, "pd_linear_args": L.LinearArgs, "pd_gn_apply_args": L.GnApplyArgs, "pd_token_wgrad_args": L.TokenWgradArgs, "pd_layernorm_args": L.LayerNormArgs, "pd_geglu_args": L.GegluArgs}
+             "pd_geglu_bwd_args": L.GegluBwdArgs, "pd_linear_args": L.LinearArgs, "pd_gn_apply_args": L.GnApplyArgs, "pd_token_wgrad_args": L.TokenWgradArgs, "pd_layernorm_args": L.LayerNormArgs, "pd_geglu_args": L.GegluArgs,
+             "pd_pack_weight_args": L.PackWeightArgs, "pd_pack_weight_batch_args": L.PackWeightBatchArgs, "pd_zero_args": L.ZeroArgs}
     for cname, cls in pairs.items():
         body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + ";", src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
