@@ -874,7 +874,7 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
   if (lds_pad > 0 && a->dtype == PD_BF16 && wide) {
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute((const void*)attn_kernel<bf16_t, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+      (void)hipFuncSetAttribute((const void*)attn_kernel<bf16_t, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
       attr_set = true;
     }
     hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), lds_pad, st, *a);

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
 //   xhat = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ res]
 // The grid is fixed-size; every wave walks a strided set of tokens and keeps its share of dgamma = sum dy xhat and
 // dbeta = sum dy in registers; per-workgroup partials go to a workspace and are summed in a fixed order by a second kernel.
-constexpr int LN_MAXP = 4;                             // C <= 64 lanes * 8 * 4 = 2048
+[[maybe_unused]] constexpr int LN_MAXP = 4;                             // C <= 64 lanes * 8 * 4 = 2048
 
 // NP = 8-element pieces per lane (C <= 512 * NP): narrow rows keep few registers, so more waves hide the three dependent
 // reductions per token
