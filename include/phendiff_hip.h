@@ -166,6 +166,9 @@ typedef struct {
   const float* gamma; const float* beta;
   float* scale; float* shift;          /* out [B][C0+C1] */
   float* mean; float* rstd;            /* optional out [B][groups] (kept for the backward, pd_gn_silu_bwd), or NULL */
+  const float* temb; int temb_stride;  /* optional: ResnetBlock2D time_embedding_norm = "scale_shift" (cond_unet_2d.py:103,180):
+                                          row n = temb + n*temb_stride holds [scale | shift] (2*(C0+C1) floats, this resnet's
+                                          time_emb_proj(SiLU(emb))); the written affine becomes GN(x)*(1 + scale) + shift */
 } pd_gn_finalize_args;
 int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream);
 

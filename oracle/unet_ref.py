@@ -79,13 +79,19 @@ class TimestepEmbeddingRef(nn.Module):
 
 
 class ResnetBlock2DRef(nn.Module):
-    """Appendix A.3 (time_embedding_norm="default", output_scale_factor=1, dropout=0)."""
+    """Appendix A.3 (output_scale_factor=1, dropout=0).  ``time_embedding_norm``: "default" adds the projected embedding after
+    conv1; "scale_shift" (``resnet_time_scale_shift``, cond_unet_2d.py:103,180,191,225) projects to 2*out channels and applies
+    ``GN2(h) * (1 + scale) + shift`` instead."""
 
-    def __init__(self, in_channels, out_channels, temb_channels, groups, eps, output_scale_factor=1.0):
+    def __init__(self, in_channels, out_channels, temb_channels, groups, eps, output_scale_factor=1.0,
+                 time_embedding_norm="default"):
         super().__init__()
+        if time_embedding_norm not in ("default", "scale_shift"):
+            raise ValueError(f"unknown time_embedding_norm {time_embedding_norm}")
+        self.time_embedding_norm = time_embedding_norm
         self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps, affine=True)
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
-        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels * (2 if time_embedding_norm == "scale_shift" else 1))
         self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps, affine=True)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
@@ -93,8 +99,13 @@ class ResnetBlock2DRef(nn.Module):
 
     def forward(self, x, temb):
         h = self.conv1(F.silu(self.norm1(x)))
-        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        t = self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        if self.time_embedding_norm == "default":
+            h = self.norm2(h + t)
+        else:
+            scale, shift = torch.chunk(t, 2, dim=1)
+            h = self.norm2(h) * (1 + scale) + shift
+        h = self.conv2(F.silu(h))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return (x + h) / self.output_scale_factor
@@ -155,10 +166,11 @@ class Upsample2DRef(nn.Module):
 
 class DownBlockRef(nn.Module):
     def __init__(self, in_ch, out_ch, temb_ch, num_layers, groups, eps, add_downsample, downsample_padding,
-                 attn_head_dim=None):
+                 attn_head_dim=None, tnorm="default"):
         super().__init__()
         self.resnets = nn.ModuleList(
-            [ResnetBlock2DRef(in_ch if i == 0 else out_ch, out_ch, temb_ch, groups, eps) for i in range(num_layers)])
+            [ResnetBlock2DRef(in_ch if i == 0 else out_ch, out_ch, temb_ch, groups, eps, time_embedding_norm=tnorm)
+             for i in range(num_layers)])
         self.attentions = None
         if attn_head_dim is not None:
             self.attentions = nn.ModuleList(
@@ -179,9 +191,9 @@ class DownBlockRef(nn.Module):
 
 
 class MidBlockRef(nn.Module):
-    def __init__(self, ch, temb_ch, groups, eps, attn_head_dim, add_attention=True):
+    def __init__(self, ch, temb_ch, groups, eps, attn_head_dim, add_attention=True, tnorm="default"):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2DRef(ch, ch, temb_ch, groups, eps) for _ in range(2)])
+        self.resnets = nn.ModuleList([ResnetBlock2DRef(ch, ch, temb_ch, groups, eps, time_embedding_norm=tnorm) for _ in range(2)])
         self.attentions = nn.ModuleList(
             [AttentionRef(ch, ch // attn_head_dim, groups, eps) if add_attention else None])
 
@@ -193,13 +205,14 @@ class MidBlockRef(nn.Module):
 
 
 class UpBlockRef(nn.Module):
-    def __init__(self, in_ch, prev_out_ch, out_ch, temb_ch, num_layers, groups, eps, add_upsample, attn_head_dim=None):
+    def __init__(self, in_ch, prev_out_ch, out_ch, temb_ch, num_layers, groups, eps, add_upsample, attn_head_dim=None,
+                 tnorm="default"):
         super().__init__()
         rs = []
         for i in range(num_layers):
             res_skip = in_ch if i == num_layers - 1 else out_ch
             res_in = prev_out_ch if i == 0 else out_ch
-            rs.append(ResnetBlock2DRef(res_in + res_skip, out_ch, temb_ch, groups, eps))
+            rs.append(ResnetBlock2DRef(res_in + res_skip, out_ch, temb_ch, groups, eps, time_embedding_norm=tnorm))
         self.resnets = nn.ModuleList(rs)
         self.attentions = None
         if attn_head_dim is not None:
@@ -228,22 +241,36 @@ class CondUNet2DRef(nn.Module):
                  down_block_types=("DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"),
                  up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
                  attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, num_class_embeds=None,
-                 flip_sin_to_cos=True, freq_shift=0, downsample_padding=1, add_attention=True):
+                 flip_sin_to_cos=True, freq_shift=0, downsample_padding=1, add_attention=True,
+                 center_input_sample=False, class_embed_type=None, resnet_time_scale_shift="default",
+                 time_embedding_type="positional"):
         super().__init__()
+        if time_embedding_type != "positional":
+            raise NotImplementedError("oracle: positional time embedding only (GaussianFourierProjection takes log(t): no shipped config)")
+        if class_embed_type not in (None, "timestep", "identity"):
+            raise ValueError(f"unknown class_embed_type {class_embed_type}")
         self.config = SimpleNamespace(
             sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
             block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
             down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
             attention_head_dim=attention_head_dim, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
             num_class_embeds=num_class_embeds, flip_sin_to_cos=flip_sin_to_cos, freq_shift=freq_shift,
-            downsample_padding=downsample_padding, center_input_sample=False, class_embed_type=None,
-            time_embedding_type="positional")
+            downsample_padding=downsample_padding, center_input_sample=center_input_sample, class_embed_type=class_embed_type,
+            time_embedding_type=time_embedding_type, resnet_time_scale_shift=resnet_time_scale_shift)
+        tn = resnet_time_scale_shift
         boc = list(block_out_channels)
         ted = boc[0] * 4
         self.time_embed_dim = ted  # cond_unet_2d.py:111-113
         self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)  # :127-129
         self.time_embedding = TimestepEmbeddingRef(boc[0], ted)  # :143
-        self.class_embedding = nn.Embedding(num_class_embeds, ted) if num_class_embeds is not None else None  # :146-147
+        if class_embed_type is None and num_class_embeds is not None:  # :146-153
+            self.class_embedding = nn.Embedding(num_class_embeds, ted)
+        elif class_embed_type == "timestep":
+            self.class_embedding = TimestepEmbeddingRef(boc[0], ted)
+        elif class_embed_type == "identity":
+            self.class_embedding = nn.Identity()
+        else:
+            self.class_embedding = None
         g, eps = norm_num_groups, norm_eps
         self.down_blocks = nn.ModuleList()
         out_ch = boc[0]
@@ -252,9 +279,9 @@ class CondUNet2DRef(nn.Module):
             final = i == len(boc) - 1
             hd = (attention_head_dim if attention_head_dim is not None else out_ch) if t == "AttnDownBlock2D" else None
             self.down_blocks.append(DownBlockRef(in_ch, out_ch, ted, layers_per_block, g, eps, not final,
-                                                 downsample_padding, hd))
+                                                 downsample_padding, hd, tn))
         mid_hd = attention_head_dim if attention_head_dim is not None else boc[-1]
-        self.mid_block = MidBlockRef(boc[-1], ted, g, eps, mid_hd, add_attention)  # :185-197
+        self.mid_block = MidBlockRef(boc[-1], ted, g, eps, mid_hd, add_attention, tn)  # :185-197
         self.up_blocks = nn.ModuleList()
         rev = list(reversed(boc))
         out_ch = rev[0]
@@ -263,7 +290,7 @@ class CondUNet2DRef(nn.Module):
             in_ch = rev[min(i + 1, len(boc) - 1)]
             final = i == len(boc) - 1
             hd = (attention_head_dim if attention_head_dim is not None else out_ch) if t == "AttnUpBlock2D" else None
-            self.up_blocks.append(UpBlockRef(in_ch, prev, out_ch, ted, layers_per_block + 1, g, eps, not final, hd))
+            self.up_blocks.append(UpBlockRef(in_ch, prev, out_ch, ted, layers_per_block + 1, g, eps, not final, hd, tn))
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)  # :236-238
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)  # :240-242
 
@@ -289,6 +316,8 @@ class CondUNet2DRef(nn.Module):
         if self.class_embedding is not None:
             if class_labels is None and class_emb is None:
                 raise ValueError("either class_labels or class_emb should be provided when doing class conditioning")
+            if c.class_embed_type == "timestep":  # :301-302: the labels go through the sinusoid first
+                class_labels = timestep_embedding_ref(class_labels, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift)
             if class_emb is None:
                 class_emb = self.class_embedding(class_labels).to(self.dtype)
             emb = emb + class_emb
@@ -297,6 +326,8 @@ class CondUNet2DRef(nn.Module):
     def forward(self, sample, timestep, class_labels=None, class_emb=None, return_dict=True):
         if class_labels is not None and class_emb is not None:
             raise ValueError("Cannot specify both class_labels and class_emb")
+        if self.config.center_input_sample:  # :272-273
+            sample = 2 * sample - 1.0
         emb = self.embed(sample.shape[0], timestep, class_labels, class_emb)
         sample = self.conv_in(sample)
         skips = (sample,)

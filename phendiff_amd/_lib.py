@@ -79,7 +79,8 @@ class ConvArgs(C.Structure):
 class GnFinalizeArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("HW", C.c_int), ("groups", C.c_int), ("eps", C.c_float),
                 ("C0", C.c_int), ("T0", C.c_int), ("stats0", vp), ("C1", C.c_int), ("T1", C.c_int), ("stats1", vp),
-                ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("rstd", vp)]
+                ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("rstd", vp),
+                ("temb", vp), ("temb_stride", C.c_int)]
 
 
 class GnBwdArgs(C.Structure):

@@ -145,6 +145,19 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const pd_conv_in_args a) {
 // pd_gn_stats: (1) per-channel partial sums over a pixel slice, coalesced 8-channel pieces, fp32 per
 // thread then fp64 combine; (2) finalize: group moments in fp64 -> per-(sample, channel) scale / shift.
 // ================================================================================================
+// ResnetBlock2D(time_embedding_norm = "scale_shift"): y = GN(x) * (1 + s) + t with [s | t] = this resnet's time_emb_proj row --
+// folded into the per-(sample, channel) affine the consumer applies: (x*sc + sh)*(1 + s) + t
+__device__ __forceinline__ void gn_write_affine(const pd_gn_finalize_args& a, int n, int C, int c, float sc, float sh) {
+  if (a.temb) {
+    const float* row = a.temb + (size_t)n * a.temb_stride;
+    const float s = 1.0f + row[c];
+    sc *= s;
+    sh = sh * s + row[C + c];
+  }
+  a.scale[(size_t)n * C + c] = sc;
+  a.shift[(size_t)n * C + c] = sh;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const pd_gn_stats_args a) {
   using E = Elem<T>;
@@ -268,8 +281,7 @@ __global__ __launch_bounds__(1024) void gn_finalize2_kernel(const pd_gn_finalize
   for (int c = c_lo + tid; c < c_hi; c += 1024) {
     const int g = c / gs - g_lo;
     const float sc = rstd_s[g] * a.gamma[c];
-    a.scale[(size_t)n * C + c] = sc;
-    a.shift[(size_t)n * C + c] = a.beta[c] - mean_s[g] * sc;
+    gn_write_affine(a, n, C, c, sc, a.beta[c] - mean_s[g] * sc);
   }
 }
 
@@ -321,8 +333,7 @@ __global__ __launch_bounds__(1024) void gn_finalize3_kernel(const pd_gn_finalize
     const int cc = c_lo + tid;
     const int g = tid / gs;
     const float sc = rstd_s[g] * a.gamma[cc];
-    a.scale[(size_t)n * C + cc] = sc;
-    a.shift[(size_t)n * C + cc] = a.beta[cc] - mean_s[g] * sc;
+    gn_write_affine(a, n, C, cc, sc, a.beta[cc] - mean_s[g] * sc);
   }
 }
 
@@ -466,6 +477,7 @@ extern "C" int pd_gn_finalize(const pd_gn_finalize_args* a, void* stream) {
   PD_CHECK(a->stats0 && a->gamma && a->beta && a->scale && a->shift, PD_ERR_ARG, "pd_gn_finalize: null pointer");
   PD_CHECK((a->C1 == 0) == (a->stats1 == nullptr) && (a->C1 == 0 || a->T1 > 0), PD_ERR_ARG, "pd_gn_finalize: stats1/C1 mismatch");
   PD_CHECK((a->mean == nullptr) == (a->rstd == nullptr), PD_ERR_ARG, "pd_gn_finalize: mean/rstd must be given together");
+  PD_CHECK(a->temb == nullptr || a->temb_stride >= 2 * C, PD_ERR_ARG, "pd_gn_finalize: temb_stride must cover the [scale | shift] row (2*C)");
   const int gs = C / a->groups;
   PD_CHECK(gs <= 1024, PD_ERR_SHAPE, "pd_gn_finalize: %d channels per group", gs);
   if (gs <= 16) {

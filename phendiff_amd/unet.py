@@ -41,11 +41,12 @@ class _TimestepEmbedding(nn.Module):
 
 
 class _Resnet(nn.Module):
-    def __init__(self, cin, cout, tdim, groups, eps):
+    def __init__(self, cin, cout, tdim, groups, eps, scale_shift=False):
         super().__init__()
+        self.scale_shift = scale_shift          # resnet_time_scale_shift = "scale_shift": the projection is [scale | shift]
         self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
         self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
-        self.time_emb_proj = nn.Linear(tdim, cout)
+        self.time_emb_proj = nn.Linear(tdim, cout * (2 if scale_shift else 1))
         self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
@@ -77,22 +78,22 @@ class _Block(nn.Module):
         super().__init__()
 
 
-def _down_block(cin, cout, tdim, n, groups, eps, add_down, down_pad, head_dim):
+def _down_block(cin, cout, tdim, n, groups, eps, add_down, down_pad, head_dim, ss=False):
     b = _Block()
-    b.resnets = nn.ModuleList([_Resnet(cin if i == 0 else cout, cout, tdim, groups, eps) for i in range(n)])
+    b.resnets = nn.ModuleList([_Resnet(cin if i == 0 else cout, cout, tdim, groups, eps, ss) for i in range(n)])
     if head_dim is not None:
         b.attentions = nn.ModuleList([_Attention(cout, cout // head_dim, groups, eps) for _ in range(n)])
     b.downsamplers = nn.ModuleList([_Sampler(cout, 2, down_pad)]) if add_down else None
     return b
 
 
-def _up_block(cin, prev, cout, tdim, n, groups, eps, add_up, head_dim):
+def _up_block(cin, prev, cout, tdim, n, groups, eps, add_up, head_dim, ss=False):
     b = _Block()
     rs = []
     for i in range(n):
         skip = cin if i == n - 1 else cout
         rin = prev if i == 0 else cout
-        rs.append(_Resnet(rin + skip, cout, tdim, groups, eps))
+        rs.append(_Resnet(rin + skip, cout, tdim, groups, eps, ss))
     b.resnets = nn.ModuleList(rs)
     if head_dim is not None:
         b.attentions = nn.ModuleList([_Attention(cout, cout // head_dim, groups, eps) for _ in range(n)])
@@ -100,9 +101,9 @@ def _up_block(cin, prev, cout, tdim, n, groups, eps, add_up, head_dim):
     return b
 
 
-def _mid_block(ch, tdim, groups, eps, head_dim, add_attention):
+def _mid_block(ch, tdim, groups, eps, head_dim, add_attention, ss=False):
     b = _Block()
-    b.resnets = nn.ModuleList([_Resnet(ch, ch, tdim, groups, eps) for _ in range(2)])
+    b.resnets = nn.ModuleList([_Resnet(ch, ch, tdim, groups, eps, ss) for _ in range(2)])
     b.attentions = nn.ModuleList([_Attention(ch, ch // head_dim, groups, eps) if add_attention else None])
     return b
 
@@ -139,10 +140,13 @@ class CustomCondUNet2DModel(nn.Module):
         if len(c.block_out_channels) != len(c.down_block_types):  # :121-124
             raise ValueError("Must provide the same number of `block_out_channels` as `down_block_types`.")
         # what the HIP path implements (everything the shipped configs use)
-        if c.time_embedding_type != "positional" or c.class_embed_type is not None or c.act_fn != "silu" \
-                or c.resnet_time_scale_shift != "default" or c.center_input_sample or c.mid_block_scale_factor != 1:
-            raise NotImplementedError("phendiff_amd: only positional time embedding / nn.Embedding class conditioning / "
-                                      "silu / default time-scale-shift are implemented on the HIP path")
+        if c.time_embedding_type != "positional" or c.act_fn != "silu" or c.mid_block_scale_factor != 1:
+            raise NotImplementedError("phendiff_amd: positional time embedding, silu and mid_block_scale_factor = 1 are what the HIP "
+                                      "path implements (no shipped config uses the fourier projection, other activations or a scale)")
+        if c.class_embed_type not in (None, "timestep", "identity"):
+            raise ValueError(f"unknown class_embed_type {c.class_embed_type}")
+        if c.resnet_time_scale_shift not in ("default", "scale_shift"):
+            raise ValueError(f"unknown resnet_time_scale_shift {c.resnet_time_scale_shift}")
         for t in c.down_block_types + c.up_block_types:
             if t not in ("DownBlock2D", "AttnDownBlock2D", "UpBlock2D", "AttnUpBlock2D"):
                 raise NotImplementedError(f"block type {t}")
@@ -158,7 +162,15 @@ class CustomCondUNet2DModel(nn.Module):
         g, eps = c.norm_num_groups, c.norm_eps
         self.conv_in = nn.Conv2d(c.in_channels, boc[0], 3, padding=1)
         self.time_embedding = _TimestepEmbedding(boc[0], tdim)
-        self.class_embedding = nn.Embedding(c.num_class_embeds, tdim) if c.num_class_embeds is not None else None
+        if c.class_embed_type is None and c.num_class_embeds is not None:      # cond_unet_2d.py:146-153
+            self.class_embedding = nn.Embedding(c.num_class_embeds, tdim)
+        elif c.class_embed_type == "timestep":
+            self.class_embedding = _TimestepEmbedding(boc[0], tdim)
+        elif c.class_embed_type == "identity":
+            self.class_embedding = nn.Identity()
+        else:
+            self.class_embedding = None
+        ss = c.resnet_time_scale_shift == "scale_shift"
         self.down_blocks = nn.ModuleList()
         out_ch = boc[0]
         for i, t in enumerate(c.down_block_types):
@@ -167,9 +179,9 @@ class CustomCondUNet2DModel(nn.Module):
             if t == "AttnDownBlock2D":
                 hd = c.attention_head_dim if c.attention_head_dim is not None else out_ch
             self.down_blocks.append(_down_block(in_ch, out_ch, tdim, c.layers_per_block, g, eps,
-                                                i != len(boc) - 1, c.downsample_padding, hd))
+                                                i != len(boc) - 1, c.downsample_padding, hd, ss))
         mid_hd = c.attention_head_dim if c.attention_head_dim is not None else boc[-1]
-        self.mid_block = _mid_block(boc[-1], tdim, g, eps, mid_hd, c.add_attention)
+        self.mid_block = _mid_block(boc[-1], tdim, g, eps, mid_hd, c.add_attention, ss)
         self.up_blocks = nn.ModuleList()
         rev = list(reversed(boc))
         out_ch = rev[0]
@@ -180,7 +192,7 @@ class CustomCondUNet2DModel(nn.Module):
             if t == "AttnUpBlock2D":
                 hd = c.attention_head_dim if c.attention_head_dim is not None else out_ch
             self.up_blocks.append(_up_block(in_ch, prev, out_ch, tdim, c.layers_per_block + 1, g, eps,
-                                            i != len(boc) - 1, hd))
+                                            i != len(boc) - 1, hd, ss))
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
@@ -284,7 +296,9 @@ class CustomCondUNet2DModel(nn.Module):
             return UNet2DOutput(sample=out) if return_dict else (out,)
         plan = self.plan_for(B, sample.shape[2], sample.shape[3], dev)
         x = sample.contiguous().to(torch.float32)
-        labels = class_labels.to(device=dev, dtype=torch.int64).contiguous() if class_labels is not None else None
+        labels = None
+        if class_labels is not None:      # nn.Embedding indices, or (class_embed_type timestep / identity) float values / rows
+            labels = class_labels.to(device=dev, dtype=torch.int64 if self.config.class_embed_type is None else torch.float32).contiguous()
         cemb = class_emb.to(device=dev, dtype=torch.float32).contiguous() if class_emb is not None else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         temb = plan.temb_rows(ts, labels, cemb, stream)
@@ -340,7 +354,13 @@ class _PackedWeights:
         te = m.time_embedding
         self.w1T, self.b1 = f32(te.linear_1.weight.t()), f32(te.linear_1.bias)
         self.w2T, self.b2 = f32(te.linear_2.weight.t()), f32(te.linear_2.bias)
-        self.class_table = f32(m.class_embedding.weight) if m.class_embedding is not None else None
+        self.class_table = f32(m.class_embedding.weight) if isinstance(m.class_embedding, nn.Embedding) else None
+        # class_embed_type: "timestep" = a second TimestepEmbedding over the sinusoid of the labels; "identity" = rows given as is
+        self.class_mode = m.config.class_embed_type
+        if self.class_mode == "timestep":
+            ce = m.class_embedding
+            self.cw1T, self.cb1 = f32(ce.linear_1.weight.t()), f32(ce.linear_1.bias)
+            self.cw2T, self.cb2 = f32(ce.linear_2.weight.t()), f32(ce.linear_2.bias)
         self.resnets = {}
         self.attns = {}
         self.samplers = {}
@@ -363,7 +383,8 @@ class _PackedWeights:
                 e.fused_shortcut = False
             e.eps = r.norm1.eps
             e.temb_off = off
-            off += e.cout
+            e.scale_shift = r.scale_shift
+            off += r.time_emb_proj.weight.shape[0]
             proj_w.append(r.time_emb_proj.weight.detach())
             proj_b.append(r.time_emb_proj.bias.detach())
             self.resnets[name] = e
@@ -468,7 +489,7 @@ class UNetPlan:
         return t
 
     # ---- op emitters -----------------------------------------------------------------------------
-    def _gn(self, x0, x1, gamma, beta, eps):
+    def _gn(self, x0, x1, gamma, beta, eps, temb_off=None):
         """GroupNorm(32) of [x0 | x1] -> per-(sample, channel) scale/shift, from the statistics the producers of x0 / x1
         emitted in their epilogues (no pass over the tensors)."""
         B, h, w, c0 = x0.shape
@@ -480,6 +501,9 @@ class UNetPlan:
         a = L.GnFinalizeArgs(B=self.B, HW=h * w, groups=self.groups, eps=eps, C0=c0, T0=t0, stats0=st0.data_ptr(),
                              C1=c1, T1=t1, stats1=L.ptr(st1), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
                              scale=scale.data_ptr(), shift=shift.data_ptr())
+        if temb_off is not None:      # scale_shift ResNets: this norm's affine is modulated by the step's [scale | shift] row
+            a.temb_stride = self.w.proj_dim
+            self._temb_ptr_fields.append((a, temb_off))
         if self.train:
             mean, rstd = self._f32(self.B, self.groups), self._f32(self.B, self.groups)
             a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
@@ -575,13 +599,17 @@ class UNetPlan:
         e = self.w.resnets[name]
         pre = e.cout >= self.PREAPPLY_MIN_COUT
         z1 = z2 = None
+        if e.scale_shift and self.train:
+            raise NotImplementedError("the backward plan implements resnet_time_scale_shift = 'default' only")
+        # "default": the projected embedding is added by conv1's epilogue; "scale_shift": it modulates norm2's affine instead
+        t1 = None if e.scale_shift else e.temb_off
         gn1 = self._gn(x0, x1, e.g1, e.be1, e.eps)
         if pre:
             z1 = self._gn_apply(x0, x1, gn1, 1)
-            h1, _ = self._conv(z1, None, e.w1, e.b1, e.cout, temb_off=e.temb_off)
+            h1, _ = self._conv(z1, None, e.w1, e.b1, e.cout, temb_off=t1)
         else:
-            h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=e.temb_off)
-        gn2 = self._gn(h1, None, e.g2, e.be2, e.eps)
+            h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=t1)
+        gn2 = self._gn(h1, None, e.g2, e.be2, e.eps, temb_off=e.temb_off if e.scale_shift else None)
         if pre:
             z2 = self._gn_apply(h1, None, gn2, 1)
         src, kw = (z2, dict()) if pre else (h1, dict(silu=1, gn=gn2))
@@ -689,8 +717,24 @@ class UNetPlan:
                                     w2=w.w2T.data_ptr(), b2=w.b2.data_ptr(), class_table=L.ptr(w.class_table),
                                     wp=w.wpT.data_ptr(), bp=w.bp.data_ptr())
         # conv_in (cond_unet_2d.py:127-129,313): NCHW fp32 sample -> NHWC, MFMA 1x1 conv over 32 im2col channels
-        a0, self._in_args = self._conv(None, None, w.conv_in_wv, w.conv_in_b, boc[0], ksize=1, pad=0,
-                                       im2col3=c.in_channels, src_shape=(B, H, W, 32))
+        self._in_field = "x0"
+        centered = None
+        if c.center_input_sample:      # cond_unet_2d.py:272-273: sample = 2 * sample - 1.0 (before conv_in's zero padding)
+            if self.train:
+                raise NotImplementedError("the backward plan does not implement center_input_sample")
+            centered = self._f32(B, c.in_channels, H, W)
+            self._center_const = (torch.ones_like(centered), torch.full((B,), 2.0, device=self.device), torch.full((B,), -1.0, device=self.device))
+            ones, two, neg = self._center_const
+            ca = L.AddNoiseArgs(numel=centered.numel(), per_sample=centered[0].numel(), velocity=0, x=None, noise=ones.data_ptr(),
+                                sa=two.data_ptr(), sb=neg.data_ptr(), out=centered.data_ptr())
+            self.ops.append(_Op(self.lib.pd_add_noise, ca, "center", 0.0, 2.0 * centered.numel() * 4))
+        a0, conv_in_args = self._conv(None, None, w.conv_in_wv, w.conv_in_b, boc[0], ksize=1, pad=0,
+                                      im2col3=c.in_channels, src_shape=(B, H, W, 32))
+        if centered is not None:
+            conv_in_args.x0 = centered.data_ptr()
+            self._in_args, self._in_field = ca, "x"
+        else:
+            self._in_args = conv_in_args
         self.ops[-1].what = "conv_in"
         self.ops[-1].flops = 2.0 * B * H * W * boc[0] * c.in_channels * 9
         self.ops[-1].bytes = B * H * W * (c.in_channels * 4 + boc[0] * (4 if self.code == L.PD_F32 else 2))
@@ -741,12 +785,38 @@ class UNetPlan:
             out = torch.empty((rows, self.w.proj_dim), dtype=torch.float32, device=self.device)
         a = self.temb_args
         a.rows = rows
-        if self.w.class_table is None:      # no class conditioning: labels / class_emb are ignored (cond_unet_2d.py:297-309)
+        w = self.w
+        if w.class_mode == "identity":        # class_embed_type = "identity": the "labels" ARE the embedding rows
+            if class_emb is None and labels is not None:
+                class_emb = labels.to(device=self.device, dtype=torch.float32).contiguous()
+            labels = None
+        elif w.class_mode == "timestep":      # labels -> sinusoid -> class_embedding (a second TimestepEmbedding), :301-305
+            if class_emb is None and labels is not None:
+                class_emb = self._class_rows_timestep(labels, rows, stream)
+            labels = None
+        elif w.class_table is None:           # no class conditioning: labels / class_emb are ignored (cond_unet_2d.py:297-309)
             labels = class_emb = None
+        self._temb_keep = (labels, class_emb)
         a.timesteps, a.labels, a.class_emb = ts.data_ptr(), L.ptr(labels), L.ptr(class_emb)
         a.emb, a.proj = None, out.data_ptr()
         L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
         return out
+
+    def _class_rows_timestep(self, labels, rows, stream):
+        """``class_embedding(time_proj(class_labels))`` through ``pd_temb`` with the class MLP's weights: its ``emb`` output is the
+        row block the main call adds (the projections it also computes land in a scratch table)."""
+        w, c = self.w, self.m.config
+        emb = torch.empty((rows, self.m.time_embed_dim), dtype=torch.float32, device=self.device)
+        scratch = torch.empty((rows, w.proj_dim), dtype=torch.float32, device=self.device)
+        vals = labels.to(device=self.device, dtype=torch.float32).contiguous()
+        a = L.TembArgs(rows=rows, c0=c.block_out_channels[0], tdim=self.m.time_embed_dim, proj_dim=w.proj_dim,
+                       flip_sin_to_cos=int(c.flip_sin_to_cos), freq_shift=float(c.freq_shift), num_classes=0,
+                       timesteps=vals.data_ptr(), labels=None, class_emb=None, w1=w.cw1T.data_ptr(), b1=w.cb1.data_ptr(),
+                       w2=w.cw2T.data_ptr(), b2=w.cb2.data_ptr(), class_table=None, wp=w.wpT.data_ptr(), bp=w.bp.data_ptr(),
+                       emb=emb.data_ptr(), proj=scratch.data_ptr())
+        L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
+        self._class_keep = (vals, scratch)
+        return emb
 
     def profile(self, x_ptr, temb_ptr, out_ptr, stream, reps=3):
         """Per-kernel-kind device time of one UNet evaluation, measured with HIP events recorded on the launch
@@ -785,7 +855,7 @@ class UNetPlan:
         """One UNet evaluation: NCHW fp32 at ``x_ptr`` -> NCHW fp32 prediction at ``out_ptr``; ``temb_ptr`` is the
         [B][proj_dim] fp32 table of this step.  Asynchronous, allocation-free."""
         if self._cur != (x_ptr, temb_ptr, out_ptr):
-            self._in_args.x0 = x_ptr
+            setattr(self._in_args, self._in_field, x_ptr)
             self._out_args.y = out_ptr
             for a, off in self._temb_ptr_fields:
                 a.temb = temb_ptr + 4 * off

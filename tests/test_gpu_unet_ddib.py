@@ -61,6 +61,52 @@ def test_unet_forward_super_small(mode, tol, size):
     assert rel(got2, ref2) < tol
 
 
+VARIANTS = [dict(center_input_sample=True), dict(resnet_time_scale_shift="scale_shift"), dict(class_embed_type="timestep"),
+            dict(class_embed_type="identity", num_class_embeds=None),
+            dict(center_input_sample=True, resnet_time_scale_shift="scale_shift", class_embed_type="timestep")]
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "+".join(sorted(v)))
+def test_unet_forward_config_variants(mode, tol, variant):
+    """The constructor switches of CustomCondUNet2DModel that no shipped config sets (cond_unet_2d.py:103,146-153,272-273,
+    301-302): ``center_input_sample`` (2x - 1 as one elementwise launch in front of conv_in), ``resnet_time_scale_shift =
+    "scale_shift"`` (the projected embedding modulates norm2's affine inside pd_gn_finalize instead of being added by conv1),
+    ``class_embed_type`` "timestep" (a second TimestepEmbedding over the sinusoid of the labels) and "identity" (rows as given)."""
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef
+    torch.manual_seed(11)
+    cfg = dict(P.UNET_CONFIGS["super_small"], sample_size=32, **variant)
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    r = CondUNet2DRef(**{k: v for k, v in cfg.items() if k in keys}).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype=mode, **cfg)
+    assert sum(p.numel() for p in m.parameters()) == sum(p.numel() for p in r.parameters())
+    m.load_state_dict(r.state_dict())
+    m = m.to("cuda:0")
+    x, labels = synth_batch(3, 32)
+    if variant.get("class_embed_type") == "identity":
+        labels = torch.randn(3, m.time_embed_dim, generator=torch.Generator().manual_seed(5))
+    elif variant.get("class_embed_type") == "timestep":
+        labels = torch.tensor([0.0, 1.0, 7.0])
+    for t in (2999, 17):
+        with torch.no_grad():
+            ref = r(x, t, class_labels=labels).sample
+        got = m(x.cuda(), t, class_labels=labels.cuda()).sample
+        assert rel(got, ref) < tol, (mode, variant, t)
+    # the same model through the DDIB transfer, eager and as one hipGraph (per-step embedding rows baked into the nodes)
+    if variant.get("class_embed_type") is None:
+        from oracle import DDIMSchedulerRef, ConditionalDDIMPipelineRef, ddib_ref
+        cfg = dict(P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+        ilab = synth_batch(3, 32)[1]
+        want, _ = ddib_ref(ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**cfg)), x, ilab, 1 - ilab, 2)
+        pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**cfg))
+        got = P.ddib(pipe, x.cuda(), ilab.cuda(), (1 - ilab).cuda(), 2)
+        assert rel(got, want) < (2e-5 if mode == "f32" else 2e-2)
+        runner = P.DDIBGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
+        got_g = runner.run(x.cuda(), ilab.cuda(), (1 - ilab).cuda()).images
+        assert np.array_equal(got_g.cpu().numpy(), got)
+
+
 def test_unet_forward_small_denoiser_f32():
     r, m = make_pair("small_denoiser_config", 32, "f32")
     x, labels = synth_batch(2, 32)

@@ -93,6 +93,29 @@ def test_pack_conv_weight_layout():
     assert pb.dtype == torch.bfloat16 and torch.equal(pb.float(), p.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("variant", [dict(center_input_sample=True), dict(resnet_time_scale_shift="scale_shift"),
+                                     dict(class_embed_type="timestep"), dict(class_embed_type="identity", num_class_embeds=None)],
+                         ids=lambda v: "+".join(sorted(v)))
+def test_config_variants_build_the_reference_module_tree(variant):
+    """Constructor switches no shipped config sets (cond_unet_2d.py:103,146-153,272-273): same parameters, names and default
+    init as the restated reference class; the switches the HIP path does not implement still refuse at construction."""
+    cfg = dict(P.UNET_CONFIGS["super_small"], **variant)
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    torch.manual_seed(0)
+    ref = CondUNet2DRef(**{k: v for k, v in cfg.items() if k in keys})
+    torch.manual_seed(0)
+    got = P.CustomCondUNet2DModel(**cfg)
+    rs, gs = ref.state_dict(), got.state_dict()
+    assert list(rs) == list(gs) and all(torch.equal(rs[k], gs[k]) for k in rs)
+    if "resnet_time_scale_shift" in variant:
+        assert got.down_blocks[0].resnets[0].time_emb_proj.weight.shape[0] == 2 * 64
+    for bad in (dict(time_embedding_type="fourier"), dict(act_fn="mish"), dict(mid_block_scale_factor=2)):
+        with pytest.raises(NotImplementedError):
+            P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], **bad))
+    with pytest.raises(ValueError):
+        P.CustomCondUNet2DModel(**dict(P.UNET_CONFIGS["super_small"], class_embed_type="projection"))
+
+
 @pytest.mark.parametrize("name", ["super_small", "small_denoiser_config"])
 def test_module_tree_matches_diffusers_names(name):
     keys = CondUNet2DRef.__init__.__code__.co_varnames
