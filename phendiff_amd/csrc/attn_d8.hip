@@ -69,6 +69,29 @@ template <typename T> struct AttnOps {
     if (h) { q.v[0] = (short)bits16(hi); q.v[1] = (short)bits16(mid); q.v[2] = (short)bits16(lo); }
     return -(fmaf(M_C0, Elem<T>::to_f(hi), Elem<T>::to_f(mid)) + Elem<T>::to_f(lo));
   }
+  // x as three T-precision terms: x ~= M_C0 * hi + mid + lo (24 / 33 mantissa bits for bf16 / fp16)
+  static __device__ __forceinline__ void split3(float x, T& hi, T& mid, T& lo) {
+    hi = Elem<T>::from_f(x * (1.0f / M_C0));
+    const float r1 = fmaf(-M_C0, Elem<T>::to_f(hi), x);
+    mid = Elem<T>::from_f(r1);
+    lo = Elem<T>::from_f(r1 - Elem<T>::to_f(mid));
+  }
+  // backward kernels: a per-row constant c rides in the same three k-slots (the other operand holds M_C0, 1, 1): product + c
+  static __device__ __forceinline__ void set_terms(QF& q, int h, float c) {
+    T hi, mid, lo;
+    split3(c, hi, mid, lo);
+    if (h) { q.v[0] = (short)bits16(hi); q.v[1] = (short)bits16(mid); q.v[2] = (short)bits16(lo); }
+  }
+  static __device__ __forceinline__ void set_ones(QF& q, int h) {
+    if (h) { q.v[0] = (short)bits16(Elem<T>::from_f(M_C0)); q.v[1] = (short)bits16(Elem<T>::from_f(1.0f)); q.v[2] = q.v[1]; }
+  }
+  static __device__ __forceinline__ void store_terms(unsigned char* row16, float c) {   // a 16-byte LDS row: [hi mid lo 0 0 0 0 0]
+    T t[8];
+    split3(c, t[0], t[1], t[2]);
+#pragma unroll
+    for (int i = 3; i < 8; ++i) t[i] = Elem<T>::from_f(0.0f);
+    *(s16x8*)row16 = *(const s16x8*)t;
+  }
   static __device__ __forceinline__ void init_const_slot(unsigned char* slot) {   // k-slots 8..15 of every K row
     T c[8];
 #pragma unroll
@@ -656,19 +679,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const pd_attn_bwd_args
   const float qscale = 0.35355339059327373f * 1.4426950408889634f;
 
   const int query = qb * 128 + wave * 32 + r, qc = min(query, N - 1);
-  const typename Ops::QF qf = Ops::load_q((const T*)a.q + (bh + qc) * 8, h, qscale);
-  const typename Ops::QF dof = Ops::load_q((const T*)a.dout + ((size_t)b * N + qc) * C + head * 8, h, 1.0f);
+  const typename Ops::QF qf0 = Ops::load_q((const T*)a.q + (bh + qc) * 8, h, qscale);
+  const typename Ops::QF dof0 = Ops::load_q((const T*)a.dout + ((size_t)b * N + qc) * C + head * 8, h, 1.0f);
   const typename Ops::QF of = Ops::load_q((const T*)a.o + ((size_t)b * N + qc) * C + head * 8, h, 1.0f);
-  float delta = Ops::dot(dof, of);
+  float delta = Ops::dot(dof0, of);
   delta += __shfl_xor(delta, 32);
   if (h == 0 && query < N) a.delta[bh + query] = delta;
-  const f32x16 negl = (f32x16)(-a.lse[bh + qc]);
-  const f32x16 negd = (f32x16)(-delta);
+  // -lse and -delta: in the C operand (fp32), or in the three spare k-slots of the two QK-shaped MFMAs (16-bit types: no
+  // 2 x 16-register constant blocks -> one more wave per SIMD)
+  constexpr bool SLOTS = !Ops::M_IN_C;
+  f32x16 negl = (f32x16)(0.f), negd = (f32x16)(0.f);
+  typename Ops::QF qf = qf0, dof = dof0;
+  if constexpr (SLOTS) { Ops::set_terms(qf, h, -a.lse[bh + qc]); Ops::set_terms(dof, h, -delta); }
+  else { negl = (f32x16)(-a.lse[bh + qc]); negd = (f32x16)(-delta); }
   f32x16 dq = (f32x16)(0.f);
 
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
-    if (tid == 0) { *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f); *(f32x4*)(vlds[b2] + KT * KROW) = (f32x4)(0.f); }
+    if (tid == 0) {
+      *(f32x4*)(klds[b2] + KT * KROW) = (f32x4)(0.f); *(f32x4*)(vlds[b2] + KT * KROW) = (f32x4)(0.f);
+      if constexpr (SLOTS) { Ops::init_const_slot(klds[b2] + KT * KROW); Ops::init_const_slot(vlds[b2] + KT * KROW); }
+    }
     *(T*)(ktlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
   }
   const int vrow_off = (r < 8 ? r : 8) * Ops::VT_PITCH + Ops::vlane_off(h);   // A rows 8..31: the zero row
@@ -734,11 +765,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_arg
   using Ops = AttnOps<T>;
   constexpr int KROW = Ops::KROW;
   constexpr int QT = sizeof(T) == 4 ? 128 : 256;       // queries per LDS tile (fp32 validation mode: LDS budget)
-  __shared__ __attribute__((aligned(16))) unsigned char qlds[2][QT * KROW + 16];
-  __shared__ __attribute__((aligned(16))) unsigned char dolds[2][QT * KROW + 16];
+  // 16-bit types: every Q / dO row is followed (QT rows later) by a 16-byte extension row [hi mid lo 0 ...] = -lse / -delta of
+  // that query in three T-precision terms: k-slots 8..10 of the A operand, against (M_C0, 1, 1) in K / V -- the per-row constants
+  // ride in the MFMA instead of a 16-register C block assembled from eight LDS reads per sub-tile (161 -> fewer registers:
+  // one more wave per SIMD).  fp32: the C-operand form (nl / nd).
+  constexpr bool SLOTS = !Ops::M_IN_C;
+  constexpr int ROWS = SLOTS ? 2 * QT * KROW : QT * KROW + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char qlds[2][ROWS];
+  __shared__ __attribute__((aligned(16))) unsigned char dolds[2][ROWS];
   __shared__ __attribute__((aligned(16))) unsigned char qtlds[2][9 * Ops::VT_PITCH];
   __shared__ __attribute__((aligned(16))) unsigned char dotlds[2][9 * Ops::VT_PITCH];
-  __shared__ __attribute__((aligned(16))) float nl[2][QT], nd[2][QT];
+  __shared__ __attribute__((aligned(16))) float nl[2][SLOTS ? 4 : QT], nd[2][SLOTS ? 4 : QT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -757,11 +794,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_arg
   const int key = kb * 128 + wave * 32 + r, kc = min(key, N - 1);
   typename Ops::QF kfr = Ops::load_q((const T*)a.k + (bh + kc) * 8, h, 1.0f);
   typename Ops::QF vfr = Ops::load_q((const T*)a.v + (bh + kc) * 8, h, 1.0f);
+  if constexpr (SLOTS) { Ops::set_ones(kfr, h); Ops::set_ones(vfr, h); }
   f32x16 dk = (f32x16)(0.f), dv = (f32x16)(0.f);
 
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
-    if (tid == 0) { *(f32x4*)(qlds[b2] + QT * KROW) = (f32x4)(0.f); *(f32x4*)(dolds[b2] + QT * KROW) = (f32x4)(0.f); }
+    if constexpr (!SLOTS) {
+      if (tid == 0) { *(f32x4*)(qlds[b2] + QT * KROW) = (f32x4)(0.f); *(f32x4*)(dolds[b2] + QT * KROW) = (f32x4)(0.f); }
+    }
     if (tid < QT) {
       *(T*)(qtlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
       *(T*)(dotlds[b2] + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
@@ -769,8 +809,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_arg
   }
   const int vrow_off = (r < 8 ? r : 8) * Ops::VT_PITCH + Ops::vlane_off(h);   // A rows 8..31: the zero row
   // K-row style addressing of the Q / dO row images; the bf16 zero slot sits after QT rows here
-  const int ka0 = (sizeof(T) == 2 && h) ? QT * KROW : Ops::kaddr(r, h);
-  const int kst = Ops::kstep(h);
+  const int ka0 = SLOTS ? (h ? QT * KROW + r * KROW : r * KROW) : Ops::kaddr(r, h);      // h == 1: the extension rows
+  const int kst = SLOTS ? 32 * KROW : Ops::kstep(h);
 
   typename E::Frag stq, stdo;
   float stl = 0.f, std_ = 0.f;
@@ -798,19 +838,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_arg
         *(T*)(qtlds[b2] + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(qv[d]);
         *(T*)(dotlds[b2] + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(dv_[d]);
       }
-      nl[b2][tid] = stl; nd[b2][tid] = std_;
+      if constexpr (SLOTS) {
+        Ops::store_terms(qlds[b2] + (QT + tid) * KROW, stl);
+        Ops::store_terms(dolds[b2] + (QT + tid) * KROW, std_);
+      } else { nl[b2][tid] = stl; nd[b2][tid] = std_; }
     }
   };
   auto body = [&](int cur, int sub) {
     const typename Ops::KF qa = Ops::load_k(qlds[cur] + ka0 + sub * kst);
     const typename Ops::KF doa = Ops::load_k(dolds[cur] + ka0 + sub * kst);
-    f32x16 cl, cd;       // accumulator register i <-> query (i&3) + 8(i>>2) + 4h of the sub-tile
+    f32x16 cl = (f32x16)(0.f), cd = (f32x16)(0.f);       // accumulator register i <-> query (i&3) + 8(i>>2) + 4h of the sub-tile
+    if constexpr (!SLOTS) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = *(const f32x4*)&nl[cur][sub * 32 + 8 * g + 4 * h];
-      const f32x4 d4 = *(const f32x4*)&nd[cur][sub * 32 + 8 * g + 4 * h];
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *(const f32x4*)&nl[cur][sub * 32 + 8 * g + 4 * h];
+        const f32x4 d4 = *(const f32x4*)&nd[cur][sub * 32 + 8 * g + 4 * h];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { cl[4 * g + i] = l4[i]; cd[4 * g + i] = d4[i]; }
+        for (int i = 0; i < 4; ++i) { cl[4 * g + i] = l4[i]; cd[4 * g + i] = d4[i]; }
+      }
     }
     f32x16 p = Ops::qk(qa, kfr, cl);
     f32x16 ds = Ops::qk(doa, vfr, cd);
