@@ -599,17 +599,18 @@ class UNetPlan:
         e = self.w.resnets[name]
         pre = e.cout >= self.PREAPPLY_MIN_COUT
         z1 = z2 = None
-        if e.scale_shift and self.train:
+        ss = getattr(e, "scale_shift", False)       # the latent-diffusion plan's entries have no such switch
+        if ss and self.train:
             raise NotImplementedError("the backward plan implements resnet_time_scale_shift = 'default' only")
         # "default": the projected embedding is added by conv1's epilogue; "scale_shift": it modulates norm2's affine instead
-        t1 = None if e.scale_shift else e.temb_off
+        t1 = None if ss else e.temb_off
         gn1 = self._gn(x0, x1, e.g1, e.be1, e.eps)
         if pre:
             z1 = self._gn_apply(x0, x1, gn1, 1)
             h1, _ = self._conv(z1, None, e.w1, e.b1, e.cout, temb_off=t1)
         else:
             h1, _ = self._conv(x0, x1, e.w1, e.b1, e.cout, silu=1, gn=gn1, temb_off=t1)
-        gn2 = self._gn(h1, None, e.g2, e.be2, e.eps, temb_off=e.temb_off if e.scale_shift else None)
+        gn2 = self._gn(h1, None, e.g2, e.be2, e.eps, temb_off=e.temb_off if ss else None)
         if pre:
             z2 = self._gn_apply(h1, None, gn2, 1)
         src, kw = (z2, dict()) if pre else (h1, dict(silu=1, gn=gn2))
@@ -786,11 +787,12 @@ class UNetPlan:
         a = self.temb_args
         a.rows = rows
         w = self.w
-        if w.class_mode == "identity":        # class_embed_type = "identity": the "labels" ARE the embedding rows
+        class_mode = getattr(w, "class_mode", None)
+        if class_mode == "identity":        # class_embed_type = "identity": the "labels" ARE the embedding rows
             if class_emb is None and labels is not None:
                 class_emb = labels.to(device=self.device, dtype=torch.float32).contiguous()
             labels = None
-        elif w.class_mode == "timestep":      # labels -> sinusoid -> class_embedding (a second TimestepEmbedding), :301-305
+        elif class_mode == "timestep":      # labels -> sinusoid -> class_embedding (a second TimestepEmbedding), :301-305
             if class_emb is None and labels is not None:
                 class_emb = self._class_rows_timestep(labels, rows, stream)
             labels = None
