@@ -510,7 +510,6 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
   const float qk_bound = qn * kn;                 // every scaled score of this query is <= qk_bound (Cauchy-Schwarz)
   f32x16 o = (f32x16)(0.f), zero = (f32x16)(0.f);
   float m = 0.f;
-  bool first = true;
 
   // constant LDS content
   if (tid == 0) Ops::init_const_slot(lds + KCONST_OFF);
@@ -569,12 +568,23 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // the reference maximum starts at the exact maximum over the first 32 keys (one QK^T MFMA, nothing accumulated): from the
+  // first tile on, a tile whose bound allows it takes the check-free body -- the first tile used to pay the exact-max path for
+  // all of its 256 keys (1/16 of the work at N = 4096, a quarter at N = 1024).  N >= 1024 here: no key of this block is padding.
+  {
+    const f32x16 s0 = Ops::qk(Ops::load_k(lds + koff), qf, zero);
+    float tmax = s0[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s0[i]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    m = Ops::set_m(qf, zero, h, tmax);
+  }
   for (int k0 = 0, cur = 0; k0 < N; k0 += KT, cur ^= 1) {
     if (k0 + KT < N) stage(cur ^ 1, k0 + KT);      // buffer cur^1 was last read before the barrier that ended the previous tile
     const int kl = koff + cur * kbuf;
     const int vb = voff + cur * vbuf;
     const bool full_tile = k0 + KT <= N;
-    const bool need = first || (qk_bound - m > RESCALE_THR);
+    const bool need = qk_bound - m > RESCALE_THR;
     if (full_tile && !__builtin_amdgcn_ballot_w64(need)) {
       // check-free body, software-pipelined as in attn_kernel
       typename Ops::KF kfn = Ops::load_k(lds + kl);
@@ -610,21 +620,20 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
             if (key >= N) s[i] = -INFINITY;
           }
         }
-        if (__builtin_amdgcn_ballot_w64(first || qk_bound - m > RESCALE_THR)) {   // wave-uniform
+        if (__builtin_amdgcn_ballot_w64(qk_bound - m > RESCALE_THR)) {   // wave-uniform
           float tmax = s[0];
 #pragma unroll
           for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-          if (__builtin_amdgcn_ballot_w64(first || tmax > RESCALE_THR)) {
-            const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));           // finite: the first tile holds key 0
-            const float m_new = Ops::set_m(qf, zero, h, m + (first ? t2 : fmaxf(t2, 0.f)));
+          if (__builtin_amdgcn_ballot_w64(tmax > RESCALE_THR)) {
+            const float t2 = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = Ops::set_m(qf, zero, h, m + fmaxf(t2, 0.f));
             const float delta = m_new - m;
-            const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            const float sc = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] *= sc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] -= delta;
             m = m_new;
-            first = false;
           }
         }
 #pragma unroll
