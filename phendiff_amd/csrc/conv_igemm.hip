@@ -15,6 +15,7 @@
 // distinct slots per ds_read_b128 lane group (conflict-free for TW = 32).
 #include <type_traits>
 #include <stdio.h>
+#include <stdlib.h>
 #include "pd_common.h"
 #include "pd_stage.h"
 #include "pd_conv.h"
@@ -46,9 +47,14 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 #else
 #define PD_STAMP(k) do {} while (0)
 #endif
-template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL>
-__global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2) void conv_kernel(const ConvP p) {   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
+// NCO = 2 (3x3 stride 1, 256-pixel tiles, Cout % 128 == 0): a workgroup computes TWO 64-channel output tiles from one staged
+// halo tile -- every staged (GroupNorm + SiLU-transformed) activation and every LDS fragment read feeds twice the MFMAs, and the
+// grid of the 128 / 256-channel layers (4096 / 2048 workgroups of the NCO = 1 form on 768 slots = 5.33 / 2.67 rounds) becomes
+// 2048 / 1024 workgroups on 512 slots = whole rounds.  128 accumulator registers: two workgroups per CU instead of three.
+template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1>
+__global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2)) void conv_kernel(const ConvP p) {   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
+  static_assert(NCO == 1 || (NCO == 2 && DB && KS == 3 && STRIDE == 1), "two output tiles per workgroup: 3x3 stride-1 double-buffered variant only");
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using SR = typename Stage<T>::R;
@@ -86,8 +92,8 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int ct32 = co_t * 2 + wc;                      // this wave's 32-co tile
-  const bool wave_active = (ct32 * 32) < p.Cout_pad;   // wave-uniform
+  const int ct32 = co_t * (2 * NCO) + wc;              // this wave's (first) 32-co tile; NCO = 2: the second one is ct32 + 2
+  const bool wave_active = (ct32 * 32) < p.Cout_pad;   // wave-uniform (NCO = 2 is only launched with Cout_pad % 128 == 0: always)
 
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0, 0, p.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1 ? p.x1 : p.x0), 0, p.bytes1, 0x00020000);
@@ -201,10 +207,11 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
     rbase[f] = ((py * STRIDE) * IN_TW + px * STRIDE) * PITCH + h * 8 * E::BYTES;
   }
 
-  f32x16 acc[NF];
+  f32x16 acc[NCO][NF];
   const int main_ksteps = (TAIL ? p.n_main : p.nchunks) * KSTEPS;
   const int all_ksteps = main_ksteps + (TAIL ? p.n_tail * 2 : 0);
   const T* wbase = (const T*)p.w + (size_t)ct32 * all_ksteps * 512 + lane * 8;
+  const size_t wstep = (size_t)2 * all_ksteps * 512;   // NCO = 2: elements between this wave's two 32-co tiles
 
   // Weight (A) fragments live in a register ring of AR entries, prefetched AD k-steps ahead and CONTINUOUSLY across
   // chunk boundaries (a chunk's fragments are contiguous with the next chunk's), so L2 latency (~600-800 cycles under
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
   // ONE scheduling region with counted waits.
   constexpr int AR = (KSTEPS % 3 == 0) ? 3 : 2;
   constexpr int AD = AR - 1;
-  Frag aring[AR];
+  Frag aring[AR][NCO];
   const int last_kstep = all_ksteps - 1;
 
   // one chunk of MFMAs out of `buf`; when DB, pieces of the NEXT chunk are transformed + written to `nbuf` in between
@@ -229,7 +236,8 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if constexpr (ACTIVE) {
-        aring[(ks + AD) % AR] = E::load(wbase + (size_t)PD_WIDX(min(g0 + ks + AD, last_kstep)) * 512);
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) aring[(ks + AD) % AR][c] = E::load(wbase + c * wstep + (size_t)PD_WIDX(min(g0 + ks + AD, last_kstep)) * 512);
         {
           const int tap = ks >> 1, s = ks & 1;
           const int toff = ((tap / KS) * IN_TW + (tap % KS)) * PITCH + s * 16 * E::BYTES;
@@ -238,7 +246,9 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
         }
         __builtin_amdgcn_s_setprio(1);   // keeps the 4-MFMA cluster together and ahead of the other wave's VALU work (+5 %)
 #pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f] = E::mma(aring[ks % AR], bc[f], acc[f]);
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+          for (int f = 0; f < NF; ++f) acc[c][f] = E::mma(aring[ks % AR][c], bc[f], acc[c][f]);
         __builtin_amdgcn_s_setprio(0);
       }
       if constexpr (DB && HAVE_NEXT) {
@@ -258,15 +268,20 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
     constexpr int CENTER = ((KS / 2) * IN_TW + (KS / 2)) * PITCH;
     if constexpr (ACTIVE) {
       const T* wt = wbase + (size_t)(main_ksteps + (chunk - p.n_main) * 2) * 512;
-      const Frag a0 = E::load(wt), a1 = E::load(wt + 512);
+      Frag a0[NCO], a1[NCO];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) { a0[c] = E::load(wt + c * wstep); a1[c] = E::load(wt + c * wstep + 512); }
       Frag b0[NF], b1[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) { b0[f] = E::load(buf + rbase[f] + CENTER); b1[f] = E::load(buf + rbase[f] + CENTER + 16 * E::BYTES); }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int f = 0; f < NF; ++f) acc[f] = E::mma(a0, b0[f], acc[f]);
+      for (int c = 0; c < NCO; ++c) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) acc[f] = E::mma(a1, b1[f], acc[f]);
+        for (int f = 0; f < NF; ++f) acc[c][f] = E::mma(a0[c], b0[f], acc[c][f]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[c][f] = E::mma(a1[c], b1[f], acc[c][f]);
+      }
       __builtin_amdgcn_s_setprio(0);
     }
     if constexpr (HAVE_NEXT) {
@@ -281,19 +296,21 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
   PD_STAMP(7);
   // bias / temb first: they are older than the HBM loads below in the in-order vmcnt queue, so initialising the
   // accumulators does not wait for the activation tile
-  f32x4 bt[4];
+  f32x4 bt[NCO][4];
   if (wave_active) {
 #pragma unroll
+    for (int c = 0; c < NCO; ++c)
+#pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int co = ct32 * 32 + 8 * g + 4 * h;
-      bt[g] = *(const f32x4*)(p.bias + co);
+      const int co = (ct32 + 2 * c) * 32 + 8 * g + 4 * h;
+      bt[c][g] = *(const f32x4*)(p.bias + co);
       if (p.temb) {
         const float* tp = p.temb + (size_t)n * p.temb_stride + co;
-        if (ct32 * 32 + 32 <= p.Cout) {          // wave-uniform: all 32 channels real
-          bt[g] += *(const f32x4*)tp;
+        if ((ct32 + 2 * c) * 32 + 32 <= p.Cout) {          // wave-uniform: all 32 channels real
+          bt[c][g] += *(const f32x4*)tp;
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) if (co + i < p.Cout) bt[g][i] += tp[i];
+          for (int i = 0; i < 4; ++i) if (co + i < p.Cout) bt[c][g][i] += tp[i];
         }
       }
     }
@@ -302,20 +319,23 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
   PD_STAMP(8);
   // accumulators start at bias[co] + temb[n][co] (lane (pixel, h), register i <-> co = 8(i>>2) + 4h + (i&3)):
   // the epilogue then has no per-channel loads at all
-  {
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) {
     f32x16 init = (f32x16)(0.f);
     if (wave_active) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) init[4 * g + i] = bt[g][i];
+        for (int i = 0; i < 4; ++i) init[4 * g + i] = bt[c][g][i];
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) acc[f] = init;
+    for (int f = 0; f < NF; ++f) acc[c][f] = init;
   }
   if (wave_active) {
 #pragma unroll
-    for (int i = 0; i < AD; ++i) aring[i] = E::load(wbase + (size_t)PD_WIDX(min(i, last_kstep)) * 512);
+    for (int i = 0; i < AD; ++i)
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) aring[i][c] = E::load(wbase + c * wstep + (size_t)PD_WIDX(min(i, last_kstep)) * 512);
   }
   PD_STAMP(9);
   if (DB) {
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
         const int co = co_w + 8 * g + 4 * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (co + i < p.Cout) ((float*)p.y)[(((size_t)n * p.Cout + co + i) * p.Hout + oy) * p.Wout + ox] = acc[f][4 * g + i];
+          if (co + i < p.Cout) ((float*)p.y)[(((size_t)n * p.Cout + co + i) * p.Hout + oy) * p.Wout + ox] = acc[0][f][4 * g + i];
       }
     }
     return;
@@ -393,13 +413,17 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
   // stores are fully coalesced 16-byte accesses (a pixel's 64 channels = one 128-B line in bf16).
   constexpr int EP_PITCH = 64 * E::BYTES + 16;
   if (!DB) __syncthreads();                 // DB: the chunk loop already ended on a barrier
+#pragma unroll
+  for (int cth = 0; cth < NCO; ++cth) {     // NCO = 2: the two 64-channel tiles go through the same LDS staging area in turn
+  const int co_tile = co_t * NCO + cth;
+  if (cth > 0) __syncthreads();
   if (wave_active) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int plin = (wp * NF + f) * 32 + r;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        store4((T*)(lds + plin * EP_PITCH) + wc * 32 + 8 * g + 4 * h, acc[f][4 * g], acc[f][4 * g + 1], acc[f][4 * g + 2], acc[f][4 * g + 3]);
+        store4((T*)(lds + plin * EP_PITCH) + wc * 32 + 8 * g + 4 * h, acc[cth][f][4 * g], acc[cth][f][4 * g + 1], acc[cth][f][4 * g + 2], acc[cth][f][4 * g + 3]);
     }
   }
   __syncthreads();
@@ -407,7 +431,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
   constexpr int PPP = 64 / EPC;                // pieces per pixel
   constexpr int PXI = 256 / PPP;               // pixels per iteration
   const int piece = tid % PPP, prow = tid / PPP;
-  const int co = co_t * 64 + piece * EPC;
+  const int co = co_tile * 64 + piece * EPC;
   float ssum[EPC], ssq[EPC];                   // GroupNorm statistics of what is stored (consumer's norm input)
 #pragma unroll
   for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
     if (tid < 128) {
       const int c = tid >> 1, which = tid & 1;
       const int pc = c / EPC, j = c % EPC;
-      const int cog = co_t * 64 + c;
+      const int cog = co_tile * 64 + c;
       float tot = 0.f;
 #pragma unroll 8
       for (int pr = 0; pr < PXI; ++pr) tot += red[(pr * PPP + pc) * (2 * EPC) + which * EPC + j];
@@ -482,10 +506,11 @@ __global__ __launch_bounds__(256, ((KS == 1 || (KS == 3 && STRIDE == 1 && TH * T
       }
     }
   }
+  }   // cth
   PD_STAMP(6);
 }
 
-template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false>
+template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false, int NCO = 1>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int IN_TH = (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
@@ -498,7 +523,8 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int LDS_MAIN = DB ? LDS_DB : LDS_TILE;
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
-  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL>;
+  static_assert(NCO == 1 || DB, "NCO = 2 is a double-buffered variant");
+  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO>;
   if (LDS_BYTES > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -513,7 +539,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   q.tiles_x_shift = -1;
   for (int sft = 0; sft < 16; ++sft) if ((1 << sft) == q.tiles_x) q.tiles_x_shift = sft;
   q.n_co_tiles = (p.Cout_pad + 63) / 64;
-  hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.n_co_tiles, p.B), dim3(256), LDS_BYTES, st, q);
+  hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.n_co_tiles / NCO, p.B), dim3(256), LDS_BYTES, st, q);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
@@ -532,6 +558,17 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
   if (ksize == 3 && stride == 1) {
     // 8-wide images (the SD UNet's innermost level): a 16 x 8 tile wastes half of an 8 x 8 image's tile instead of three quarters
     const bool tiny = p.Hout <= 16;
+    // two 64-channel output tiles per workgroup (NCO = 2) where that still leaves the chip at least two rounds of workgroups:
+    // 16-bit engines, NHWC output, Cout a multiple of 128.  PD_CONV_NCO=1 / 2: diagnostic override (same-box A/B).
+    if constexpr (sizeof(T) == 2) {
+      static const int nco_env = getenv("PD_CONV_NCO") ? atoi(getenv("PD_CONV_NCO")) : 0;
+      const long long wgs2 = (long long)((p.Wout + 31) / 32) * ((p.Hout + 7) / 8) * (p.Cout_pad / 128) * p.B;
+      // layers with a GroupNorm prologue and >= 128 input channels only (64 -> 128 @128^2: 0.110 -> 0.116 ms): same-box, 256 -> 256 @64^2 0.219 -> 0.185 ms, 128 -> 128 @128^2 0.234 -> 0.197,
+      // 512 -> 256 0.403 -> 0.343; WITHOUT a prologue (nothing to amortise) 0.184 -> 0.194
+      const bool nco2 = w >= 32 && p.Cout_pad % 128 == 0 && p.Cout == p.Cout_pad && p.out_mode != PD_OUT_NCHW_F32 &&
+                        (nco_env ? nco_env == 2 : (wgs2 >= 512 && p.scale != nullptr && p.C0 + p.C1 >= 128));
+      if (nco2) return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 2>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 2>(p, st);
+    }
     if (p.n_tail > 0) {
       if (w >= 32) return launch_conv<T, 3, 1, 8, 32, true>(p, st);
       if (w >= 16) return launch_conv<T, 3, 1, 16, 16, true>(p, st);
