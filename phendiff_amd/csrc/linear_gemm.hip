@@ -8,6 +8,7 @@
 //   MFMAs per wave), weights in pd_conv's packed fragment order straight from L2 (1 KiB coalesced per fragment).
 // Operand conventions are pd_conv's: B fragment = lane (token r, half h) holds channels 16 s + 8 h + (0..7) of a k-step,
 // D: lane owns a token, register i <-> channel 8 (i>>2) + 4 h + (i&3) of a 32-channel tile.
+#include <stdlib.h>
 #include "pd_common.h"
 #include <type_traits>
 #include "pd_stage.h"
@@ -141,14 +142,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
   const int total_chunks = nchunks + (tail_ksteps ? 1 : 0);
   const int b_lane = (wp * 64 + r) * PITCH + 8 * h * ES;
 
-  if constexpr (NC == 2) {
+  if constexpr (NC >= 2) {
     // wide tiles (big grids): weight fragments two k-steps ahead in registers, activation fragments read at the top of the
     // k-step; the kernel is held at 3 workgroups per CU (__launch_bounds__: 164-166 registers, accumulators in VGPRs) --
     // prefetching the activation fragments as well spills there (measured), the other resident waves cover that latency
 #ifdef PD_LIN_AD                                       // diagnostic builds: same-box A/B of the prefetch depth
     constexpr int AD = PD_LIN_AD, AR = 4;
 #else
-    constexpr int AD = 2, AR = 4;                      // weight fragments 2 k-steps ahead in a ring of 4 (static indices: 4 k-steps / chunk)
+    constexpr int AD = NC == 4 ? 1 : 2, AR = NC == 4 ? 2 : 4;   // weight fragments 2 k-steps ahead in a ring of 4 (static indices: 4 k-steps / chunk);
+                                                                // NC = 4 (256-channel tiles, 128 accumulator registers): 1 ahead in a ring of 2
 #endif
     Frag aring[AR][NC];
     const int last_kstep = ksteps - 1;
@@ -515,7 +517,8 @@ static int launch_linear(const LinP& p, hipStream_t st) {
   constexpr int ES = Elem<T>::BYTES;
   constexpr int XT = 128 * (64 * ES + 16), EPI = 128 * (64 * NC * ES + 16);
   constexpr int EPI_ST = EPI + 256 * (2 * 16 / ES) * 4;        // + per-thread statistics partials
-  constexpr int LDS = 2 * XT > EPI_ST ? 2 * XT : EPI_ST;
+  // NC = 4 is launched without statistics (no partials behind the output tile): 67.6 KB, two workgroups per CU
+  constexpr int LDS = NC == 4 ? (2 * XT > EPI ? 2 * XT : EPI) : (2 * XT > EPI_ST ? 2 * XT : EPI_ST);
   auto kern = linear_kernel<T, NC, GLU>;
   if (LDS > 64 * 1024) {
     static bool attr_set = false;
@@ -572,6 +575,14 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a->kmax2_out == nullptr || (a->qkv_heads > 0 && a->dtype != PD_F32), PD_ERR_SHAPE,
            "pd_linear: kmax2_out needs the head-major q/k/v output and a 16-bit dtype");
   p.kmax2 = a->kmax2_out;
+  // 256-channel tiles (NC = 4): every staged token tile feeds twice the MFMAs (the activation stream is this kernel's larger cost,
+  // DESIGN.md 9); two workgroups per CU.  PD_LIN_NC4=0/1: diagnostic override (same-box A/B).
+  static const int nc4_env = getenv("PD_LIN_NC4") ? atoi(getenv("PD_LIN_NC4")) : -1;
+  const bool nc4 = !narrow && a->N_pad % 256 == 0 && a->N == a->N_pad && !a->stats_out && (nc4_env >= 0 ? nc4_env == 1 : (long long)p.t_tiles * (a->N_pad / 256) >= 512);
+  if (nc4 && !glu && a->dtype != PD_F32) {
+    p.c_tiles = a->N_pad / 256;
+    return a->dtype == PD_F16 ? launch_linear<half_t, 4>(p, (hipStream_t)stream) : launch_linear<bf16_t, 4>(p, (hipStream_t)stream);
+  }
   if (a->dtype == PD_F16) {
     if (glu) return launch_linear<half_t, 2, true>(p, (hipStream_t)stream);
     return narrow ? launch_linear<half_t, 1>(p, (hipStream_t)stream) : launch_linear<half_t, 2>(p, (hipStream_t)stream);
