@@ -558,15 +558,26 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
   if (ksize == 3 && stride == 1) {
     // 8-wide images (the SD UNet's innermost level): a 16 x 8 tile wastes half of an 8 x 8 image's tile instead of three quarters
     const bool tiny = p.Hout <= 16;
-    // two 64-channel output tiles per workgroup (NCO = 2) where that still leaves the chip at least two rounds of workgroups:
-    // 16-bit engines, NHWC output, Cout a multiple of 128.  PD_CONV_NCO=1 / 2: diagnostic override (same-box A/B).
+    // Two 64-channel output tiles per workgroup (NCO = 2; 16-bit engines, NHWC / head-major output, Cout a multiple of 128) when
+    // the estimate below says so: workgroups run in rounds of (resident workgroups per CU) x CUs -- three per CU for NCO = 1,
+    // two for NCO = 2 -- and the last round is as long as a full one; per MFMA the NCO = 2 form is ~5 % faster behind a
+    // GroupNorm prologue (the transform and the LDS fragment reads are shared by two tiles) and ~16 % slower without one
+    // (same-box: 256 -> 256 @64^2 0.219 -> 0.185 ms, 128 -> 128 @128^2 0.234 -> 0.197, 512 -> 256 0.403 -> 0.343; no prologue
+    // 0.184 -> 0.194; 64 -> 128 @128^2 0.110 -> 0.116: K too small).  PD_CONV_NCO=1 / 2: diagnostic override (same-box A/B).
     if constexpr (sizeof(T) == 2) {
       static const int nco_env = getenv("PD_CONV_NCO") ? atoi(getenv("PD_CONV_NCO")) : 0;
-      const long long wgs2 = (long long)((p.Wout + 31) / 32) * ((p.Hout + 7) / 8) * (p.Cout_pad / 128) * p.B;
-      // layers with a GroupNorm prologue and >= 128 input channels only (64 -> 128 @128^2: 0.110 -> 0.116 ms): same-box, 256 -> 256 @64^2 0.219 -> 0.185 ms, 128 -> 128 @128^2 0.234 -> 0.197,
-      // 512 -> 256 0.403 -> 0.343; WITHOUT a prologue (nothing to amortise) 0.184 -> 0.194
-      const bool nco2 = w >= 32 && p.Cout_pad % 128 == 0 && p.Cout == p.Cout_pad && p.out_mode != PD_OUT_NCHW_F32 &&
-                        (nco_env ? nco_env == 2 : (wgs2 >= 512 && p.scale != nullptr && p.C0 + p.C1 >= 128));
+      static int cus = 0;
+      if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      }
+      bool nco2 = false;
+      if (w >= 32 && p.Cout_pad % 128 == 0 && p.Cout == p.Cout_pad && p.out_mode != PD_OUT_NCHW_F32) {
+        const long long wgs1 = (long long)((p.Wout + 31) / 32) * ((p.Hout + 7) / 8) * (p.Cout_pad / 64) * p.B, wgs2 = wgs1 / 2;
+        auto eff = [](long long wgs, long long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
+        const double speed2 = (p.scale != nullptr && p.C0 + p.C1 >= 128) ? 1.05 : 0.84;
+        nco2 = nco_env ? nco_env == 2 : eff(wgs2, 2ll * cus) * speed2 > eff(wgs1, 3ll * cus);
+      }
       if (nco2) return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 2>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 2>(p, st);
     }
     if (p.n_tail > 0) {
