@@ -619,7 +619,7 @@ def main():
     images = world * B * args.steps
     value = images / elapsed
     res = {
-        "metric": "img2img images/sec (50-step DDIM invert+denoise, 256x256)", "value": round(value, 4), "unit": "images/s",
+        "metric": f"img2img images/sec ({S}-step DDIM invert+denoise, {size}x{size})", "value": round(value, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", **ranks,
         "config": {"workload": f"configs[2]: {size}x{size} pipeline_conditional_ddim invert->class-swap->denoise, "
