@@ -111,6 +111,62 @@ def test_conv3x3_fused_prologue_epilogue(env, mode):
     assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "f32"])
+@pytest.mark.parametrize("tail", [False, True])
+def test_conv3x3_two_output_tiles_per_workgroup(env, mode, tail):
+    """A shape at which pd_conv's rounds-of-workgroups estimate picks the NCO = 2 kernel in the 16-bit engines (B = 16, 64 x 64,
+    128 -> 256 channels behind a GroupNorm prologue: 1024 workgroups of the one-tile form = 1.33 rounds on a 256-CU chip, 512
+    of the two-tile form = one whole round): prologue over a channel concat, bias + temb, residual or the fused 1x1 shortcut
+    tail, and the per-tile GroupNorm statistics of both output tiles."""
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    g = torch.Generator().manual_seed(31)
+    B, c0, c1, cout, h, w_ = 16, 96, 32, 256, 64, 64
+    x0, x1 = torch.randn(B, c0, h, w_, generator=g), torch.randn(B, c1, h, w_, generator=g)
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / ((c0 + c1) * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    scale, shift = torch.rand(B, c0 + c1, generator=g) + 0.5, torch.randn(B, c0 + c1, generator=g)
+    temb = torch.randn(B, 300, generator=g)
+    xin = torch.cat([bf16_round(x0, mode), bf16_round(x1, mode)], 1)
+    xin = bf16_round(F.silu(xin * scale[:, :, None, None] + shift[:, :, None, None]), mode)
+    ref = F.conv2d(xin, bf16_round(w, mode), b, padding=1) + temb[:, 9:9 + cout, None, None]
+    X0, X1 = nhwc(x0.to(dev), tdt), nhwc(x1.to(dev), tdt)
+    sc, sh, tb = scale.to(dev), shift.to(dev), temb[:, 9:].contiguous().to(dev)
+    y = torch.full((B, h, w_, cout), float("nan"), dtype=tdt, device=dev)
+    T = lib.pd_conv_stat_tiles(h, w_, 3, 1)
+    st = torch.full((B, T, cout, 2), float("nan"), device=dev)
+    a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=h, Wout=w_, C0=c0, C1=c1, Cout=cout, Cout_pad=cout, ksize=3, stride=1, pad=1,
+                   upsample=0, silu=1, out_mode=0, heads=0, x0=X0.data_ptr(), x1=X1.data_ptr(), scale=sc.data_ptr(), shift=sh.data_ptr(),
+                   bias=None, temb=tb.data_ptr(), temb_stride=tb.shape[1], residual=None, y=y.data_ptr(), stats_out=st.data_ptr(), im2col3=0)
+    if tail:
+        t0 = 64
+        xa = torch.randn(B, t0, h, w_, generator=g)
+        ws = torch.randn(cout, t0, 1, 1, generator=g) / t0 ** 0.5
+        bs = torch.randn(cout, generator=g)
+        p2, ps = pack(w, tdt), pack(ws, tdt)
+        ct = p2.shape[0]
+        wp = torch.cat([p2.reshape(ct, -1, 64, 8), ps.reshape(ct, -1, 64, 8)], 1).contiguous().to(dev)
+        XA = nhwc(xa.to(dev), tdt)
+        bias = (b + bs).to(dev)
+        a.tail_x0, a.tail_x1, a.tail_C0, a.tail_C1 = XA.data_ptr(), None, t0, 0
+        ref = ref + F.conv2d(bf16_round(xa, mode), bf16_round(ws, mode), bs)
+    else:
+        res = torch.randn(B, cout, h, w_, generator=g)
+        R = nhwc(res.to(dev), tdt)
+        wp = pack(w, tdt).to(dev)
+        bias = b.to(dev)
+        a.residual = R.data_ptr()
+        ref = ref + bf16_round(res, mode)
+    a.w_packed, a.bias = wp.data_ptr(), bias.data_ptr()
+    L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+    torch.cuda.synchronize()
+    got = y.float().permute(0, 3, 1, 2)
+    assert rel(got, ref) < TOL[mode]
+    # statistics of what was stored: per (sample, channel) sums over all tiles
+    yc = got.cpu().double()
+    assert rel(st[..., 0].sum(1).cpu(), yc.sum((2, 3))) < 1e-4 and rel(st[..., 1].sum(1).cpu(), (yc * yc).sum((2, 3))) < 1e-4
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
 @pytest.mark.parametrize("hw", [(32, 32), (16, 16), (64, 96), (8, 8)])
 def test_conv3x3_stride2(env, mode, hw):

@@ -203,10 +203,11 @@ def test_geglu_backward(env, mode):
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [(1024, 320, 960, 0, 0), (300, 64, 64, 1, 0), (2048, 1280, 10240, 0, 0), (77 * 3, 96, 256, 0, 0), (515, 5120, 1280, 1, 0),
-                                 (4096, 96, 320, 1, 32), (130, 32, 8, 0, 0)])
+                                 (4096, 96, 320, 1, 32), (130, 32, 8, 0, 0), (65536 + 70, 128, 512, 1, 0)])
 def test_linear_gemm(env, mode, cfg):
     """pd_linear against F.linear: full / ragged token tiles, K with a trailing half chunk (96, 32), N not a multiple of the
-    128-channel tile, residual, strided input rows (a slice of a fused projection's output)."""
+    128-channel tile, residual, strided input rows (a slice of a fused projection's output).  The (2048, 1280, 10240) and the
+    last shape are launched with 256-channel tiles (NC = 4) in the 16-bit engines (N % 256 == 0 and >= 512 workgroups)."""
     from phendiff_amd.packing import pack_conv_weight
     L, lib, _, dev = env
     code, tdt = DT[mode]
