@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
   constexpr int NIT = TM * CK / 8 / 256;               // 8-channel pieces per thread per chunk (4)
   constexpr int TNO = GLU ? TN / 2 : TN;               // output channels per workgroup tile
   constexpr int EP_PITCH = TN * ES + 16;
-  static_assert(!GLU || NC == 2, "the fused GEGLU epilogue pairs the two channel tiles of a wave");
+  static_assert(!GLU || NC == 2 || NC == 4, "the fused GEGLU epilogue pairs the (value, gate) channel tiles of a wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][XTILE] | epilogue [TM][EP_PITCH]
 
   // block -> (token tile, channel tile): the channel tiles of one token tile are 8 blocks apart in dispatch order, i.e. on
@@ -244,14 +244,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
   // ---- epilogue: [token][128 channels] through LDS, then coalesced 16-byte residual loads / stores
   if constexpr (GLU) {
 #pragma unroll
+    for (int u = 0; u < NC / 2; ++u)           // this wave's (value, gate) tile pairs: packed tiles 2u, 2u + 1
+#pragma unroll
     for (int f = 0; f < 2; ++f) {
       const int tok = wp * 64 + f * 32 + r;
       f32x16 o;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] = acc[0][f][i] * gelu_f<ES>(acc[NC - 1][f][i]);
+      for (int i = 0; i < 16; ++i) o[i] = acc[2 * u][f][i] * gelu_f<ES>(acc[2 * u + 1][f][i]);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        store4((T*)(lds + tok * EP_PITCH) + wc * 32 + 8 * g + 4 * h, o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+        store4((T*)(lds + tok * EP_PITCH) + (wc * (NC / 2) + u) * 32 + 8 * g + 4 * h, o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
     }
   } else
 #pragma unroll
@@ -578,9 +580,13 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   // 256-channel tiles (NC = 4): every staged token tile feeds twice the MFMAs (the activation stream is this kernel's larger cost,
   // DESIGN.md 9); two workgroups per CU.  PD_LIN_NC4=0/1: diagnostic override (same-box A/B).
   static const int nc4_env = getenv("PD_LIN_NC4") ? atoi(getenv("PD_LIN_NC4")) : -1;
-  const bool nc4 = !narrow && a->N_pad % 256 == 0 && a->N == a->N_pad && !a->stats_out && (nc4_env >= 0 ? nc4_env == 1 : (long long)p.t_tiles * (a->N_pad / 256) >= 512);
-  if (nc4 && !glu && a->dtype != PD_F32) {
-    p.c_tiles = a->N_pad / 256;
+  // a ragged last tile (N not a multiple of 256) repeats clamped weight tiles whose results are never stored: allowed up to 10 % waste
+  const int c_tiles4 = (a->N_pad + 255) / 256;
+  const bool nc4 = !narrow && !a->stats_out && (long long)c_tiles4 * 256 * 10 <= (long long)a->N_pad * 11 &&
+                   (nc4_env >= 0 ? nc4_env == 1 : (long long)p.t_tiles * c_tiles4 >= 512);
+  if (nc4 && a->dtype != PD_F32) {
+    p.c_tiles = c_tiles4;
+    if (glu) return a->dtype == PD_F16 ? launch_linear<half_t, 4, true>(p, (hipStream_t)stream) : launch_linear<bf16_t, 4, true>(p, (hipStream_t)stream);
     return a->dtype == PD_F16 ? launch_linear<half_t, 4>(p, (hipStream_t)stream) : launch_linear<bf16_t, 4>(p, (hipStream_t)stream);
   }
   if (a->dtype == PD_F16) {
