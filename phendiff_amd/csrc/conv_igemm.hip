@@ -182,9 +182,13 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
+            // UNCONDITIONAL loads from clamped (always valid) addresses, masked afterwards: guarded loads make the compiler wait
+            // for each one before issuing the next (27 serial L2 round trips = most of this workgroup's lifetime)
             const int iy = oy + ky - 1, ix = ox + kx - 1;
-            if (ci < p.C0r && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
-              v[ci * 9 + ky * 3 + kx] = src[(((size_t)n * p.C0r + ci) * p.Hin + iy) * p.Win + ix];
+            const bool ok = ci < p.C0r && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            const int cic = min(ci, p.C0r - 1), iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
+            const float xv = src[(((size_t)n * p.C0r + cic) * p.Hin + iyc) * p.Win + ixc];
+            v[ci * 9 + ky * 3 + kx] = ok ? xv : 0.f;
           }
         }
       }

@@ -285,14 +285,24 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
   for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   long long kmax_nn = -1; float kmax_run = 0.f;   // running max |k|^2 of this thread's key rows (p.kmax2)
   if (co < NO) {
-#pragma unroll 4
+    // residual pieces of all iterations up front, unconditionally, from clamped (valid) rows: a load under the per-iteration
+    // guards is waited for before the next one is issued
+    u32x4 rres[TM / TPI];
+    if (p.residual) {
+#pragma unroll
+      for (int it = 0; it < TM / TPI; ++it) {
+        const long long mc = min(m0 + it * TPI + trow, p.M - 1);
+        rres[it] = *(const u32x4*)((const T*)p.residual + (size_t)mc * NO + co);
+      }
+    }
+#pragma unroll
     for (int it = 0; it < TM / TPI; ++it) {
       const int tok = it * TPI + trow;
       const long long m = m0 + tok;
       if (m >= p.M) continue;
       u32x4 v = *(const u32x4*)(lds + tok * EP_PITCH + piece * 16);
       if (p.residual) {
-        const u32x4 rr = *(const u32x4*)((const T*)p.residual + (size_t)m * NO + co);
+        const u32x4 rr = rres[it];
         if constexpr (ES == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
