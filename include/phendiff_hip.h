@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 1
+/* Bumped whenever an args struct grows or an entry point is added (a caller built against an older header passes shorter
+ * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
+ * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3. */
+#define PD_ABI_VERSION 3
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
@@ -188,7 +191,11 @@ typedef struct {
                            kmax2_out produces it in the q/k/v projection's epilogue), or NULL.  With it (bf16 / fp16, large
                            launches) the kernel needs no per-tile key norms: K / V tiles go global -> LDS by DMA
                            (global_load_lds), V^T fragments come from transposed LDS reads.  Results are the same function
-                           of the inputs either way (softmax is invariant to the running reference maximum). */
+                           of the inputs either way (softmax is invariant to the running reference maximum) PROVIDED the
+                           bound holds: kmax2[b][head] >= max_n |k|^2 of THIS launch's keys is a hard precondition (a slot
+                           that is too small lets p = 2^(s - m) grow without the rescale: inf / NaN in fp16).  A first
+                           32-key score above the implied bound makes the wave fall back to the exact running-maximum
+                           path -- a safety net for zero / stale slots, not a substitute for the precondition. */
 } pd_attn_args;
 int pd_attn_d8(const pd_attn_args* a, void* stream);
 

@@ -43,6 +43,16 @@ UNET_CONFIGS = {
         up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4,
         attention_head_dim=None, norm_num_groups=32, norm_eps=1e-6, num_class_embeds=None,
         flip_sin_to_cos=False, freq_shift=1, downsample_padding=0, sample_size=256),
+    # models_configs/denoiser/SD_2-1_config.json: a PIXEL-space class-conditional CondUNet2DModel with SD-2.1's widths -- attention
+    # (head_dim 8 -> 40 / 80 / 160 heads) on the first three levels, N = 16 384 tokens at 128^2.  The file also carries keys the
+    # class does not take (conv_in_kernel, conv_out_kernel, resnet_out_scale_factor, resnet_skip_time_act, upcast_attention,
+    # use_linear_projection: diffusers' from_config drops them with a warning).
+    "SD_2-1_config": dict(
+        in_channels=3, out_channels=3, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+        down_block_types=("AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
+        up_block_types=("UpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D"),
+        attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, num_class_embeds=2,
+        flip_sin_to_cos=True, freq_shift=0, downsample_padding=1, sample_size=128),
     # public google/ddpm-cifar10-32 layout (known-answer check only)
     "ddpm_cifar10": dict(
         in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 256), layers_per_block=2,

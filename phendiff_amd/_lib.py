@@ -17,17 +17,12 @@ LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "libphendiff_hip.so")
 
 def source_hash() -> str:
     """sha256 over the library's sources (csrc/*.hip, csrc/*.h, include/phendiff_hip.h, the build script): identifies the code
-    a build / a committed profile belongs to."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(_HERE, "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".sh")))
-    files.append(os.path.join(_HERE, "..", "include", "phendiff_hip.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()
+    a build / a committed profile belongs to.  The definition lives in csrc/source_hash.py (standalone: build.sh runs it too)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_pd_source_hash", os.path.join(_HERE, "csrc", "source_hash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
 
 
 def library_is_current() -> bool:
@@ -43,7 +38,7 @@ def library_is_current() -> bool:
 PD_F32, PD_BF16, PD_F16 = 0, 1, 2
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 vp = C.c_void_p
 

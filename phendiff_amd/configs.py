@@ -27,7 +27,21 @@ UNET_CONFIGS = {
         downsample_padding=0, flip_sin_to_cos=False, freq_shift=1, in_channels=3, layers_per_block=2, mid_block_scale_factor=1,
         norm_eps=1e-06, norm_num_groups=32, out_channels=3, sample_size=256, time_embedding_type="positional",
         up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D", "UpBlock2D", "UpBlock2D", "UpBlock2D")),
+    # models_configs/denoiser/SD_2-1_config.json -- 641 914 883 parameters: a pixel-space class-conditional CondUNet2DModel with
+    # SD-2.1's widths; AttnDownBlock2D on the first three levels (head_dim 8 -> 40 / 80 / 160 heads; N = 16 384 tokens at 128^2).
+    # The file's other keys (conv_in_kernel, conv_out_kernel, resnet_out_scale_factor, resnet_skip_time_act, upcast_attention,
+    # use_linear_projection) are not arguments of CustomCondUNet2DModel: `from_config` drops them with a warning, as diffusers does.
+    "SD_2-1_config": dict(
+        act_fn="silu", attention_head_dim=8, block_out_channels=(320, 640, 1280, 1280), center_input_sample=False,
+        class_embed_type=None, down_block_types=("AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
+        downsample_padding=1, flip_sin_to_cos=True, freq_shift=0, in_channels=3, layers_per_block=2,
+        mid_block_scale_factor=1, norm_eps=1e-05, norm_num_groups=32, num_class_embeds=2, out_channels=3,
+        resnet_time_scale_shift="default", sample_size=128, time_embedding_type="positional",
+        up_block_types=("UpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D")),
 }
+# keys of the shipped JSONs that CustomCondUNet2DModel.__init__ (cond_unet_2d.py:74-107) does not take
+UNET_CONFIG_IGNORED_KEYS = ("conv_in_kernel", "conv_out_kernel", "resnet_out_scale_factor", "resnet_skip_time_act", "upcast_attention",
+                            "use_linear_projection")
 
 SCHEDULER_CONFIGS = {
     # models_configs/noise_scheduler/3k_steps_clipping_rescaling.json (paired with super_small in launch_script_DDIM.sh:46-47)

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
   qn += __shfl_xor(qn, 32);
   qn = sqrtf(qn) * 1.00001f + 1e-6f;
   const float kn = sqrtf(a.kmax2[b * a.heads + head]) * 1.00002f;
-  const float qk_bound = qn * kn;                 // every scaled score of this query is <= qk_bound (Cauchy-Schwarz)
+  float qk_bound = qn * kn;                       // every scaled score of this query is <= qk_bound (Cauchy-Schwarz)
   f32x16 o = (f32x16)(0.f), zero = (f32x16)(0.f);
   float m = 0.f;
 
@@ -578,6 +578,10 @@ __global__ __launch_bounds__(512) void attn_glds_kernel(const pd_attn_args a) {
     for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s0[i]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     m = Ops::set_m(qf, zero, h, tmax);
+    // kmax2 is a HARD precondition (>= max |k|^2 of this (sample, head): pd_linear.kmax2_out after a pd_zero).  Safety net for a
+    // slot that is zero / stale / belongs to another K: a first-sub-tile score above the "bound" proves it wrong ->
+    // this wave keeps the exact running-maximum path for the whole launch (no unbounded 2^(s - m); costs speed, not results)
+    if (tmax > qk_bound) qk_bound = INFINITY;
   }
   for (int k0 = 0, cur = 0; k0 < N; k0 += KT, cur ^= 1) {
     if (k0 + KT < N) stage(cur ^ 1, k0 + KT);      // buffer cur^1 was last read before the barrier that ended the previous tile

@@ -416,10 +416,41 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   // NHWC / head-major: stage the 64-channel tile through LDS as [pixel][co] so that the residual add and the
   // stores are fully coalesced 16-byte accesses (a pixel's 64 channels = one 128-B line in bf16).
   constexpr int EP_PITCH = 64 * E::BYTES + 16;
+  constexpr int EPC = 16 / E::BYTES;           // channels per 16-byte piece
+  constexpr int PPP = 64 / EPC;                // pieces per pixel
+  constexpr int PXI = 256 / PPP;               // pixels per iteration
+  constexpr int NEP = TP / PXI;                // iterations (pieces per thread)
+  static_assert(PXI % TW == 0 || TW % PXI == 0, "epilogue piece map");
+  const int piece = tid % PPP, prow = tid / PPP;
+  // Piece `it` of this thread is pixel (py0 + DPY(it), px0 + DPX(it)) of the tile with compile-time DPY / DPX (no carry between
+  // them: PXI divides TW or the other way round), so its byte offset in the NHWC output is one 32-bit base + a scalar step --
+  // round 3: the 64-bit multiplies per piece of the old address computation were a third of the epilogue's VALU time, and
+  // the guarded residual load was waited for right after its issue (one exposed L2 / HBM round trip per piece: +10k cycles
+  // of a 49k-cycle workgroup on the 64-channel 256^2 layers).  Residual pieces are now loaded up front, unconditionally,
+  // through a buffer resource (invalid pixel / no residual tensor -> out-of-range offset -> zeros, no traffic); stores go
+  // through a buffer resource too (out-of-range -> dropped), so the loop has no divergent branch.
+  const int py0 = prow / TW, px0 = prow % TW;
+  const unsigned out_bytes = (unsigned)p.B * p.Hout * p.Wout * p.Cout * E::BYTES;     // < 2 GiB (checked by pd_conv)
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.out_mode == PD_OUT_NHWC ? out_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.y), 0, p.residual ? out_bytes : 0u, 0x00020000);
+  const unsigned row_bytes = (unsigned)p.Wout * p.Cout * E::BYTES, px_bytes = (unsigned)p.Cout * E::BYTES;
+  auto piece_off = [&](int it, int co) -> unsigned {       // byte offset of piece `it` (or OOB_OFF) for the 64-channel tile at `co`
+    const int dpy = (it * PXI) / TW, dpx = (it * PXI) % TW;
+    const int oy = y0 + py0 + dpy, ox = x0 + px0 + dpx;
+    const unsigned off = (unsigned)((n * p.Hout + y0 + py0) * p.Wout + x0 + px0) * px_bytes + (unsigned)co * E::BYTES
+                         + (unsigned)dpy * row_bytes + (unsigned)dpx * px_bytes;
+    return (oy < p.Hout && ox < p.Wout && co < p.Cout) ? off : OOB_OFF;
+  };
   if (!DB) __syncthreads();                 // DB: the chunk loop already ended on a barrier
 #pragma unroll
   for (int cth = 0; cth < NCO; ++cth) {     // NCO = 2: the two 64-channel tiles go through the same LDS staging area in turn
   const int co_tile = co_t * NCO + cth;
+  const int co = co_tile * 64 + piece * EPC;
+  u32x4 rr[NEP];
+  if (p.out_mode == PD_OUT_NHWC) {
+#pragma unroll
+    for (int it = 0; it < NEP; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(rres, piece_off(it, co), 0, 0);
+  }
   if (cth > 0) __syncthreads();
   if (wave_active) {
 #pragma unroll
@@ -431,58 +462,56 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
     }
   }
   __syncthreads();
-  constexpr int EPC = 16 / E::BYTES;           // channels per 16-byte piece
-  constexpr int PPP = 64 / EPC;                // pieces per pixel
-  constexpr int PXI = 256 / PPP;               // pixels per iteration
-  const int piece = tid % PPP, prow = tid / PPP;
-  const int co = co_tile * 64 + piece * EPC;
   float ssum[EPC], ssq[EPC];                   // GroupNorm statistics of what is stored (consumer's norm input)
 #pragma unroll
   for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  if (co < p.Cout) {
+  if (p.out_mode == PD_OUT_NHWC) {
 #pragma unroll
-    for (int it = 0; it < TP / PXI; ++it) {
+    for (int it = 0; it < NEP; ++it) {
+      const int plin = it * PXI + prow;
+      const unsigned off = piece_off(it, co);
+      u32x4 v = *(const u32x4*)(lds + plin * EP_PITCH + piece * 16);
+      if (p.residual) {                        // kernel-uniform
+        if constexpr (E::BYTES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float lo, hi, rl, rh;
+            Pack16<T>::unpack(v[j], lo, hi); Pack16<T>::unpack(rr[it][j], rl, rh);
+            v[j] = Pack16<T>::pack(lo + rl, hi + rh);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(__uint_as_float(v[j]) + __uint_as_float(rr[it][j]));
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(v, ry, off, 0, 0);
+      if (p.stats) {                           // kernel-uniform
+        if (off == OOB_OFF) v = (u32x4)(0u);   // pixels beyond the image / padded channels do not count
+        if constexpr (E::BYTES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float lo, hi;
+            Pack16<T>::unpack(v[j], lo, hi);
+            ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float x = __uint_as_float(v[j]); ssum[j] += x; ssq[j] += x * x; }
+        }
+      }
+    }
+  } else if (co < p.Cout) {  // PD_OUT_QKV_HEADS: [which][B][heads][N][8]
+#pragma unroll
+    for (int it = 0; it < NEP; ++it) {
       const int plin = it * PXI + prow;
       const int oy = y0 + plin / TW, ox = x0 + plin % TW;
       if (oy >= p.Hout || ox >= p.Wout) continue;
-      u32x4 v = *(const u32x4*)(lds + plin * EP_PITCH + piece * 16);
-      const size_t opix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
-      if (p.out_mode == PD_OUT_NHWC) {
-        if (p.residual) {
-          const u32x4 rr = *(const u32x4*)((const T*)p.residual + opix * p.Cout + co);
-          if constexpr (E::BYTES == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float lo, hi, rl, rh;
-              Pack16<T>::unpack(v[j], lo, hi); Pack16<T>::unpack(rr[j], rl, rh);
-              v[j] = Pack16<T>::pack(lo + rl, hi + rh);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(__uint_as_float(v[j]) + __uint_as_float(rr[j]));
-          }
-        }
-        *(u32x4*)((T*)p.y + opix * p.Cout + co) = v;
-        if (p.stats) {
-          if constexpr (E::BYTES == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float lo, hi;
-              Pack16<T>::unpack(v[j], lo, hi);
-              ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float x = __uint_as_float(v[j]); ssum[j] += x; ssq[j] += x * x; }
-          }
-        }
-      } else {  // PD_OUT_QKV_HEADS: [which][B][heads][N][8]
-        const int Cq = p.heads * 8;
-        const int which = co / Cq, cc = co - which * Cq;
-        const size_t N = (size_t)p.Hout * p.Wout;
-        const size_t tok = (size_t)oy * p.Wout + ox;
-        *(u32x4*)((T*)p.y + ((((size_t)which * p.B + n) * p.heads + (cc >> 3)) * N + tok) * 8 + (cc & 7)) = v;
-      }
+      const u32x4 v = *(const u32x4*)(lds + plin * EP_PITCH + piece * 16);
+      const int Cq = p.heads * 8;
+      const int which = co / Cq, cc = co - which * Cq;
+      const size_t N = (size_t)p.Hout * p.Wout;
+      const size_t tok = (size_t)oy * p.Wout + ox;
+      *(u32x4*)((T*)p.y + ((((size_t)which * p.B + n) * p.heads + (cc >> 3)) * N + tok) * 8 + (cc & 7)) = v;
     }
   }
   if (p.stats) {   // kernel-uniform
@@ -655,6 +684,8 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   const size_t bytes0 = (size_t)a->B * a->Hin * a->Win * a->C0 * esz, bytes1 = (size_t)a->B * a->Hin * a->Win * a->C1 * esz;
   PD_CHECK(bytes0 < 0x80000000ull && bytes1 < 0x80000000ull, PD_ERR_SHAPE,
            "pd_conv: source tensor exceeds 2 GiB (32-bit buffer offsets); split the batch");
+  PD_CHECK(a->out_mode != PD_OUT_NHWC || (size_t)a->B * a->Hout * a->Wout * a->Cout * esz < 0x80000000ull, PD_ERR_SHAPE,
+           "pd_conv: NHWC output exceeds 2 GiB (32-bit buffer offsets); split the batch");
   ConvP p{};
   p.B = a->B; p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout;
   p.C0 = a->C0; p.C1 = a->C1; p.Cout = a->Cout; p.Cout_pad = a->Cout_pad;

@@ -16,14 +16,27 @@ template <typename T> struct Stage {
   static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
     R r; r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); return r;
   }
-  // y = silu?(x*sc + sh) on 8 packed bf16, zeroed when !valid
+  // y = silu?(x*sc + sh) on 8 packed 16-bit values, zeroed when !valid.  `affine` / `silu` are kernel-uniform: the two common
+  // forms (GroupNorm + SiLU; plain copy) are whole separate paths -- written as per-element `if`s the compiler turned both flags
+  // into two v_cndmask per element (16 of a piece's ~70 VALU instructions, round-3 ISA reading)
   static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
                                                      bool affine, bool silu, bool valid) {
     u32x4 o = in.v;
-    if (affine || silu) {
+    if (affine && silu) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x2 x;                                     // packed fp32 math: one VALU slot per channel pair
+        float xl, xh;
+        Pack16<T>::unpack(in.v[j], xl, xh);
+        x.x = xl; x.y = xh;
+        x = silu_fast2(x * (f32x2){sc[2 * j], sc[2 * j + 1]} + (f32x2){sh[2 * j], sh[2 * j + 1]});
+        o[j] = Pack16<T>::pack(x.x, x.y);
+      }
+      if (!valid) o = (u32x4)(0u);
+    } else if (affine || silu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 x;
         float xl, xh;
         Pack16<T>::unpack(in.v[j], xl, xh);
         x.x = xl; x.y = xh;

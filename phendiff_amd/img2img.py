@@ -228,6 +228,17 @@ def shard_batches(num_batches: int, rank: int, world_size: int, even_batches: bo
     return mine
 
 
+def _refuse_class_modes_in_graph(plan, who):
+    """The captured trajectories pass one int64 label per (step, image) row and capture `temb_rows` once: that is the
+    `nn.Embedding` class table (every shipped config) or no class conditioning.  `class_embed_type` "identity" (the rows ARE
+    float embedding vectors) and "timestep" (a second embedding MLP whose scratch tensors would be allocated inside the capture)
+    run through the eager loops (`inversion` / `ddib` / the pipeline call) only."""
+    mode = getattr(plan.w, "class_mode", None)
+    if mode is not None:
+        raise NotImplementedError(f"{who}: class_embed_type={mode!r} is not captured into a hipGraph; use the eager loop "
+                                  "(img2img.ddib / ConditionalDDIMPipeline.__call__)")
+
+
 class DDIBGraph:
     """One hipGraph for the whole invert -> class-swap -> denoise trajectory of a batch.
 
@@ -251,6 +262,7 @@ class DDIBGraph:
             raise ValueError(f"batch_size {B} exceeds what one launch plan holds at {H}x{W} ({unet.max_batch(H, W)} images: tensors are "
                              f"addressed with 32-bit byte offsets); replay several DDIBGraph runners (shard_batches) instead")
         self.plan = unet.new_plan(B, H, W, dev) if private_plan else unet.plan_for(B, H, W, dev)
+        _refuse_class_modes_in_graph(self.plan, "DDIBGraph")
         cin = unet.config.in_channels
         # schedulers (host tables)
         self.inv = DDIMInverseScheduler.from_config(pipe.scheduler.config, variant=variant)
@@ -514,6 +526,7 @@ class CFGForwardStartGraph:
         if B > unet.max_batch(H, W):
             raise ValueError(f"batch_size {B} exceeds what one launch plan holds at {H}x{W} ({unet.max_batch(H, W)} images)")
         self.plan = unet.plan_for(B, H, W, dev)
+        _refuse_class_modes_in_graph(self.plan, "CFGForwardStartGraph")
         cin = unet.config.in_channels
         sch = pipe.scheduler
         sch.set_timesteps(S)

@@ -211,6 +211,11 @@ class CustomCondUNet2DModel(nn.Module):
     @classmethod
     def from_config(cls, config, compute_dtype="bf16", **overrides):
         d = dict(config) if isinstance(config, dict) else dict(vars(config))
+        dropped = sorted(k for k in d if k not in _CONFIG_DEFAULTS and not k.startswith("_"))
+        if dropped:      # diffusers' ConfigMixin.extract_init_dict: "... were passed to X, but are not expected and will be ignored"
+            import warnings
+            warnings.warn(f"The config attributes {dropped} were passed to {cls.__name__}, but are not expected and will be ignored "
+                          "(e.g. models_configs/denoiser/SD_2-1_config.json carries UNet2DConditionModel keys).", stacklevel=2)
         d = {k: v for k, v in d.items() if k in _CONFIG_DEFAULTS}
         d.update(overrides)
         return cls(compute_dtype=compute_dtype, **d)
@@ -788,6 +793,7 @@ class UNetPlan:
         a.rows = rows
         w = self.w
         class_mode = getattr(w, "class_mode", None)
+        tdim = self.m.time_embed_dim
         if class_mode == "identity":        # class_embed_type = "identity": the "labels" ARE the embedding rows
             if class_emb is None and labels is not None:
                 class_emb = labels.to(device=self.device, dtype=torch.float32).contiguous()
@@ -798,6 +804,14 @@ class UNetPlan:
             labels = None
         elif w.class_table is None:           # no class conditioning: labels / class_emb are ignored (cond_unet_2d.py:297-309)
             labels = class_emb = None
+        # pd_temb reads rows timesteps, rows labels and rows * time_embed_dim class_emb floats: refuse anything shorter
+        if ts.numel() < rows:
+            raise ValueError(f"temb_rows: {ts.numel()} timesteps for {rows} rows")
+        if labels is not None and labels.numel() != rows:
+            raise ValueError(f"temb_rows: {labels.numel()} class labels for {rows} rows")
+        if class_emb is not None and class_emb.numel() != rows * tdim:
+            raise ValueError(f"temb_rows: class_emb has {class_emb.numel()} elements, needs rows x time_embed_dim = {rows} x {tdim}"
+                             + (" (class_embed_type='identity': pass the embedding rows, not integer labels)" if class_mode == "identity" else ""))
         self._temb_keep = (labels, class_emb)
         a.timesteps, a.labels, a.class_emb = ts.data_ptr(), L.ptr(labels), L.ptr(class_emb)
         a.emb, a.proj = None, out.data_ptr()

@@ -106,8 +106,25 @@ def main_google():
     print("wrote ddib_google_ddpm_64_s2.npz")
 
 
+def main_sd21_denoiser():
+    """models_configs/denoiser/SD_2-1_config.json (641.9 M parameters: pixel-space class-conditional UNet with SD-2.1 widths,
+    d = 8 attention with 40 / 80 / 160 heads on three levels): one UNet evaluation and a DDIB class transfer (S = 2) at 32x32."""
+    torch.manual_seed(0)
+    unet = CondUNet2DRef(**dict(UNET_CONFIGS["SD_2-1_config"], sample_size=32)).eval()
+    pipe = ConditionalDDIMPipelineRef(unet, DDIMSchedulerRef(**SCHED_3K))
+    x, labels = synth_batch(2, 32)
+    with torch.no_grad():
+        eps = unet(x, 1500, class_labels=labels).sample
+    out, inverted = ddib_ref(pipe, x, labels, 1 - labels, 2)
+    np.savez_compressed(os.path.join(HERE, "ddib_sd21_denoiser_32_s2.npz"), images=x.numpy(), labels=labels.numpy(),
+                        inverted=inverted.numpy(), out_images=out, unet_out_t1500=eps.numpy())
+    print("wrote ddib_sd21_denoiser_32_s2.npz")
+
+
 if __name__ == "__main__":
-    if "--sd" in sys.argv:
+    if "--sd21-denoiser" in sys.argv:
+        main_sd21_denoiser()
+    elif "--sd" in sys.argv:
         main_sd()
     elif "--google" in sys.argv:
         main_google()
@@ -115,3 +132,4 @@ if __name__ == "__main__":
         main()
         main_sd()
         main_google()
+        main_sd21_denoiser()

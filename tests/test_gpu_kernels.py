@@ -361,6 +361,31 @@ def test_attention_dma_staged_loose_bound_and_lse(env):
     assert float((lse.cpu() - ref_lse).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_attention_dma_staged_zero_key_bound_falls_back(env, mode):
+    """A kmax2 slot that under-estimates max |k|^2 -- here ZERO, what a caller that skipped pd_linear / reused a pd_zero'ed slot
+    would pass -- violates the documented precondition; the kernel's safety net (a first-sub-tile score above the implied bound
+    -> exact running-maximum path) must still return finite, correct probabilities instead of an unbounded 2^(s - m) (fp16: inf).
+    Keys grow towards the end of the sequence so that the late scores exceed the first tile's by far more than the fp16 rescale
+    threshold."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, N = 4, 32, 2048
+    g = torch.Generator().manual_seed(29)
+    q, k, v = (bf16_round(torch.randn(B, heads, N, 8, generator=g), mode) for _ in range(3))
+    k = bf16_round(k * torch.linspace(0.5, 12.0, N).view(1, 1, N, 1), mode)
+    q = bf16_round(q * 3.0, mode)
+    Q, K, V = (t.to(tdt).to(dev).contiguous() for t in (q, k, v))
+    out = torch.full((B, N, heads * 8), float("nan"), dtype=tdt, device=dev)
+    a = L.AttnArgs(dtype=code, B=B, heads=heads, N=N, q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), out=out.data_ptr(),
+                   kmax2=torch.zeros((B, heads), device=dev).data_ptr())
+    L.check(lib.pd_attn_d8(C.byref(a), stream()), "pd_attn_d8")
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, heads * 8)
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref) < (8e-3 if mode == "bf16" else 1e-3)
+
+
 def test_conv_in(env):
     L, lib, _, dev = env
     g = torch.Generator().manual_seed(9)

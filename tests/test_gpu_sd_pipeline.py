@@ -181,6 +181,28 @@ def test_sd_img2img_full_size_stack_vs_oracle():
     got = P.ddib(pipe, x.cuda(), labels.cuda(), (1 - labels).cuda(), 2, generator=torch.Generator().manual_seed(5))
     assert got.shape == want.shape == (1, 512, 512, 3)
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-3
+    # the same stack on the 16-bit engines: fp16 is configs[4]'s stated dtype (img2img_comparison.py:56-59) -- 512x512 VAE
+    # activations and 1 280-channel UNet activations in fp16 storage must stay finite (a failure names the buffer), then parity
+    from conftest import record_error
+    from phendiff_amd.diagnostics import assert_finite_activations
+    del pipe, unet, vae
+    torch.cuda.empty_cache()
+    for mode, tol_lat, tol_img in (("fp16", 4e-3, 8e-3), ("bf16", 3e-2, 6e-2)):
+        unet = P.SDUNet2DConditionModel(compute_dtype=mode, **P.SD21_UNET_CONFIG)
+        unet.load_state_dict(r_unet.state_dict())
+        vae = P.AutoencoderKL(compute_dtype=mode, **P.SD_VAE_CONFIG)
+        vae.load_state_dict(r_vae.state_dict())
+        pipe = P.CustomStableDiffusionImg2ImgPipeline(vae.to("cuda:0"), unet.to("cuda:0"), P.DDIMScheduler(**sched_cfg), emb)
+        lat, _ = P.LDM_preprocess(pipe, x.cuda(), [labels.cuda()], generator=torch.Generator().manual_seed(5))
+        got = P.ddib(pipe, x.cuda(), labels.cuda(), (1 - labels).cuda(), 2, generator=torch.Generator().manual_seed(5))
+        rep = assert_finite_activations(list(unet._plans.values()) + list(vae._plans.values()), what=f"SD img2img stack, {mode} engine",
+                                        limit=65504.0 if mode == "fp16" else float("inf"))
+        assert np.isfinite(got).all()
+        e_lat = record_error(float((lat.cpu() - latents).norm() / latents.norm()))
+        e_img = record_error(float(np.linalg.norm(got - want) / np.linalg.norm(want)))
+        assert e_lat < tol_lat and e_img < tol_img, (mode, e_lat, e_img, rep["__max__"])
+        del pipe, unet, vae
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])

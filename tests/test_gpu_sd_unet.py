@@ -68,7 +68,7 @@ def test_sd_unet_forward(mode, tol, cfg, size):
 def test_sd21_unet_full_size_forward_vs_oracle():
     """The real SD-2.1 UNet2DConditionModel configuration (865.9 M parameters: 320 / 640 / 1280 / 1280 channels, 5 / 10 / 20 / 20
     heads of 64, 1024-wide context, 1280-wide time embedding with 22 720 projection outputs) at 64x64 latents, random init:
-    exact-fp32 and bf16 engines against the CPU oracle -- the widths at which the split time-embedding kernels, the fused
+    exact-fp32, bf16 and fp16 engines against the CPU oracle -- the widths at which the split time-embedding kernels, the fused
     GEGLU GEMMs and the pre-applied GroupNorm path are actually taken."""
     import os
     import phendiff_amd as P
@@ -91,6 +91,18 @@ def test_sd21_unet_full_size_forward_vs_oracle():
     m16.load_state_dict(sd)
     got16 = m16.to("cuda:0")(x.cuda(), ts.cuda(), ehs).sample
     assert rel(got16, ref) < 4e-2, rel(got16, ref)
+    del m16
+    torch.cuda.empty_cache()
+    # fp16 storage (BASELINE configs[4]'s dtype) at the real widths: 1 280-channel activations are where fp16's 65 504 ceiling
+    # could bite -- every buffer of the forward must be finite (the failure names the block), then parity with the oracle
+    from phendiff_amd.diagnostics import assert_finite_activations
+    mh = P.SDUNet2DConditionModel(compute_dtype="fp16", **P.SD21_UNET_CONFIG)
+    mh.load_state_dict(sd)
+    mh = mh.to("cuda:0")
+    goth = mh(x.cuda(), ts.cuda(), ehs).sample
+    rep = assert_finite_activations(list(mh._plans.values()), what="SD-2.1 UNet fp16 forward")
+    assert rep["__max__"][1] < 65504.0 / 8, rep["__max__"]          # three bits of headroom on random-init weights
+    assert bool(torch.isfinite(goth).all()) and rel(goth, ref) < 5e-3, rel(goth, ref)
 
 
 def test_sd_unet_rejects_bad_calls():

@@ -105,6 +105,19 @@ def test_unet_forward_config_variants(mode, tol, variant):
         runner = P.DDIBGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
         got_g = runner.run(x.cuda(), ilab.cuda(), (1 - ilab).cuda()).images
         assert np.array_equal(got_g.cpu().numpy(), got)
+    else:
+        # the captured trajectories pass one int64 label per row: the other class-embedding forms are refused at construction
+        # (they used to read rows * time_embed_dim floats from that buffer), and a short buffer is refused by temb_rows
+        pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
+        with pytest.raises(NotImplementedError, match="class_embed_type"):
+            P.DDIBGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
+        with pytest.raises(NotImplementedError, match="class_embed_type"):
+            P.CFGForwardStartGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
+        if variant.get("class_embed_type") == "identity":
+            plan = m.plan_for(3, 32, 32, torch.device("cuda:0"))
+            with pytest.raises(ValueError, match="time_embed_dim"):
+                plan.temb_rows(torch.zeros(3, device="cuda"), torch.zeros(3, dtype=torch.int64, device="cuda"), None,
+                               torch.cuda.current_stream().cuda_stream)
 
 
 def test_unet_forward_small_denoiser_f32():
@@ -144,6 +157,51 @@ def test_unet_forward_orig_google_ddpm(mode, tol):
         out = graph.run(xg.cuda(), labels.cuda(), (1 - labels).cuda())
         torch.cuda.synchronize()
         assert rel(out.inverted, d["inverted"]) < 2e-5 and rel(out.images, d["out_images"]) < 2e-5
+
+
+# models_configs/denoiser/SD_2-1_config.json -- the fourth shipped denoiser: pixel-space class-conditional UNet with
+# SD-2.1 widths (320 / 640 / 1280 / 1280: GroupNorm groups of 10 / 20 / 40 channels), d = 8 attention on three levels + the mid block
+# (40 / 80 / 160 heads), 641 914 883 parameters.  One oracle instance (17 s to initialise on the host) serves the three engines.
+@pytest.fixture(scope="module")
+def sd21_denoiser_oracle():
+    from oracle import CondUNet2DRef, UNET_CONFIGS as REF_CONFIGS
+    torch.manual_seed(0)                      # the seed / construction order of tests/golden/make_golden.py --sd21-denoiser
+    return CondUNet2DRef(**dict(REF_CONFIGS["SD_2-1_config"], sample_size=32)).eval()
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 2.5e-2), ("fp16", 3e-3)])
+def test_unet_forward_sd21_denoiser_config(sd21_denoiser_oracle, mode, tol):
+    import warnings
+    import phendiff_amd as P
+    r = sd21_denoiser_oracle
+    # from_config takes the file's key set: the six UNet2DConditionModel keys are dropped with a warning, as diffusers does
+    file_cfg = dict(P.UNET_CONFIGS["SD_2-1_config"], **{k: None for k in P.configs.UNET_CONFIG_IGNORED_KEYS}, sample_size=32)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = P.CustomCondUNet2DModel.from_config(file_cfg, compute_dtype=mode)
+    assert any("will be ignored" in str(x.message) and "use_linear_projection" in str(x.message) for x in w)
+    assert sum(p.numel() for p in m.parameters()) == 641_914_883
+    m.load_state_dict(r.state_dict())
+    m = m.to("cuda:0")
+    assert [len(b.attentions) for b in m.down_blocks if hasattr(b, "attentions")] == [2, 2, 2]
+    for size, t in ((32, 2999), (64, 40)):
+        x, labels = synth_batch(2, size)
+        with torch.no_grad():
+            ref = r(x, t, class_labels=labels).sample
+        got = m(x.cuda(), t, class_labels=labels.cuda()).sample
+        assert got.shape == ref.shape and rel(got, ref) < tol, (mode, size, rel(got, ref))
+    # committed oracle vectors (tests/golden/make_golden.py --sd21-denoiser): one evaluation + a DDIB class transfer, S = 2, 32x32
+    d = np.load(os.path.join(GOLDEN, "ddib_sd21_denoiser_32_s2.npz"))
+    xg, labels = torch.from_numpy(d["images"]), torch.from_numpy(d["labels"])
+    assert rel(m(xg.cuda(), 1500, class_labels=labels.cuda()).sample, d["unet_out_t1500"]) < tol
+    pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
+    graph = P.DDIBGraph(pipe, batch_size=2, num_inference_steps=2, height=32, width=32)
+    out = graph.run(xg.cuda(), labels.cuda(), (1 - labels).cuda())
+    torch.cuda.synchronize()
+    traj_tol = {"f32": 2e-5, "bf16": 1.5e-2, "fp16": 2e-3}[mode]
+    assert rel(out.inverted, d["inverted"]) < traj_tol and rel(out.images, d["out_images"]) < traj_tol
+    del m, graph, pipe
+    torch.cuda.empty_cache()
 
 
 def test_unet_rejects_bad_calls():
@@ -441,16 +499,28 @@ def test_full_size_full_length_trajectory_vs_oracle():
         ref, ref_inv = ddib_ref(ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**cfg)), x, labels, 1 - labels, 50)
     t_cpu = time.time() - t0
     ref = torch.as_tensor(ref)
-    res, res_inv = {}, {}
-    for mode, m in (("f32", m32), ("bf16", make_pair("super_small", 256, "bf16")[1])):
+    res, res_inv, lsb, lsb_mean = {}, {}, {}, {}
+    # A20: the metric's product is an 8-bit image -- uint8 = round(255 * clamp(x / 2 + 0.5, 0, 1)) of the oracle's output
+    ref_u8 = (ref.numpy() * 255).round().astype(np.int16)
+    for mode in ("f32", "bf16", "fp16"):
+        m = m32 if mode == "f32" else make_pair("super_small", 256, mode)[1]
         pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**cfg))
         out = P.DDIBGraph(pipe, batch_size=1, num_inference_steps=50).run(x.cuda(), labels.cuda(), (1 - labels).cuda())
         torch.cuda.synchronize()
         res[mode], res_inv[mode] = rel(out.images.cpu(), ref), rel(out.inverted.cpu(), ref_inv)
+        d = np.abs(out.images_u8.cpu().numpy().astype(np.int16) - ref_u8)
+        lsb[mode], lsb_mean[mode] = int(d.max()), float(d.mean())
+        from conftest import record_error
+        record_error(float(lsb[mode]))
     print(f"full-length oracle trajectory: {t_cpu:.1f} s on the CPU; rel-L2 of the final images: f32 engine {res['f32']:.2e}, "
-          f"bf16 engine {res['bf16']:.2e}; of the inverted latents after 50 steps: {res_inv['f32']:.2e} / {res_inv['bf16']:.2e}")
+          f"bf16 engine {res['bf16']:.2e}, fp16 engine {res['fp16']:.2e}; of the inverted latents after 50 steps: {res_inv['f32']:.2e} / "
+          f"{res_inv['bf16']:.2e} / {res_inv['fp16']:.2e}; worst uint8 pixel (LSB) {lsb}, mean |d| {lsb_mean}")
     # measured: f32 6.1e-7 / 5.6e-7, bf16 3.4e-3 / 4.1e-3 (images / inverted latents)
     assert res["f32"] < 2e-5 and res_inv["f32"] < 2e-5 and res["bf16"] < 1.0e-2 and res_inv["bf16"] < 1.0e-2
+    assert res["fp16"] < 2e-3 and res_inv["fp16"] < 2e-3
+    # worst 8-bit pixel of the 65 536 x 3 after 50 + 50 steps: the bench engine's (bf16) contract at full
+    # length, stated as measured x ~2 (bounds set from the round-3 run recorded in profiles/r3_parity_errors.json)
+    assert lsb["f32"] <= 1 and lsb["bf16"] <= 16 and lsb["fp16"] <= 4, lsb
 
 
 def test_forward_slices_batches_beyond_the_2gib_tensor_limit(monkeypatch):

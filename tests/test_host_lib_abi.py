@@ -26,7 +26,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/phendiff_hip.h but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype in phendiff_amd/_lib.py"
     assert sorted(L.SYMBOLS) == names
-    assert lib.pd_abi_version() == 1
+    # one version number in three places: the header's macro, the binding's constant, the library's answer (bumped whenever an
+    # args struct grows or an entry point is added: r2 added trailing pointer fields, r3 = 3)
+    import re
+    macro = int(re.search(r"#define PD_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.pd_abi_version() == L.ABI_VERSION == macro
     assert lib.pd_last_error() is not None
 
 
