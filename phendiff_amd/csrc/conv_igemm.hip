@@ -300,26 +300,33 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   PD_STAMP(7);
   // bias / temb first: they are older than the HBM loads below in the in-order vmcnt queue, so initialising the
   // accumulators does not wait for the activation tile
+  // Round 3: all of them issued back to back, ONE wait -- the per-group `if (temb) { load; add }` form made the compiler wait for
+  // each (bias, temb) pair before issuing the next: 4 serial L2 round trips = 4.6k of a 64-channel workgroup's 37k cycles
+  // (s_memtime stamps).  The time-embedding rows come through a buffer resource (no tensor -> zero records -> zeros; the padded
+  // channels of a partial last tile lie beyond the resource and read zeros).
   f32x4 bt[NCO][4];
+  u32x4 tv[NCO][4];
+  if (wave_active) {
+    const __amdgpu_buffer_rsrc_t rtemb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.temb ? p.temb : p.bias), 0,
+        p.temb ? ((unsigned)n * (unsigned)p.temb_stride + (unsigned)p.Cout) * 4u : 0u, 0x00020000);   // up to the end of row n's slice
+#pragma unroll
+    for (int c = 0; c < NCO; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = (ct32 + 2 * c) * 32 + 8 * g + 4 * h;
+        bt[c][g] = *(const f32x4*)(p.bias + co);
+        tv[c][g] = __builtin_amdgcn_raw_buffer_load_b128(rtemb, (unsigned)(n * p.temb_stride + co) * 4u, 0, 0);
+      }
+  }
+  if (!p.im2col3) issue_loads(0);      // everything below overlaps the HBM latency of chunk 0
   if (wave_active) {
 #pragma unroll
     for (int c = 0; c < NCO; ++c)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = (ct32 + 2 * c) * 32 + 8 * g + 4 * h;
-      bt[c][g] = *(const f32x4*)(p.bias + co);
-      if (p.temb) {
-        const float* tp = p.temb + (size_t)n * p.temb_stride + co;
-        if ((ct32 + 2 * c) * 32 + 32 <= p.Cout) {          // wave-uniform: all 32 channels real
-          bt[c][g] += *(const f32x4*)tp;
-        } else {
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) if (co + i < p.Cout) bt[c][g][i] += tp[i];
-        }
-      }
-    }
+        for (int i = 0; i < 4; ++i) bt[c][g][i] += __uint_as_float(tv[c][g][i]);
   }
-  if (!p.im2col3) issue_loads(0);      // everything below overlaps the HBM latency of chunk 0
   PD_STAMP(8);
   // accumulators start at bias[co] + temb[n][co] (lane (pixel, h), register i <-> co = 8(i>>2) + 4h + (i&3)):
   // the epilogue then has no per-channel loads at all

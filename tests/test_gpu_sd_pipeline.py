@@ -187,7 +187,7 @@ def test_sd_img2img_full_size_stack_vs_oracle():
     from phendiff_amd.diagnostics import assert_finite_activations
     del pipe, unet, vae
     torch.cuda.empty_cache()
-    for mode, tol_lat, tol_img in (("fp16", 4e-3, 8e-3), ("bf16", 3e-2, 6e-2)):
+    for mode, tol_lat, tol_img in (("fp16", 1e-3, 6e-3), ("bf16", 6e-3, 5e-2)):     # measured 3.7e-4 / 3.1e-3 and 3.0e-3 / 2.5e-2
         unet = P.SDUNet2DConditionModel(compute_dtype=mode, **P.SD21_UNET_CONFIG)
         unet.load_state_dict(r_unet.state_dict())
         vae = P.AutoencoderKL(compute_dtype=mode, **P.SD_VAE_CONFIG)

@@ -102,7 +102,7 @@ def test_sd21_unet_full_size_forward_vs_oracle():
     goth = mh(x.cuda(), ts.cuda(), ehs).sample
     rep = assert_finite_activations(list(mh._plans.values()), what="SD-2.1 UNet fp16 forward")
     assert rep["__max__"][1] < 65504.0 / 8, rep["__max__"]          # three bits of headroom on random-init weights
-    assert bool(torch.isfinite(goth).all()) and rel(goth, ref) < 5e-3, rel(goth, ref)
+    assert bool(torch.isfinite(goth).all()) and rel(goth, ref) < 3e-3, rel(goth, ref)       # measured 1.3e-3
 
 
 def test_sd_unet_rejects_bad_calls():

@@ -517,10 +517,10 @@ def test_full_size_full_length_trajectory_vs_oracle():
           f"{res_inv['bf16']:.2e} / {res_inv['fp16']:.2e}; worst uint8 pixel (LSB) {lsb}, mean |d| {lsb_mean}")
     # measured: f32 6.1e-7 / 5.6e-7, bf16 3.4e-3 / 4.1e-3 (images / inverted latents)
     assert res["f32"] < 2e-5 and res_inv["f32"] < 2e-5 and res["bf16"] < 1.0e-2 and res_inv["bf16"] < 1.0e-2
-    assert res["fp16"] < 2e-3 and res_inv["fp16"] < 2e-3
+    assert res["fp16"] < 1e-3 and res_inv["fp16"] < 1e-3      # measured 4.3e-4 / 5.0e-4
     # worst 8-bit pixel of the 65 536 x 3 after 50 + 50 steps: the bench engine's (bf16) contract at full
     # length, stated as measured x ~2 (bounds set from the round-3 run recorded in profiles/r3_parity_errors.json)
-    assert lsb["f32"] <= 1 and lsb["bf16"] <= 16 and lsb["fp16"] <= 4, lsb
+    assert lsb["f32"] <= 1 and lsb["bf16"] <= 6 and lsb["fp16"] <= 2, lsb      # measured 1 / 3 / 1
 
 
 def test_forward_slices_batches_beyond_the_2gib_tensor_limit(monkeypatch):
