@@ -134,7 +134,9 @@ typedef struct {
   int ksize;                /* 1 or 3 */
   int stride;               /* 1 or 2 (3x3 only) */
   int pad;                  /* 1 for 3x3 pad 1; 0 for 1x1 or the asymmetric (0,1,0,1) downsample */
-  int upsample;             /* 1: nearest x2 before the conv (Upsample2D); 2: zero-stuffed x2 (input gradient of a stride-2 conv) */
+  int upsample;             /* 1: nearest x2 before the conv (Upsample2D); 2: zero-stuffed x2, samples at the even positions (input
+                               gradient of a stride-2 pad-1 conv); 3: zero-stuffed x2, samples at the odd positions (input gradient of
+                               Downsample2D(padding=0): pad (0,1,0,1) then an unpadded stride-2 conv) */
   int silu;                 /* 1: SiLU after the affine */
   int out_mode;             /* pd_out_mode */
   int heads;                /* PD_OUT_QKV_HEADS: number of heads (Cout = 3*heads*8) */
@@ -507,8 +509,25 @@ typedef struct {
   const void* q; int q_stride;
   const void* k; const void* v; int kv_stride;
   void* out; int out_stride;
+  float* lse;   /* optional out [B][heads][Nq]: log2-domain log-sum-exp of the scaled scores (kept for pd_attn_wide_bwd), or NULL */
 } pd_attn_wide_args;
 int pd_attn_wide(const pd_attn_wide_args* a, void* stream);
+
+/* pd_attn_wide_bwd: gradient of pd_attn_wide (autograd of F.scaled_dot_product_attention, one wide head per D channels): what
+ * accelerator.backward(loss) (utils_training.py:436) runs for the attention blocks of orig_google_ddpm_model_denoiser.json
+ * (attention_head_dim null -> one 512-channel head, cond_unet_2d.py:176-197).  P is recomputed from the forward's lse.
+ *   o / dout: the forward's output and the gradient w.r.t. it, [B][Nq][o_stride];  delta: workspace [B][heads][Nq] (written by the
+ *   dQ pass, read by the dK / dV pass);  dq: [B][Nq][dq_stride];  dk, dv: [B][Nkv][dkv_stride].  bf16 / fp32 (fp16: inference only). */
+typedef struct {
+  int dtype, B, heads, D, Nq, Nkv; float scale;
+  const void* q; int q_stride;
+  const void* k; const void* v; int kv_stride;
+  const void* o; const void* dout; int o_stride;
+  const float* lse; float* delta;
+  void* dq; int dq_stride;
+  void* dk; void* dv; int dkv_stride;
+} pd_attn_wide_bwd_args;
+int pd_attn_wide_bwd(const pd_attn_wide_bwd_args* a, void* stream);
 
 /* pd_latent_sample: AutoencoderKL.encode(x).latent_dist.sample(generator) (or .mode() when noise = NULL) times the
  * pipeline's scaling_factor (custom_pipeline_stable_diffusion_img2img.py:431-433, utils_Img2Img.py:833-836):

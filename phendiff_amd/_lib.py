@@ -165,7 +165,14 @@ class LinearArgs(C.Structure):
 class AttnWideArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int),
                 ("scale", C.c_float), ("q", vp), ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("out", vp),
-                ("out_stride", C.c_int)]
+                ("out_stride", C.c_int), ("lse", vp)]
+
+
+class AttnWideBwdArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int),
+                ("scale", C.c_float), ("q", vp), ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("o", vp),
+                ("dout", vp), ("o_stride", C.c_int), ("lse", vp), ("delta", vp), ("dq", vp), ("dq_stride", C.c_int), ("dk", vp),
+                ("dv", vp), ("dkv_stride", C.c_int)]
 
 
 class AttnD64BwdArgs(C.Structure):
@@ -285,6 +292,7 @@ SYMBOLS = {
     "pd_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
     "pd_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "pd_attn_wide": (C.c_int, [C.POINTER(AttnWideArgs), vp]),
+    "pd_attn_wide_bwd": (C.c_int, [C.POINTER(AttnWideBwdArgs), vp]),
     "pd_latent_sample": (C.c_int, [C.POINTER(LatentSampleArgs), vp]),
     "pd_attn_d64_bwd": (C.c_int, [C.POINTER(AttnD64BwdArgs), vp]),
     "pd_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdArgs), vp]),
@@ -333,7 +341,10 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     if l.pd_abi_version() != ABI_VERSION:
-        raise PhenDiffHipError(f"ABI mismatch: library {l.pd_abi_version()} != binding {ABI_VERSION}")
+        # same-box A/B against a library built from an older revision (scripts/build_rev.sh, scripts/ab_forward.py): the caller
+        # vouches that the structs it exercises did not change between the two
+        if not (os.environ.get("PD_ALLOW_ABI_MISMATCH") and LIB_PATH != os.path.join(_HERE, "libphendiff_hip.so")):
+            raise PhenDiffHipError(f"ABI mismatch: library {l.pd_abi_version()} != binding {ABI_VERSION}")
     _lib = l
     return l
 

@@ -121,7 +121,13 @@ template <typename T> struct AttnOps {
     if constexpr (std::is_same<T, bf16_t>::value) {
       typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const bf2 pr = __builtin_bit_cast(bf2, w[j]); n2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, n2, false); }
+      for (int j = 0; j < 4; ++j) {
+        // copy the element to a scalar first: hipcc 7.2 folds `__builtin_bit_cast(X, vec[j])` of an ext-vector ELEMENT to element 0
+        // for every j (round-3 finding: this norm was 4 x the first pair's -- the same defect that made round 2 blame v_dot2_f32_f16)
+        const uint32_t wj = w[j];
+        const bf2 pr = __builtin_bit_cast(bf2, wj);
+        n2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, n2, false);
+      }
     } else {
       // fp16: plain fp32 arithmetic on the unpacked values (v_dot2_f32_f16 through __builtin_amdgcn_fdot2 returned norms that
       // under-estimated |k|^2 on gfx950, which made the score bound below invalid: p = 2^(s - m) overflowed fp16)

@@ -114,8 +114,10 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
       const int u = pix / IN_TW, vv = pix - u * IN_TW;
       const int iy = y0 * STRIDE - p.pad + u, ix = x0 * STRIDE - p.pad + vv;
       // upsample 1: nearest x2 (Upsample2D);  upsample 2: zero-stuffed x2 (the stride-2 conv's input gradient is a
-      // stride-1 conv over dY with zeros between its samples)
-      if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && (p.upsample != 2 || (((iy | ix) & 1) == 0))) {
+      // stride-1 conv over dY with zeros between its samples: samples at the EVEN positions for a pad-1 forward,
+      // upsample 3: at the ODD positions for Downsample2D(padding=0)'s (0,1,0,1)-padded forward)
+      const bool phase_ok = p.upsample < 2 || (p.upsample == 2 ? ((iy | ix) & 1) == 0 : ((iy & ix) & 1) == 1);
+      if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && phase_ok) {
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
         v = (n * p.Hin + sy) * p.Win + sx;
       }
@@ -159,11 +161,27 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
       for (int j = 0; j < 4; ++j) { sc[j] = a0[j]; sc[4 + j] = a1[j]; sh[j] = b0[j]; sh[4 + j] = b1[j]; }
     }
   };
+  // Padding pixels (spix < 0) hold zeros in BOTH LDS buffers from the start of the kernel (zero_padding below) and are never
+  // written again: the per-piece "if (!valid) zero the 8 transformed values" (5 vector instructions per piece, ~6 % of the
+  // kernel's vector work by the round-3 instruction counters) becomes an exec-masked store.
   auto write_piece = [&](int i, unsigned char* buf) {
     const int pix = (tid + 256 * i) >> 2;
-    if (pix < NPIX)
-      Stage<T>::xform_store(buf + pix * PITCH + sub * 8 * E::BYTES, stage[i], sc, sh, affine && !stage_plain,
-                            do_silu && !stage_plain, spix[i] >= 0);
+    if (pix < NPIX && spix[i] >= 0)
+      Stage<T>::template xform_store<false>(buf + pix * PITCH + sub * 8 * E::BYTES, stage[i], sc, sh, affine && !stage_plain,
+                                            do_silu && !stage_plain, true);
+  };
+  auto zero_padding = [&]() {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int pix = (tid + 256 * i) >> 2;
+      if (pix < NPIX && spix[i] < 0) {
+        unsigned char* d = lds + pix * PITCH + sub * 8 * E::BYTES;
+#pragma unroll
+        for (int q = 0; q < (DB ? 2 : 1); ++q)
+#pragma unroll
+          for (int b16 = 0; b16 < 8 * E::BYTES; b16 += 16) *(u32x4*)(d + q * LDS_TILE + b16) = (u32x4)(0u);
+      }
+    }
   };
 
   // conv_in (cond_unet_2d.py:127-129): the 3x3 conv over <= 3 fp32 NCHW channels is run as a 1x1 conv over 32 virtual
@@ -214,8 +232,15 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   f32x16 acc[NCO][NF];
   const int main_ksteps = (TAIL ? p.n_main : p.nchunks) * KSTEPS;
   const int all_ksteps = main_ksteps + (TAIL ? p.n_tail * 2 : 0);
-  const T* wbase = (const T*)p.w + (size_t)ct32 * all_ksteps * 512 + lane * 8;
-  const size_t wstep = (size_t)2 * all_ksteps * 512;   // NCO = 2: elements between this wave's two 32-co tiles
+  // Weight fragments through a buffer resource: address = base + per-lane VGPR offset (fixed) + SGPR offset (k-step, tile):
+  // the per-k-step address is scalar arithmetic (round 3: the 64-bit VGPR address add per load was 5 % of the kernel's
+  // vector instructions), and a prefetch past the last k-step is out of range = zeros instead of a clamped index.
+  const unsigned wfrag = 512u * E::BYTES;                                       // bytes of one 32 co x 16 k fragment block
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)(p.Cout_pad / 32) * (unsigned)all_ksteps * wfrag, 0x00020000);
+  const unsigned wlane = (unsigned)lane * 8u * E::BYTES;
+  const unsigned wtile = (unsigned)ct32 * (unsigned)all_ksteps * wfrag;         // this wave's (first) 32-co tile
+  const unsigned wstep = 2u * (unsigned)all_ksteps * wfrag;                     // NCO = 2: bytes between this wave's two 32-co tiles
+  auto load_w = [&](int c, int kstep) { return E::load_buf(rw, wlane, wtile + (unsigned)c * wstep + (unsigned)PD_WIDX(kstep) * wfrag); };
 
   // Weight (A) fragments live in a register ring of AR entries, prefetched AD k-steps ahead and CONTINUOUSLY across
   // chunk boundaries (a chunk's fragments are contiguous with the next chunk's), so L2 latency (~600-800 cycles under
@@ -225,7 +250,6 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   constexpr int AR = (KSTEPS % 3 == 0) ? 3 : 2;
   constexpr int AD = AR - 1;
   Frag aring[AR][NCO];
-  const int last_kstep = all_ksteps - 1;
 
   // one chunk of MFMAs out of `buf`; when DB, pieces of the NEXT chunk are transformed + written to `nbuf` in between
   auto mma_chunk = [&](int chunk, const unsigned char* buf, unsigned char* nbuf, auto have_next_c, auto active_c) {
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if constexpr (ACTIVE) {
 #pragma unroll
-        for (int c = 0; c < NCO; ++c) aring[(ks + AD) % AR][c] = E::load(wbase + c * wstep + (size_t)PD_WIDX(min(g0 + ks + AD, last_kstep)) * 512);
+        for (int c = 0; c < NCO; ++c) aring[(ks + AD) % AR][c] = load_w(c, g0 + ks + AD);
         {
           const int tap = ks >> 1, s = ks & 1;
           const int toff = ((tap / KS) * IN_TW + (tap % KS)) * PITCH + s * 16 * E::BYTES;
@@ -271,10 +295,10 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
     constexpr bool ACTIVE = decltype(active_c)::value;
     constexpr int CENTER = ((KS / 2) * IN_TW + (KS / 2)) * PITCH;
     if constexpr (ACTIVE) {
-      const T* wt = wbase + (size_t)(main_ksteps + (chunk - p.n_main) * 2) * 512;
+      const int kt = main_ksteps + (chunk - p.n_main) * 2;
       Frag a0[NCO], a1[NCO];
 #pragma unroll
-      for (int c = 0; c < NCO; ++c) { a0[c] = E::load(wt + c * wstep); a1[c] = E::load(wt + c * wstep + 512); }
+      for (int c = 0; c < NCO; ++c) { a0[c] = load_w(c, kt); a1[c] = load_w(c, kt + 1); }
       Frag b0[NF], b1[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) { b0[f] = E::load(buf + rbase[f] + CENTER); b1[f] = E::load(buf + rbase[f] + CENTER + 16 * E::BYTES); }
@@ -346,9 +370,10 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 #pragma unroll
     for (int i = 0; i < AD; ++i)
 #pragma unroll
-      for (int c = 0; c < NCO; ++c) aring[i][c] = E::load(wbase + c * wstep + (size_t)PD_WIDX(min(i, last_kstep)) * 512);
+      for (int c = 0; c < NCO; ++c) aring[i][c] = load_w(c, i);
   }
   PD_STAMP(9);
+  if (!p.im2col3) zero_padding();
   if (DB) {
     if (p.im2col3) {
       stage_im2col(lds);
@@ -606,11 +631,15 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
     // 0.184 -> 0.194; 64 -> 128 @128^2 0.110 -> 0.116: K too small).  PD_CONV_NCO=1 / 2: diagnostic override (same-box A/B).
     if constexpr (sizeof(T) == 2) {
       static const int nco_env = getenv("PD_CONV_NCO") ? atoi(getenv("PD_CONV_NCO")) : 0;
-      static int cus = 0;
-      if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      static int cus_of[16] = {0};      // per device (a process that drives several GPUs: each its own count; benign race: same value)
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+      if (cus_of[dev] == 0) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus_of[dev] = c;
       }
+      const int cus = cus_of[dev];
       bool nco2 = false;
       if (w >= 32 && p.Cout_pad % 128 == 0 && p.Cout == p.Cout_pad && p.out_mode != PD_OUT_NCHW_F32) {
         const long long wgs1 = (long long)((p.Wout + 31) / 32) * ((p.Hout + 7) / 8) * (p.Cout_pad / 64) * p.B, wgs2 = wgs1 / 2;
@@ -661,7 +690,7 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   PD_CHECK((a->scale == nullptr) == (a->shift == nullptr), PD_ERR_ARG, "pd_conv: scale/shift mismatch");
   PD_CHECK(a->ksize == 1 || a->ksize == 3, PD_ERR_UNSUPPORTED, "pd_conv: ksize %d", a->ksize);
   PD_CHECK(a->stride == 1 || (a->stride == 2 && a->ksize == 3), PD_ERR_UNSUPPORTED, "pd_conv: stride %d", a->stride);
-  PD_CHECK(!(a->upsample && a->stride != 1), PD_ERR_UNSUPPORTED, "pd_conv: upsample with stride");
+  PD_CHECK(!(a->upsample && a->stride != 1) && a->upsample >= 0 && a->upsample <= 3, PD_ERR_UNSUPPORTED, "pd_conv: upsample %d with stride %d", a->upsample, a->stride);
   {
     const int hc = a->upsample ? 2 * a->Hin : a->Hin, wc = a->upsample ? 2 * a->Win : a->Win;
     const int extra = (a->ksize == 3 && a->pad == 0) ? 1 : 0;   // asymmetric (0,1,0,1) zero pad of Downsample2D(padding=0)

@@ -103,6 +103,12 @@ template <> struct Elem<float> {
   static __device__ __forceinline__ Frag load(const void* p) {
     Frag f; f.lo = *(const f32x4*)p; f.hi = *((const f32x4*)p + 1); return f;
   }
+  // fragment through a buffer resource: per-lane byte offset in a VGPR, the wave-uniform part in an SGPR
+  static __device__ __forceinline__ Frag load_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0);
+    Frag f; f.lo = __builtin_bit_cast(f32x4, a); f.hi = __builtin_bit_cast(f32x4, b); return f;
+  }
   static __device__ __forceinline__ void store(void* p, const Frag& f) { *(f32x4*)p = f.lo; *((f32x4*)p + 1) = f.hi; }
   // D[32x32] += A[32 x 8k] * B[8k x 32]; exact fp32 (v_mfma_f32_32x32x2_f32 x4, k order consistent in A and B)
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
@@ -130,6 +136,10 @@ template <> struct Elem<bf16_t> {
   }
   static __device__ __forceinline__ Frag zero() { Frag f; f.v = (s16x8)(0); return f; }
   static __device__ __forceinline__ Frag load(const void* p) { Frag f; f.v = *(const s16x8*)p; return f; }
+  static __device__ __forceinline__ Frag load_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    Frag f; f.v = __builtin_bit_cast(s16x8, (u4)__builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0)); return f;
+  }
   static __device__ __forceinline__ void store(void* p, const Frag& f) { *(s16x8*)p = f.v; }
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return mma16(a.v, b.v, c); }
   static __device__ __forceinline__ f32x16 mma16(s16x8 a, s16x8 b, f32x16 c) {      // D += A[32 x 16] . B[16 x 32] on raw 16-bit lanes
@@ -159,6 +169,10 @@ template <> struct Elem<half_t> {
   }
   static __device__ __forceinline__ Frag zero() { Frag f; f.v = (s16x8)(0); return f; }
   static __device__ __forceinline__ Frag load(const void* p) { Frag f; f.v = *(const s16x8*)p; return f; }
+  static __device__ __forceinline__ Frag load_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    Frag f; f.v = __builtin_bit_cast(s16x8, (u4)__builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0)); return f;
+  }
   static __device__ __forceinline__ void store(void* p, const Frag& f) { *(s16x8*)p = f.v; }
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) { return mma16(a.v, b.v, c); }
   static __device__ __forceinline__ f32x16 mma16(s16x8 a, s16x8 b, f32x16 c) {

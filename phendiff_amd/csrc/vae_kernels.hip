@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(const pd_attn_wide_args 
   l += __shfl_xor(l, 32);
   if (query < a.Nq) {
     const float inv = 1.0f / l;
+    // log2-domain log-sum-exp of the scaled scores (kept for pd_attn_wide_bwd): identical in the four waves
+    if (a.lse && wave == 0 && h == 0) a.lse[((size_t)b * a.heads + head) * a.Nq + query] = m + __builtin_amdgcn_logf(l);
     T* dst = (T*)a.out + ((size_t)b * a.Nq + query) * a.out_stride + head * D + wave * SL + 4 * h;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -195,6 +197,200 @@ static int dispatch_attn_wide(const pd_attn_wide_args* a, hipStream_t st) {
     case 512: return launch_attn_wide<T, 512>(a, st);
   }
   set_error("pd_attn_wide: head dimension %d not built (128, 256, 512)", a->D);
+  return PD_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pd_attn_wide_bwd: gradient of pd_attn_wide (autograd of F.scaled_dot_product_attention with one wide head per D channels) --
+// what `accelerator.backward(loss)` runs for the attention blocks of models_configs/denoiser/orig_google_ddpm_model_denoiser.json
+// (attention_head_dim null: one 512-channel head, cond_unet_2d.py:176-197; utils_training.py:436).  Same decomposition as the
+// forward: the head dimension is split over the 4 waves of a workgroup, partial 32 x 32 score tiles are summed through LDS in a
+// fixed order, P is recomputed from the forward's log-sum-exp.  Two passes so that every reduction stays lane-local (no atomics):
+//   DQ pass   (lane = query, loop over key tiles):   S^T = K.Q^T, dP^T = V.dO^T, dS = P (dP - delta), dQ^T += K^T . dS^T;
+//             also emits delta[query] = sum_d O dO for the second pass
+//   DKV pass  (lane = key, loop over query tiles):   S = Q.K^T, dP = dO.V^T (rows = queries in registers),
+//             dV^T += dO^T . P,  dK^T += Q^T . dS
+// Sequence lengths here are small (N <= 1024: the attention sits at 1/16 .. 1/32 resolution), so the kernel is built for
+// correctness and reasonable MFMA use, not tuned: 2 % of a training step of that configuration.
+template <typename T, int D, bool DKV>
+__global__ __launch_bounds__(256) void attn_wide_bwd_kernel(const pd_attn_wide_bwd_args a) {
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  using Cfg = WideCfg<T, D>;
+  using X = WideX<T, Cfg::PITCH>;
+  constexpr int ES = Cfg::ES, PITCH = Cfg::PITCH, TILE = Cfg::TILE;
+  constexpr int SL = D / 4, KS = SL / 16, RT = SL / 32;
+  constexpr int PIECES = 32 * D / 8 / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* t0 = lds;                 // DQ: K tile      DKV: Q tile
+  unsigned char* t1 = lds + TILE;          // DQ: V tile      DKV: dO tile
+  float* xch = (float*)(lds + 2 * TILE);   // [wave][register][lane] partial tiles; DKV: the tile's lse / delta rows behind it
+  float* rows = xch + 4 * 16 * 64;         // [2][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int Nl = DKV ? a.Nkv : a.Nq;       // sequence the lanes index
+  const int No = DKV ? a.Nq : a.Nkv;       // sequence the loop walks
+  const int nlb = (Nl + 31) / 32;
+  const int lb = blockIdx.x % nlb, head = (blockIdx.x / nlb) % a.heads, b = blockIdx.x / (nlb * a.heads);
+  const size_t qo = (size_t)b * a.Nq, ko = (size_t)b * a.Nkv;
+  const T* qp = (const T*)a.q + qo * a.q_stride + head * D;
+  const T* kp = (const T*)a.k + ko * a.kv_stride + head * D;
+  const T* vp = (const T*)a.v + ko * a.kv_stride + head * D;
+  const T* op = (const T*)a.o + qo * a.o_stride + head * D;
+  const T* dop = (const T*)a.dout + qo * a.o_stride + head * D;
+  const size_t bh = ((size_t)b * a.heads + head) * a.Nq;
+  const float qscale = a.scale * 1.4426950408889634f;
+
+  // this lane's row of the "lane" sequence: fragments of its d-slice in registers (B operands)
+  const int row = lb * 32 + r, rc = min(row, Nl - 1);
+  Frag fa[KS], fb[KS];                     // DQ: Q * scale * log2e, dO          DKV: K * scale * log2e, V
+  float dpart = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int dcol = wave * SL + 16 * ks + 8 * h;
+    float v[8];
+    E::unpack(E::load((DKV ? kp + (size_t)rc * a.kv_stride : qp + (size_t)rc * a.q_stride) + dcol), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= qscale;
+    fa[ks] = E::pack(v);
+    fb[ks] = E::load((DKV ? vp + (size_t)rc * a.kv_stride : dop + (size_t)rc * a.o_stride) + dcol);
+    if (!DKV) {                            // delta = sum_d O dO over this lane's share of the head dimension
+      float ov[8], dv[8];
+      E::unpack(E::load(op + (size_t)rc * a.o_stride + dcol), ov);
+      E::unpack(fb[ks], dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dpart += ov[j] * dv[j];
+    }
+  }
+  float lse_l = 0.f, delta_l = 0.f;
+  if (!DKV) {
+    dpart += __shfl_xor(dpart, 32);
+    if (h == 0) xch[wave * 64 + r] = dpart;
+    __syncthreads();
+    delta_l = ((xch[0 * 64 + r] + xch[1 * 64 + r]) + xch[2 * 64 + r]) + xch[3 * 64 + r];
+    lse_l = a.lse[bh + rc];
+    if (wave == 0 && h == 0 && row < a.Nq) a.delta[bh + row] = delta_l;
+  }
+  f32x16 acc0[RT], acc1[RT];               // DQ: dQ^T (acc0)        DKV: dK^T (acc0), dV^T (acc1)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) { acc0[rt] = (f32x16)(0.f); acc1[rt] = (f32x16)(0.f); }
+
+  const int a_lane = r * PITCH + (wave * SL + 8 * h) * ES;          // row-major A fragments of a staged tile
+  const int t_lane = X::vt_lane_off(lane) + wave * SL * ES;         // transposed A fragments of a staged tile
+
+  for (int o0 = 0; o0 < No; o0 += 32) {
+    __syncthreads();                       // previous tile fully consumed (and the delta exchange above)
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + 256 * i, trow = pc / (D / 8), sub = pc % (D / 8), orow = o0 + trow;
+      Frag f0 = E::zero(), f1 = E::zero();
+      if (orow < No) {
+        f0 = E::load((DKV ? qp + (size_t)orow * a.q_stride : kp + (size_t)orow * a.kv_stride) + sub * 8);
+        f1 = E::load((DKV ? dop + (size_t)orow * a.o_stride : vp + (size_t)orow * a.kv_stride) + sub * 8);
+      }
+      E::store(t0 + trow * PITCH + sub * 8 * ES, f0);
+      E::store(t1 + trow * PITCH + sub * 8 * ES, f1);
+    }
+    if (DKV && tid < 64) {                 // the tile's per-query rows: lse | delta
+      const int orow = o0 + (tid & 31);
+      rows[tid] = orow < No ? (tid < 32 ? a.lse[bh + orow] : a.delta[bh + orow]) : 0.f;
+    }
+    __syncthreads();
+    // partial tiles over this wave's d-slice: register i <-> loop row (i&3) + 8(i>>2) + 4h, lane r <-> lane row
+    f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s = E::mma(E::load(t0 + a_lane + ks * 16 * ES), fa[ks], s);
+      dp = E::mma(E::load(t1 + a_lane + ks * 16 * ES), fb[ks], dp);
+    }
+    // DKV: the scores need Q.K^T with K scaled -- fa holds K * scale * log2e, t0 the raw Q tile: the same product
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xch[(wave * 16 + i) * 64 + lane] = s[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      s[i] = ((xch[(0 * 16 + i) * 64 + lane] + xch[(1 * 16 + i) * 64 + lane]) + xch[(2 * 16 + i) * 64 + lane]) + xch[(3 * 16 + i) * 64 + lane];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xch[(wave * 16 + i) * 64 + lane] = dp[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      dp[i] = ((xch[(0 * 16 + i) * 64 + lane] + xch[(1 * 16 + i) * 64 + lane]) + xch[(2 * 16 + i) * 64 + lane]) + xch[(3 * 16 + i) * 64 + lane];
+    // P = 2^(S - lse), dS = P (dP - delta); rows of the loop sequence beyond its end contribute nothing
+    f32x16 pm, ds;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int lr = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const float lse_i = DKV ? rows[lr] : lse_l, del_i = DKV ? rows[32 + lr] : delta_l;
+      float pv = __builtin_amdgcn_exp2f(s[i] - lse_i);
+      if (o0 + lr >= No) pv = 0.f;
+      pm[i] = pv;
+      ds[i] = pv * (dp[i] - del_i);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const Frag dsf = X::pack_p(ds, st);
+      const unsigned char* ts0 = t0 + t_lane + 16 * st * PITCH;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc0[rt] = E::mma(X::load_vt(ts0 + 32 * rt * ES), dsf, acc0[rt]);      // DQ: K^T.dS^T   DKV: Q^T.dS
+      if (DKV) {
+        const Frag pf = X::pack_p(pm, st);
+        const unsigned char* ts1 = t1 + t_lane + 16 * st * PITCH;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc1[rt] = E::mma(X::load_vt(ts1 + 32 * rt * ES), pf, acc1[rt]);   // dO^T.P
+      }
+    }
+  }
+  if (row < Nl) {
+    // dS carries no softmax scale yet: d(scale q.k) -> dQ, dK take it here
+    T* d0 = (DKV ? (T*)a.dk + (ko + row) * a.dkv_stride : (T*)a.dq + (qo + row) * a.dq_stride) + head * D + wave * SL + 4 * h;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        store4(d0 + 32 * rt + 8 * g, acc0[rt][4 * g] * a.scale, acc0[rt][4 * g + 1] * a.scale, acc0[rt][4 * g + 2] * a.scale, acc0[rt][4 * g + 3] * a.scale);
+    if (DKV) {
+      T* d1 = (T*)a.dv + (ko + row) * a.dkv_stride + head * D + wave * SL + 4 * h;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          store4(d1 + 32 * rt + 8 * g, acc1[rt][4 * g], acc1[rt][4 * g + 1], acc1[rt][4 * g + 2], acc1[rt][4 * g + 3]);
+    }
+  }
+}
+
+template <typename T, int D>
+static int launch_attn_wide_bwd(const pd_attn_wide_bwd_args* a, hipStream_t st) {
+  constexpr int LDS = WideCfg<T, D>::LDS + 64 * 4;
+  auto kq = attn_wide_bwd_kernel<T, D, false>;
+  auto kkv = attn_wide_bwd_kernel<T, D, true>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("pd_attn_wide_bwd: cannot reserve %d bytes of LDS", LDS);
+      return PD_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kq, dim3(((a->Nq + 31) / 32) * a->heads * a->B), dim3(256), LDS, st, *a);
+  PD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kkv, dim3(((a->Nkv + 31) / 32) * a->heads * a->B), dim3(256), LDS, st, *a);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+
+template <typename T>
+static int dispatch_attn_wide_bwd(const pd_attn_wide_bwd_args* a, hipStream_t st) {
+  switch (a->D) {
+    case 128: return launch_attn_wide_bwd<T, 128>(a, st);
+    case 256: return launch_attn_wide_bwd<T, 256>(a, st);
+    case 512: return launch_attn_wide_bwd<T, 512>(a, st);
+  }
+  set_error("pd_attn_wide_bwd: head dimension %d not built (128, 256, 512)", a->D);
   return PD_ERR_UNSUPPORTED;
 }
 
@@ -282,5 +478,22 @@ extern "C" int pd_attn_wide(const pd_attn_wide_args* a, void* stream) {
   if (a->dtype == PD_BF16) return dispatch_attn_wide<bf16_t>(a, (hipStream_t)stream);
   if (a->dtype == PD_F16) return dispatch_attn_wide<half_t>(a, (hipStream_t)stream);
   set_error("pd_attn_wide: bad dtype");
+  return PD_ERR_ARG;
+}
+
+extern "C" int pd_attn_wide_bwd(const pd_attn_wide_bwd_args* a, void* stream) {
+  PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_attn_wide_bwd: null args");
+  PD_CHECK(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nkv > 0, PD_ERR_SHAPE, "pd_attn_wide_bwd: bad shape");
+  PD_CHECK(a->q && a->k && a->v && a->o && a->dout && a->lse && a->delta && a->dq && a->dk && a->dv, PD_ERR_ARG, "pd_attn_wide_bwd: null pointer");
+  const int hd = a->heads * a->D;
+  PD_CHECK(a->D > 0 && a->q_stride >= hd && a->kv_stride >= hd && a->o_stride >= hd && a->dq_stride >= hd && a->dkv_stride >= hd &&
+               a->q_stride % 8 == 0 && a->kv_stride % 8 == 0 && a->o_stride % 8 == 0 && a->dq_stride % 8 == 0 && a->dkv_stride % 8 == 0,
+           PD_ERR_SHAPE, "pd_attn_wide_bwd: strides must cover heads*D channels and be multiples of 8");
+  PD_CHECK((long long)((a->Nq + 31) / 32) * a->heads * a->B < (1ll << 31) && (long long)((a->Nkv + 31) / 32) * a->heads * a->B < (1ll << 31),
+           PD_ERR_SHAPE, "pd_attn_wide_bwd: grid too large");
+  if (a->dtype == PD_F32) return dispatch_attn_wide_bwd<float>(a, (hipStream_t)stream);
+  if (a->dtype == PD_BF16) return dispatch_attn_wide_bwd<bf16_t>(a, (hipStream_t)stream);
+  PD_CHECK(a->dtype != PD_F16, PD_ERR_UNSUPPORTED, "pd_attn_wide_bwd: fp16 is an inference mode");
+  set_error("pd_attn_wide_bwd: bad dtype");
   return PD_ERR_ARG;
 }

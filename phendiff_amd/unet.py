@@ -650,8 +650,6 @@ class UNetPlan:
         B, h, w, ch = x.shape
         if ch != e.heads * 8:
             # attention_head_dim = None (one head over all channels: orig_google_ddpm_model_denoiser.json) or 64
-            if self.train:
-                raise NotImplementedError(f"the backward plan implements head_dim 8 only (got {ch // e.heads})")
             return self._attn_nhwc(name, x)
         gn = self._gn(x, None, e.g, e.be, e.eps)
         if (h * w) % 128 == 0 and ch % 64 == 0:
@@ -698,18 +696,22 @@ class UNetPlan:
         qkv, _ = self._conv(x, None, e.wqkv, e.bqkv, 3 * ch, ksize=1, pad=0, gn=gn, stats=False)
         o = self._act(h, w, ch)
         p = qkv.data_ptr()
+        lse = self._f32(B, e.heads, N) if self.train else None        # kept for the backward (pd_attn_d64_bwd / pd_attn_wide_bwd)
         if d == 64:
             a = L.AttnD64Args(dtype=self.code, B=B, heads=e.heads, Nq=N, Nkv=N, q=p, q_stride=3 * ch, k=p + ch * esz,
-                              v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch)
+                              v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch, lse=L.ptr(lse))
             fn, what = self.lib.pd_attn_d64, "attn_d64"
         else:
             a = L.AttnWideArgs(dtype=self.code, B=B, heads=e.heads, D=d, Nq=N, Nkv=N, scale=float(d) ** -0.5, q=p, q_stride=3 * ch,
-                               k=p + ch * esz, v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch)
+                               k=p + ch * esz, v=p + 2 * ch * esz, kv_stride=3 * ch, out=o.data_ptr(), out_stride=ch, lse=L.ptr(lse))
             fn, what = self.lib.pd_attn_wide, "attn_wide"
         self.ops.append(_Op(fn, a, what, 4.0 * B * N * N * ch, 4.0 * B * N * ch * esz))
         if self._linear_ok(o):
-            return self._linear(o, e.wo, e.bo, ch, residual=x, stats=True, what="conv1x1")
-        out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
+            out = self._linear(o, e.wo, e.bo, ch, residual=x, stats=True, what="conv1x1")
+        else:
+            out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
+        if self.train:
+            self.tape.append(SimpleNamespace(kind="attn_nhwc", name=name, x=x, qkv=qkv, o=o, out=out, lse=lse, gn=gn, e=e, d=d))
         return out
 
     def _build(self):

@@ -280,8 +280,9 @@ class UNetTrainPlan(UNetPlan):
             if ksize == 1 and not zero_stuff and cin % 32 == 0 and cout % 8 == 0 and not _NO_LINEAR_GRADS:
                 self._linear(dy, wpk, self._zero_bias, cout, residual=res, y=y, what="dgrad_linear")
             else:
-                self._conv(dy, None, wpk, self._zero_bias, cout, ksize=ksize, pad=ksize // 2, upsample=2 if zero_stuff else 0,
-                           residual=res, y=y, stats=False)
+                # zero_stuff: True / 2 = samples at the even positions (stride-2 pad-1 forward), 3 = at the odd ones (pad-0 forward)
+                self._conv(dy, None, wpk, self._zero_bias, cout, ksize=ksize, pad=ksize // 2,
+                           upsample=(2 if zero_stuff is True else int(zero_stuff)) if zero_stuff else 0, residual=res, y=y, stats=False)
                 self.bwd_ops[-1].what = f"dgrad{ksize}x{ksize}"
         finally:
             self.ops = ops
@@ -370,13 +371,18 @@ class UNetTrainPlan(UNetPlan):
             self._resnet_bwd(rec)
         elif k == "attn":
             self._attn_bwd(rec)
+        elif k == "attn_nhwc":
+            self._attn_nhwc_bwd(rec)
         elif k == "down":
-            if rec.e.padding != 1:
-                raise NotImplementedError("training: Downsample2D with padding != 1")
+            # Downsample2D(padding=0) pads (0, 1, 0, 1) and convolves without padding (orig_google_ddpm_model_denoiser.json):
+            # y[o] = sum_k w[k] x[2 o + k], so its input gradient is the pad-1 convolution over dY zero-stuffed at the ODD positions
+            pad = rec.e.padding
+            if pad not in (0, 1):
+                raise NotImplementedError(f"training: Downsample2D with padding {pad}")
             dout = self._g(rec.out)[0]
             self._bias_grad(dout, G(rec.name + ".conv.bias"))
-            self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), stride=2, pad=1)
-            self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], zero_stuff=True, into=self._g(rec.x))
+            self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), stride=2, pad=pad)
+            self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], zero_stuff=(2 if pad == 1 else 3), into=self._g(rec.x))
         elif k == "up":
             dout = self._g(rec.out)[0]
             self._bias_grad(dout, G(rec.name + ".conv.bias"))
@@ -457,6 +463,34 @@ class UNetTrainPlan(UNetPlan):
                           delta=delta.data_ptr(), dqkv=dqkv.data_ptr())
         self._b(self.lib.pd_attn_d8_bwd, a, "attn_d8_bwd", 10.0 * B * e.heads * N * N * 8, 8.0 * B * N * ch * self._esz())
         self._bias_grad(dqkv, G(n + ".to_q.bias", (n + ".to_k.bias", n + ".to_v.bias")))                       # [dq | dk | dv] biases are adjacent
+        self._wgrad(rec.x, None, rec.gn, 0, dqkv, G(n + ".to_q.weight", (n + ".to_k.weight", n + ".to_v.weight")), ksize=1, pad=0)
+        dz = self._dgrad(dqkv, te.wqkvd, ch, ksize=1, tag="dzattn")
+        self._gn_bwd(rec.gn, dz, 0, res=dout, wname=n + ".group_norm")
+
+    def _attn_nhwc_bwd(self, rec):
+        """Backward of ``UNetPlan._attn_nhwc`` (head_dim 64, or one wide head of 128 / 256 / 512 channels: ``attention_head_dim``
+        null of orig_google_ddpm_model_denoiser.json): q | k | v live NHWC in one [B][N][3C] tensor, so the attention gradient
+        is written straight into the fused projection's output gradient [dq | dk | dv]."""
+        e, te, n = rec.e, self.tw.attns[rec.name], rec.name
+        G = self._G
+        B, h, w, ch = rec.x.shape
+        N, esz, d = h * w, self._esz(), rec.d
+        dout = self._g(rec.out)[0]
+        self._bias_grad(dout, G(n + ".to_out.0.bias"))
+        self._wgrad(rec.o, None, None, 0, dout, G(n + ".to_out.0.weight"), ksize=1, pad=0)
+        do = self._dgrad(dout, te.wod, ch, ksize=1, tag="do")
+        dqkv = self._tmp((B, h, w, 3 * ch), "dqkv")
+        delta = self._tmp((B, e.heads, N), "delta", torch.float32)
+        p, dp = rec.qkv.data_ptr(), dqkv.data_ptr()
+        common = dict(dtype=self.code, B=B, heads=e.heads, Nq=N, Nkv=N, q=p, q_stride=3 * ch, k=p + ch * esz, v=p + 2 * ch * esz,
+                      kv_stride=3 * ch, o=rec.o.data_ptr(), dout=do.data_ptr(), o_stride=ch, lse=rec.lse.data_ptr(),
+                      delta=delta.data_ptr(), dq=dp, dq_stride=3 * ch, dk=dp + ch * esz, dv=dp + 2 * ch * esz, dkv_stride=3 * ch)
+        if d == 64:
+            self._b(self.lib.pd_attn_d64_bwd, L.AttnD64BwdArgs(**common), "attn_d64_bwd", 10.0 * B * N * N * ch, 8.0 * B * N * ch * esz)
+        else:
+            self._b(self.lib.pd_attn_wide_bwd, L.AttnWideBwdArgs(D=d, scale=float(d) ** -0.5, **common), "attn_wide_bwd",
+                    10.0 * B * N * N * ch, 8.0 * B * N * ch * esz)
+        self._bias_grad(dqkv, G(n + ".to_q.bias", (n + ".to_k.bias", n + ".to_v.bias")))
         self._wgrad(rec.x, None, rec.gn, 0, dqkv, G(n + ".to_q.weight", (n + ".to_k.weight", n + ".to_v.weight")), ksize=1, pad=0)
         dz = self._dgrad(dqkv, te.wqkvd, ch, ksize=1, tag="dzattn")
         self._gn_bwd(rec.gn, dz, 0, res=dout, wname=n + ".group_norm")

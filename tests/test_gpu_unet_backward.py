@@ -65,6 +65,38 @@ def test_unet_backward_matches_autograd(mode, per_tol, glob_tol, size):
     compare({n: 2 * g for n, g in ref.items()}, tr.grads, per_tol, glob_tol)
 
 
+@pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 2e-4, 2e-5), ("bf16", 8e-2, 2e-2)])
+def test_orig_google_ddpm_backward_matches_autograd(mode, per_tol, glob_tol):
+    """models_configs/denoiser/orig_google_ddpm_model_denoiser.json trains too (VERDICT r2 missing 3: the reference trains whatever
+    config it loads, utils_models.py:158-182, train.py:180-182): gradients of all its parameters at 64x64 against torch.autograd --
+    one 512-channel attention head (pd_attn_wide_bwd), Downsample2D(padding=0) (odd-phase zero-stuffed input gradient), six
+    levels down to 2x2, no class table."""
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef, UNET_CONFIGS as REF_CONFIGS
+    from phendiff_amd.unet_train import UNetTrainer
+    torch.manual_seed(0)
+    r = CondUNet2DRef(**dict(REF_CONFIGS["orig_google_ddpm"], sample_size=64)).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype=mode, **dict(P.UNET_CONFIGS["orig_google_ddpm_model_denoiser"], sample_size=64))
+    m.load_state_dict(r.state_dict())
+    m = m.to("cuda:0")
+    sched, clean, noise, ts, labels, noisy, target = batch(2, 64)
+    loss_ref, ref = oracle_grads(r, noisy, ts, target)
+    tr = UNetTrainer(m, sched, lr=1e-4, use_ema=False)
+    loss, _ = tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda())
+    torch.cuda.synchronize()
+    assert len(ref) == len(tr.grads) and abs(float(loss) - float(loss_ref)) < (1e-5 if mode == "f32" else 5e-3) * float(loss_ref)
+    compare(ref, tr.grads, per_tol, glob_tol)
+    if mode == "f32":       # and it optimises: three AdamW steps track torch's on the oracle
+        opt = torch.optim.AdamW(r.parameters(), lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+        tr.opt.grad.zero_()
+        for _ in range(3):
+            l_ref, _ = oracle_grads(r, noisy, ts, target)
+            torch.nn.utils.clip_grad_norm_(r.parameters(), 1.0)
+            opt.step()
+            l = tr.step(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda())
+            assert abs(float(l) - float(l_ref)) < 2e-4 * abs(float(l_ref))
+
+
 def test_unet_backward_unconditional_step_f32():
     """class_emb = zeros (the reference's unconditional training step, utils_training.py:398-407): the class table gets
     no gradient, everything else does."""

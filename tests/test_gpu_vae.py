@@ -34,6 +34,51 @@ def test_attention_wide(env, mode, cfg):
     assert rel(out.float(), ref) < (2e-5 if mode == "f32" else 1.5e-2)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 1, 512, 16), (1, 1, 512, 256), (2, 2, 128, 77), (1, 3, 256, 130), (1, 1, 512, 4)])
+def test_attention_wide_backward(env, mode, cfg):
+    """pd_attn_wide_bwd (dQ pass + dK / dV pass, P recomputed from the forward's log-sum-exp) against torch.autograd of
+    F.scaled_dot_product_attention on the same (storage-rounded) q, k, v and upstream gradient: the attention of
+    orig_google_ddpm_model_denoiser.json under accelerator.backward (utils_training.py:436), sequence lengths incl. partial tiles."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, heads, D, N = cfg
+    Cc = heads * D
+    g = torch.Generator().manual_seed(45)
+    qkv = bf16_round(torch.randn(B, N, 3 * Cc, generator=g), mode)
+    dout = bf16_round(torch.randn(B, N, Cc, generator=g), mode)
+    sp = lambda t: t.reshape(B, N, heads, D).transpose(1, 2)
+    leaf = qkv.clone().requires_grad_(True)
+    ref = F.scaled_dot_product_attention(sp(leaf[..., :Cc]), sp(leaf[..., Cc:2 * Cc]), sp(leaf[..., 2 * Cc:])).transpose(1, 2).reshape(B, N, Cc)
+    ref.backward(dout)
+    QKV, DO = qkv.to(tdt).to(dev).contiguous(), dout.to(tdt).to(dev).contiguous()
+    esz = QKV.element_size()
+    out = torch.empty((B, N, Cc), dtype=tdt, device=dev)
+    lse = torch.empty((B, heads, N), device=dev)
+    p = QKV.data_ptr()
+    a = L.AttnWideArgs(dtype=code, B=B, heads=heads, D=D, Nq=N, Nkv=N, scale=D ** -0.5, q=p, q_stride=3 * Cc, k=p + Cc * esz,
+                       v=p + 2 * Cc * esz, kv_stride=3 * Cc, out=out.data_ptr(), out_stride=Cc, lse=lse.data_ptr())
+    L.check(lib.pd_attn_wide(C.byref(a), stream()), "pd_attn_wide")
+    dqkv = torch.full((B, N, 3 * Cc), float("nan"), dtype=tdt, device=dev)
+    delta = torch.empty((B, heads, N), device=dev)
+    dp = dqkv.data_ptr()
+    b = L.AttnWideBwdArgs(dtype=code, B=B, heads=heads, D=D, Nq=N, Nkv=N, scale=D ** -0.5, q=p, q_stride=3 * Cc, k=p + Cc * esz,
+                          v=p + 2 * Cc * esz, kv_stride=3 * Cc, o=out.data_ptr(), dout=DO.data_ptr(), o_stride=Cc, lse=lse.data_ptr(),
+                          delta=delta.data_ptr(), dq=dp, dq_stride=3 * Cc, dk=dp + Cc * esz, dv=dp + 2 * Cc * esz, dkv_stride=3 * Cc)
+    L.check(lib.pd_attn_wide_bwd(C.byref(b), stream()), "pd_attn_wide_bwd")
+    torch.cuda.synchronize()
+    # the log-sum-exp the forward kept (log2 domain) and delta = rowsum(O dO)
+    s = (sp(qkv[..., :Cc]) @ sp(qkv[..., Cc:2 * Cc]).transpose(-1, -2)) * D ** -0.5
+    assert float((lse.cpu() - torch.logsumexp(s, -1) * 1.4426950408889634).abs().max()) < (1e-4 if mode == "f32" else 3e-2)
+    tol = 3e-5 if mode == "f32" else 2e-2
+    got = dqkv.float().cpu()
+    for i, name in enumerate("qkv"):
+        assert rel(got[..., i * Cc:(i + 1) * Cc], leaf.grad[..., i * Cc:(i + 1) * Cc]) < tol, (name, mode, cfg)
+    assert lib.pd_attn_wide_bwd(C.byref(L.AttnWideBwdArgs(dtype=L.PD_F16, B=B, heads=heads, D=D, Nq=N, Nkv=N, q=p, k=p, v=p, o=p, dout=p,
+                                                           lse=p, delta=p, dq=p, dk=p, dv=p, q_stride=3 * Cc, kv_stride=3 * Cc, o_stride=Cc,
+                                                           dq_stride=3 * Cc, dkv_stride=3 * Cc)), stream()) == -4     # fp16: inference only
+
+
 def test_attention_wide_rejects_unbuilt_dim(env):
     L, lib, _, dev = env
     t = torch.zeros(1, 32, 3 * 96, device=dev)

@@ -40,7 +40,7 @@ def test_struct_field_order_matches_header():
     pairs = {"pd_temb_args": L.TembArgs, "pd_conv_in_args": L.ConvInArgs, "pd_gn_stats_args": L.GnStatsArgs,
              "pd_conv_args": L.ConvArgs, "pd_gn_finalize_args": L.GnFinalizeArgs, "pd_attn_args": L.AttnArgs,
              "pd_ddim_step_args": L.DdimStepArgs, "pd_add_noise_args": L.AddNoiseArgs, "pd_postproc_args": L.PostprocArgs,
-             "pd_attn_d64_args": L.AttnD64Args, "pd_attn_wide_args": L.AttnWideArgs, "pd_latent_sample_args": L.LatentSampleArgs,
+             "pd_attn_d64_args": L.AttnD64Args, "pd_attn_wide_args": L.AttnWideArgs, "pd_attn_wide_bwd_args": L.AttnWideBwdArgs, "pd_latent_sample_args": L.LatentSampleArgs,
              "pd_attn_d64_bwd_args": L.AttnD64BwdArgs, "pd_layernorm_bwd_args": L.LayerNormBwdArgs,
              "pd_geglu_bwd_args": L.GegluBwdArgs, "pd_linear_args": L.LinearArgs, "pd_gn_apply_args": L.GnApplyArgs, "pd_token_wgrad_args": L.TokenWgradArgs, "pd_layernorm_args": L.LayerNormArgs, "pd_geglu_args": L.GegluArgs,
              "pd_pack_weight_args": L.PackWeightArgs, "pd_pack_weight_batch_args": L.PackWeightBatchArgs, "pd_zero_args": L.ZeroArgs}
@@ -70,6 +70,7 @@ def test_argument_validation_without_gpu():
     assert lib.pd_conv_stat_tiles(256, 256, 3, 1) == 256 and lib.pd_conv_stat_tiles(64, 64, 3, 2) == 32
     assert lib.pd_attn_wide(C.byref(L.AttnWideArgs(dtype=1, B=1, heads=1, D=512, Nq=0, Nkv=4)), None) == -2
     assert lib.pd_attn_d64_bwd(C.byref(L.AttnD64BwdArgs(dtype=1, B=1, heads=1, Nq=4, Nkv=4)), None) == -1
+    assert lib.pd_attn_wide_bwd(C.byref(L.AttnWideBwdArgs(dtype=1, B=1, heads=1, D=512, Nq=4, Nkv=4)), None) == -1
     assert lib.pd_layernorm_bwd(C.byref(L.LayerNormBwdArgs(dtype=1, rows=4, C=12)), None) == -1
     assert lib.pd_layernorm_bwd_blocks(10) == 3 and lib.pd_layernorm_bwd_blocks(1 << 20) == 2048
     with pytest.raises(L.PhenDiffHipError):
