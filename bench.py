@@ -744,13 +744,13 @@ def main():
         else:
             ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         # HBM bytes / pipe occupancy per launch of that kernel come from committed rocprofv3 --pmc passes (counters cannot be read
-        # from inside the process): profiles/r2_hbm_traffic.json, r2_mfma_busy.json, written by scripts/collect_profiles.sh keyed
+        # from inside the process): profiles/r3_hbm_traffic.json, r3_mfma_busy.json, written by scripts/collect_profiles.sh keyed
         # by plan kind.  They are only quoted for the workload they were measured on AND while the library sources are the ones
         # they were measured with (sources_sha256); otherwise traffic stays null and the line says why.
         traffic, traffic_src, pipes, pmc_note = None, None, {}, None
         from phendiff_amd._lib import source_hash
         same_workload = B == 32 and args.dtype == "bf16" and size == 256 and args.model == "super_small"
-        for fname, field in (("r2_hbm_traffic.json", "traffic"), ("r2_mfma_busy.json", "pipes")):
+        for fname, field in (("r3_hbm_traffic.json", "traffic"), ("r3_mfma_busy.json", "pipes")):
             try:
                 j = json.load(open(os.path.join(ROOT, "profiles", fname)))
             except (OSError, ValueError):
@@ -778,6 +778,17 @@ def main():
             extra = {"issue_bound": {"what": "v_exp_f32 issue (64 lanes / 8 cycles / SIMD, 1024 SIMDs, 2.4 GHz)",
                                      "achieved_Texp_per_s": round(nexp / (d["ms"] * 1e-3) / 1e12, 2), "peak_Texp_per_s": 19.66,
                                      "frac": round(nexp / (d["ms"] * 1e-3) / 19.66e12, 4)}}
+            # the clock the chip actually holds under this kernel (profiles/r3_clock.json: GRBM_GUI_ACTIVE / 8 / kernel time over
+            # 650 launches, and rocm-smi sclk samples, scripts/measure_clock.sh) and the issue cost scripts/micro/exp_variants.hip
+            # measures for v_exp_f32 at full occupancy (8.7 cycles, not the nominal 8)
+            try:
+                clk = json.load(open(os.path.join(ROOT, "profiles", "r3_clock.json")))["N4096"]["ghz_median"]
+                peak_meas = 64.0 / 8.7 * 1024 * clk * 1e9
+                extra["issue_bound"].update({"measured_clock_ghz": clk, "frac_at_measured_clock": round(nexp / (d["ms"] * 1e-3) / (19.66e12 * clk / 2.4), 4),
+                                             "frac_at_measured_clock_and_issue_cost": round(nexp / (d["ms"] * 1e-3) / peak_meas, 4),
+                                             "clock_source": "profiles/r3_clock.json"})
+            except (OSError, ValueError, KeyError):
+                pass
         res["roofline"] = {**extra, **pipes, "kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),

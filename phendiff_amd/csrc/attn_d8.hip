@@ -939,9 +939,11 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)attn_kernel<bf16_t, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+      (void)hipFuncSetAttribute((const void*)attn_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
       attr_set = true;
     }
-    hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), lds_pad, st, *a);
+    if (a->kmax2) hipLaunchKernelGGL((attn_glds_kernel<bf16_t>), grid, dim3(512), lds_pad, st, *a);     // the shipped kernel, occupancy-capped
+    else hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), lds_pad, st, *a);
     PD_LAUNCH_CHECK();
     return PD_OK;
   }

@@ -23,6 +23,11 @@
 #ifndef PD_S2_SINGLE
 #define PD_S2_SINGLE 1
 #endif
+// Diagnostic (scripts/experiments/overlap_pair.py, -DPD_CONV_PRIO_BASE=2): wave priority of the conv kernel outside / inside its MFMA
+// clusters -- the controlled attention || convolution co-residency experiment of round 3.  The shipped build keeps 0 / 1.
+#ifndef PD_CONV_PRIO_BASE
+#define PD_CONV_PRIO_BASE 0
+#endif
 namespace pd {
 
 
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   static_assert(RPF >= 1 && TW * RPF == 32, "TW must divide 32");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  if (PD_CONV_PRIO_BASE) __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE);
 
   // ---- block -> (pixel tile, co tile, sample) = (x, y, z): the co tiles of one pixel tile are tiles-per-image blocks
   // apart in dispatch order, i.e. on the same XCD / L2 whenever tiles-per-image % 8 == 0 (speed only)
@@ -272,12 +278,12 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 #pragma unroll
           for (int f = 0; f < NF; ++f) bc[f] = E::load(buf + rbase[f] + toff);
         }
-        __builtin_amdgcn_s_setprio(1);   // keeps the 4-MFMA cluster together and ahead of the other wave's VALU work (+5 %)
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);   // keeps the 4-MFMA cluster together and ahead of the other wave's VALU work (+5 %)
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
 #pragma unroll
           for (int f = 0; f < NF; ++f) acc[c][f] = E::mma(aring[ks % AR][c], bc[f], acc[c][f]);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE);
       }
       if constexpr (DB && HAVE_NEXT) {
         // spread the NIT pieces of the next chunk evenly over the k-steps
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
       Frag b0[NF], b1[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) { b0[f] = E::load(buf + rbase[f] + CENTER); b1[f] = E::load(buf + rbase[f] + CENTER + 16 * E::BYTES); }
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);
 #pragma unroll
       for (int c = 0; c < NCO; ++c) {
 #pragma unroll
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[c][f] = E::mma(a1[c], b1[f], acc[c][f]);
       }
-      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE);
     }
     if constexpr (HAVE_NEXT) {
 #pragma unroll

@@ -5,46 +5,47 @@
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+R=${R:-r3}          # round tag of the files written (profiles/${R}_*)
 OUT=gpurun_out/profiles_new
 mkdir -p $OUT
 stats() {   # <tag> <log name> -- bench args
   local tag=$1 log=$2; shift 2
   local d=/tmp/prof_$tag
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py "$@" > $OUT/$log 2>$OUT/$log.err
-  cp "$(ls $d/*/*_kernel_stats.csv | head -1)" $OUT/r2_${tag}_kernel_stats.csv
+  cp "$(ls $d/*/*_kernel_stats.csv | head -1)" $OUT/${R}_${tag}_kernel_stats.csv
   echo "== $tag: $(tail -c 300 $OUT/$log | head -c 300)"
 }
 case "$1" in
 head)
-  stats b32 r2_bench_under_rocprof_b32.log --steps 1 --warmup 1 --batch 32 --no-cpu-baseline --no-roofline --no-sweep
+  stats b32 ${R}_bench_under_rocprof_b32.log --steps 1 --warmup 1 --batch 32 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep > /dev/null 2>$OUT/pmc_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads > /dev/null 2>$OUT/pmc_$c.err
   done
-  python3 scripts/collect_traffic.py r2 "$(ls /tmp/pmc_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls /tmp/pmc_WRITE_SIZE/*/*_counter_collection.csv | head -1)" > $OUT/traffic.txt
-  cp profiles/r2_hbm_traffic.json $OUT/
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_busy -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep > /dev/null 2>$OUT/pmc_busy.err
-  python3 scripts/collect_mfma_busy.py r2 "$(ls /tmp/pmc_busy/*/*_counter_collection.csv | head -1)" > $OUT/mfma_busy.txt
-  cp profiles/r2_mfma_busy.json $OUT/
+  python3 scripts/collect_traffic.py $R "$(ls /tmp/pmc_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls /tmp/pmc_WRITE_SIZE/*/*_counter_collection.csv | head -1)" > $OUT/traffic.txt
+  cp profiles/${R}_hbm_traffic.json $OUT/
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_busy -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads > /dev/null 2>$OUT/pmc_busy.err
+  python3 scripts/collect_mfma_busy.py $R "$(ls /tmp/pmc_busy/*/*_counter_collection.csv | head -1)" > $OUT/mfma_busy.txt
+  cp profiles/${R}_mfma_busy.json $OUT/
   # the default line last: it quotes the two PMC summaries just written (same kernel sources by construction)
-  python3 bench.py > $OUT/r2_bench_default.json 2>$OUT/bench_default.err
-  cut -c1-200 $OUT/r2_bench_default.json
-  python3 bench.py --model small_denoiser_config --batch 16 --steps 1 --warmup 1 --no-cpu-baseline --no-sweep > $OUT/r2_bench_small_denoiser_b16.json 2>/dev/null
+  python3 bench.py > $OUT/${R}_bench_default.json 2>$OUT/bench_default.err
+  cut -c1-200 $OUT/${R}_bench_default.json
+  python3 bench.py --model small_denoiser_config --batch 16 --steps 1 --warmup 1 --no-cpu-baseline --no-sweep --no-side-workloads > $OUT/${R}_bench_small_denoiser_b16.json 2>/dev/null
   ;;
 train)
-  python3 bench.py --workload train --steps 10 --warmup 2 > $OUT/r2_bench_train.json 2>/dev/null
-  cut -c1-200 $OUT/r2_bench_train.json
-  stats train_b112 r2_train_bench_under_rocprof_b112.log --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-sweep
-  mv $OUT/r2_train_b112_kernel_stats.csv $OUT/r2_train_kernel_stats_b112.csv
+  python3 bench.py --workload train --steps 10 --warmup 2 > $OUT/${R}_bench_train.json 2>/dev/null
+  cut -c1-200 $OUT/${R}_bench_train.json
+  stats train_b112 ${R}_train_bench_under_rocprof_b112.log --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
+  mv $OUT/${R}_train_b112_kernel_stats.csv $OUT/${R}_train_kernel_stats_b112.csv
   ;;
 sd)
-  python3 bench.py --workload sd_img2img --steps 2 > $OUT/r2_bench_sd_img2img.json 2>/dev/null
-  cut -c1-200 $OUT/r2_bench_sd_img2img.json
-  python3 bench.py --workload sd_train --steps 10 --warmup 2 > $OUT/r2_bench_sd_train.json 2>/dev/null
-  cut -c1-200 $OUT/r2_bench_sd_train.json
-  stats sd_img2img_b32 r2_sd_img2img_bench_under_rocprof_b32.log --workload sd_img2img --steps 1 --warmup 0 --no-roofline --no-cpu-baseline
-  mv $OUT/r2_sd_img2img_b32_kernel_stats.csv $OUT/r2_sd_img2img_kernel_stats_b32.csv
-  stats sd_train_b32 r2_sd_train_bench_under_rocprof_b32.log --workload sd_train --steps 5 --warmup 2 --no-roofline --no-cpu-baseline
-  mv $OUT/r2_sd_train_b32_kernel_stats.csv $OUT/r2_sd_train_kernel_stats_b32.csv
+  python3 bench.py --workload sd_img2img --steps 2 > $OUT/${R}_bench_sd_img2img.json 2>/dev/null
+  cut -c1-200 $OUT/${R}_bench_sd_img2img.json
+  python3 bench.py --workload sd_train --steps 10 --warmup 2 > $OUT/${R}_bench_sd_train.json 2>/dev/null
+  cut -c1-200 $OUT/${R}_bench_sd_train.json
+  stats sd_img2img_b32 ${R}_sd_img2img_bench_under_rocprof_b32.log --workload sd_img2img --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-side-workloads
+  mv $OUT/${R}_sd_img2img_b32_kernel_stats.csv $OUT/${R}_sd_img2img_kernel_stats_b32.csv
+  stats sd_train_b32 ${R}_sd_train_bench_under_rocprof_b32.log --workload sd_train --steps 5 --warmup 2 --no-roofline --no-cpu-baseline --no-side-workloads
+  mv $OUT/${R}_sd_train_b32_kernel_stats.csv $OUT/${R}_sd_train_kernel_stats_b32.csv
   ;;
 esac
 ls -la $OUT

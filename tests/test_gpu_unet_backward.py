@@ -97,6 +97,29 @@ def test_orig_google_ddpm_backward_matches_autograd(mode, per_tol, glob_tol):
             assert abs(float(l) - float(l_ref)) < 2e-4 * abs(float(l_ref))
 
 
+def test_sd21_denoiser_config_backward_matches_autograd_f32():
+    """models_configs/denoiser/SD_2-1_config.json (641.9 M parameters) trains as well: d = 8 attention with 40 / 80 / 160 heads on
+    three levels, GroupNorm groups of 10 / 20 / 40 channels, 2 560-channel concatenations -- gradients of all parameters at 32x32
+    from the exact-fp32 engine against torch.autograd over the CPU oracle."""
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef, UNET_CONFIGS as REF_CONFIGS
+    from phendiff_amd.unet_train import UNetTrainer
+    torch.manual_seed(0)
+    r = CondUNet2DRef(**dict(REF_CONFIGS["SD_2-1_config"], sample_size=32)).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype="f32", **dict(P.UNET_CONFIGS["SD_2-1_config"], sample_size=32))
+    m.load_state_dict(r.state_dict())
+    m = m.to("cuda:0")
+    sched, clean, noise, ts, labels, noisy, target = batch(2, 32)
+    loss_ref, ref = oracle_grads(r, noisy, ts, target, labels=labels)
+    tr = UNetTrainer(m, sched, lr=1e-4, use_ema=False)
+    loss, _ = tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * float(loss_ref)
+    compare(ref, tr.grads, 2e-4, 2e-5)
+    del tr, m
+    torch.cuda.empty_cache()
+
+
 def test_unet_backward_unconditional_step_f32():
     """class_emb = zeros (the reference's unconditional training step, utils_training.py:398-407): the class table gets
     no gradient, everything else does."""
