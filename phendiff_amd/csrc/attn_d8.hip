@@ -166,6 +166,15 @@ template <typename T> struct AttnOps {
   // feeds to a PV k-step (16s + 4h + {0..3}, 16s + 8 + 4h + {0..3}) are 16 contiguous bytes -> one ds_read_b128
   static __device__ __forceinline__ int vpos(int t) { return t ^ ((((t >> 2) ^ (t >> 3)) & 1) * 12); }
   static __device__ __forceinline__ int vlane_off(int h) { return h * 16; }
+  // Two probabilities -> one dword of the PV MFMA's B operand.  bf16 (round 3): the upper halves of the two fp32 words by ONE
+  // v_perm_b32 (full-rate, ~3 cycles at this occupancy) instead of v_cvt_pk_bf16_f32 (4.8 cycles measured,
+  // scripts/micro/exp_variants.hip): truncation instead of round-to-nearest.  The row sum l is accumulated by the same MFMA from
+  // the same truncated values (the ones row of A), so the -2^-9 mean bias divides out of O = (P V) / l; the random part has the
+  // variance of round-to-nearest (one ulp wide either way).  8 of these per 32 x 32 tile: ~14 of its ~217 cycles.
+  static __device__ __forceinline__ uint32_t pack_p(float lo, float hi) {
+    if constexpr (std::is_same<T, bf16_t>::value) return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+    else return Pack16<T>::pack(lo, hi);
+  }
   // O^T += A . P^T for one 32-key sub-tile; p = exponentiated tile (fp32 accumulator layout)
   static __device__ __forceinline__ f32x16 pv(const VF& a, const f32x16& p, f32x16 o) {
 #pragma unroll
@@ -173,7 +182,7 @@ template <typename T> struct AttnOps {
       // B fragment: element j <-> key 16s + 8(j>>2) + 4h + (j&3) == accumulator register 8s + j
       uint32_t bw[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bw[j] = Pack16<T>::pack(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
+      for (int j = 0; j < 4; ++j) bw[j] = pack_p(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
       u32x4 bv = {bw[0], bw[1], bw[2], bw[3]};
       o = Elem<T>::mma16(__builtin_bit_cast(s16x8, a.v[s]), __builtin_bit_cast(s16x8, bv), o);
     }

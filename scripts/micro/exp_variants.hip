@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     } else if (MODE == 8) {       // v_ldexp_f32 (scale by 2^n: the cheap half of a split exponential)
       REP16(asm volatile("v_ldexp_f32 %0, %0, %4\n v_ldexp_f32 %1, %1, %5\n v_ldexp_f32 %2, %2, %6\n v_ldexp_f32 %3, %3, %7"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5), "v"(a6), "v"(a7));)
+    } else if (MODE == 10) {      // v_perm_b32: the upper halves of two fp32 words = a truncating bf16 pack
+      REP16(asm volatile("v_perm_b32 %0, %4, %5, %8\n v_perm_b32 %1, %5, %6, %8\n v_perm_b32 %2, %6, %7, %8\n v_perm_b32 %3, %7, %4, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5), "v"(a6), "v"(a7), "s"(0x07060302u));)
     } else if (MODE == 9) {       // v_pk_fma_f32
       double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5;
       REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %5, %4\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %5, %4"
@@ -71,5 +74,6 @@ int main() {
   run<7>("v_exp_f32 + v_fma_f32 (1:1)");
   run<8>("v_ldexp_f32");
   run<9>("v_pk_fma_f32");
+  run<10>("v_perm_b32");
   return 0;
 }
