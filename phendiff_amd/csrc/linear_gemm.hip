@@ -547,6 +547,227 @@ static int launch_linear(const LinP& p, hipStream_t st) {
   return PD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// linear_dma_kernel (round 3): the plain nn.Linear GEMM with BOTH operands staged by DMA (global_load_lds) and the weight chunk
+// SHARED by the workgroup through LDS.  linear_kernel moves 0.75 KB through the vector L1 per MFMA (16 KB of activations + 2 x 16 KB
+// of per-wave weight fragments per 64 MFMAs) = ~96 B/clk/CU at matrix-pipe peak against the L1's 64: the diagnosis of round 2.
+// Here a workgroup is 8 waves = 256 tokens x (64 NC) channels; per 64-channel K chunk it stages
+//   X: 256 tokens x 64 k            = 32 KB  as 32 one-KiB pieces of 8 full 128-byte rows (one per wave-instruction, no registers,
+//                                      no VALU, no ds_write); rows are XOR-swizzled through the SOURCE address (16-byte piece q of
+//                                      row r sits in slot q ^ (r & 7)), so the 32 consecutive tokens of a B fragment read
+//                                      (ds_read_b128) cover all 64 banks exactly once,
+//   W: (2 NC) x 4 packed fragments  = 8 NC KB: pd_conv's fragment order is already lane-linear (1 KiB per fragment),
+// i.e. 0.375 KB (NC = 2) / 0.25 KB (NC = 4) per MFMA.  Two LDS buffers: the DMA of chunk c + 1 is issued before chunk c's MFMAs,
+// retired by `s_waitcnt vmcnt(0)` + the chunk's one barrier (inline asm: a compiler-visible global_load_lds would order every
+// later ds_read behind it).  Plain layers only (no GroupNorm prologue, dense output, no statistics): the transformer blocks'
+// q/k/v, to_out, GEGLU and FeedForward projections and their input gradients -- 90 % of the SD UNet's Linear FLOPs.
+template <typename T, int NC, bool GLU, int CK>
+__global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma_kernel(const LinP p) {
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  static_assert(CK == 64 || CK == 32, "K chunk");
+  constexpr int ES = 2, TM = 256, TN = 64 * NC;
+  constexpr int KSC = CK / 16;                           // k-steps per chunk
+  constexpr int RPP = 1024 / (CK * ES);                  // token rows per 1-KiB DMA piece (8 / 16)
+  constexpr int SPR = CK * ES / 16;                      // 16-byte slots per row (8 / 4)
+  constexpr int XP = TM / RPP / 8;                       // X pieces per wave per chunk (4 / 2)
+  constexpr int WP = 2 * NC * KSC / 8;                   // W fragments per wave per chunk
+  constexpr int XB = TM * CK * ES;                       // 32 KB: one X chunk, [token][64 k] unpadded, slot-swizzled
+  constexpr int WB = (2 * NC) * KSC * 1024;              // 2 NC channel tiles x KSC k-steps x 1 KiB fragments
+  constexpr int BUF = XB + WB;
+  constexpr int NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;    // three buffers (DMA two chunks ahead) where they fit; CK = 64, NC = 4: two of 64 KB
+  constexpr int TNO = GLU ? TN / 2 : TN;
+  constexpr int EP_PITCH = TN * ES + 16;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // [NBUF][X | W]; epilogue [TM][EP_PITCH]
+
+  int tt, ct;
+  {
+    const int b = blockIdx.x;
+    if ((p.t_tiles & 7) == 0) { tt = (b & 7) + 8 * (b / (8 * p.c_tiles)); ct = (b >> 3) % p.c_tiles; }
+    else { ct = b % p.c_tiles; tt = b / p.c_tiles; }
+  }
+  const long long m0 = (long long)tt * TM;
+  const int n0 = ct * TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wave >> 1, wc = wave & 1;               // token quarter (64 tokens), channel half (32 NC channels)
+  const int r = lane & 31, h = lane >> 5;
+  const int ksteps = p.K / 16, nchunks = p.K / CK;
+  const int last_ct32 = p.N_pad / 32 - 1;
+
+  // ---- DMA sources.  X piece pc (8 rows) = wave * 4 + j: lane -> row pc * 8 + lane / 8, LDS slot lane % 8 holds source piece slot ^ (row & 7)
+  // CK = 64: 8 rows of 128 B per piece, slot s of row r holds source piece s ^ (r & 7).  CK = 32: 16 rows of 64 B, slot s holds
+  // source piece s ^ ((r >> 2) & 3) -- either way the 16 lanes of a ds_read_b128 group cover the 64 banks once.
+  const unsigned char* xsrc[XP];
+#pragma unroll
+  for (int j = 0; j < XP; ++j) {
+    const int row = (wave * XP + j) * RPP + lane / SPR;
+    const int slot = lane % SPR;
+    const int srcp = CK == 64 ? (slot ^ (row & 7)) : (slot ^ ((row >> 2) & 3));
+    const long long m = m0 + row < p.M ? m0 + row : p.M - 1;      // rows past M re-read the last row (never stored)
+    xsrc[j] = (const unsigned char*)p.x + ((size_t)m * p.x_stride + srcp * 8) * ES;
+  }
+  // W fragment f = wave * WP + j of the chunk's 2 NC x KSC: channel tile f / KSC, k-step f % KSC
+  const unsigned char* wsrc[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int f = wave * WP + j;
+    const int c32 = min(n0 / 32 + f / KSC, last_ct32);              // tiles beyond N_pad do not exist: clamp (never stored)
+    wsrc[j] = (const unsigned char*)p.w + (((size_t)c32 * ksteps + (f % KSC)) * 512 + lane * 8) * ES;
+  }
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto dma = [&](const unsigned char* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto stage = [&](int chunk, int b2) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base + b2 * BUF);
+#pragma unroll
+    for (int j = 0; j < XP; ++j) dma(xsrc[j] + (size_t)chunk * CK * ES, base + (wave * XP + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < WP; ++j) dma(wsrc[j] + (size_t)chunk * KSC * 512 * ES, base + XB + (wave * WP + j) * 1024);
+  };
+
+  // accumulators start at the bias: acc[c][f] = channel tile c of this wave's half x token fragment f
+  f32x16 acc[NC][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int c32 = min(n0 / 32 + wc * NC + c, last_ct32);
+    const int cob = GLU ? ((c32 & 1) ? p.N / 2 : 0) + 32 * (c32 >> 1) : c32 * 32;
+    f32x16 init;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(p.bias + cob + 8 * g + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) init[4 * g + i] = bv[i];
+    }
+    acc[c][0] = init; acc[c][1] = init;
+  }
+  // fragment read offsets inside a buffer: B (tokens): row = wt * 64 + f * 32 + r, piece 2 ks + h in slot (2 ks + h) ^ (row & 7);
+  // A (weights): fragment (wc * NC + c) * 4 + ks, lane-linear
+  int brow[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) brow[f] = (wt * 64 + f * 32 + r) * (CK * ES);
+  const int bsw = CK == 64 ? (r & 7) : ((r >> 2) & 3);   // the row's swizzle key: the other terms of the row index are multiples of 32
+  const int a_lane = XB + (wc * NC * KSC) * 1024 + lane * 16;
+
+  // NBUF buffers, DMA running NBUF - 1 chunks ahead; per chunk: wait until this chunk's pieces have landed (each wave counts its own
+  // PER DMAs: the younger chunk may stay in flight), ONE barrier (everybody's pieces landed AND everybody finished the previous
+  // chunk, whose buffer the next DMA overwrites), issue the DMA of chunk + NBUF - 1, multiply.
+  constexpr int PER = XP + WP;
+  stage(0, 0);
+  if (NBUF == 3 && nchunks > 1) stage(1, 1);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (NBUF == 3 && chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (chunk + NBUF - 1 < nchunks) stage(chunk + NBUF - 1, (chunk + NBUF - 1) % NBUF);
+    const unsigned char* buf = lds + (chunk % NBUF) * BUF;
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) {
+      Frag a[NC], b[2];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[c] = E::load(buf + a_lane + (c * KSC + ks) * 1024);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) b[f] = E::load(buf + brow[f] + (((2 * ks + h) ^ bsw) * 16));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        acc[c][0] = E::mma(a[c], b[0], acc[c][0]);
+        acc[c][1] = E::mma(a[c], b[1], acc[c][1]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  __syncthreads();                                       // every wave is done with the last buffer: the epilogue reuses the LDS
+
+  // ---- epilogue: [token][TN channels] through LDS, then coalesced 16-byte residual loads / stores
+  if constexpr (GLU) {
+#pragma unroll
+    for (int u = 0; u < NC / 2; ++u)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int tok = wt * 64 + f * 32 + r;
+        f32x16 o;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = acc[2 * u][f][i] * gelu_f<ES>(acc[2 * u + 1][f][i]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          store4((T*)(lds + tok * EP_PITCH) + (wc * (NC / 2) + u) * 32 + 8 * g + 4 * h, o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+      }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int tok = wt * 64 + f * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          store4((T*)(lds + tok * EP_PITCH) + (wc * NC + c) * 32 + 8 * g + 4 * h, acc[c][f][4 * g], acc[c][f][4 * g + 1], acc[c][f][4 * g + 2],
+                 acc[c][f][4 * g + 3]);
+      }
+  }
+  __syncthreads();
+  constexpr int EPC = 8;                                 // channels per 16-byte piece
+  constexpr int PPT = TNO / EPC;                         // pieces per token
+  constexpr int TPI = 512 / PPT;                         // tokens per iteration
+  constexpr int NIT = TM / TPI;
+  const int piece = tid % PPT, trow = tid / PPT;
+  const int NO = GLU ? p.N / 2 : p.N;
+  const int co = (GLU ? ct * TNO : n0) + piece * EPC;
+  const unsigned ybytes = (unsigned)min((unsigned long long)p.M * NO * ES, 0xffffffffull);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.y), 0, p.residual ? ybytes : 0u, 0x00020000);
+  u32x4 res[NIT];
+  unsigned off[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const long long m = m0 + it * TPI + trow;
+    off[it] = (m < p.M && co < NO) ? (unsigned)(((size_t)m * NO + co) * ES) : OOB_OFF;
+    res[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, off[it], 0, 0);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    u32x4 v = *(const u32x4*)(lds + (it * TPI + trow) * EP_PITCH + piece * 16);
+    if (p.residual) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo, hi, rl, rh;
+        Pack16<T>::unpack(v[j], lo, hi); Pack16<T>::unpack(res[it][j], rl, rh);
+        v[j] = Pack16<T>::pack(lo + rl, hi + rh);
+      }
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(v, ry, off[it], 0, 0);
+  }
+}
+
+template <typename T, int NC, bool GLU, int CK>
+static int launch_linear_dma(const LinP& p, hipStream_t st) {
+  constexpr int BUF = 256 * CK * 2 + 2 * NC * (CK / 16) * 1024, NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
+  constexpr int MAIN = NBUF * BUF, EPI = 256 * (64 * NC * 2 + 16);
+  constexpr int LDS = MAIN > EPI ? MAIN : EPI;
+  auto kern = linear_dma_kernel<T, NC, GLU, CK>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("pd_linear: cannot reserve %d bytes of LDS", LDS);
+      return PD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.t_tiles * p.c_tiles)), dim3(512), LDS, st, p);
+  PD_LAUNCH_CHECK();
+  return PD_OK;
+}
+template <typename T>
+static int dispatch_linear_dma(const LinP& p, int variant, bool glu, hipStream_t st) {   // variant: 2 = (NC 2, CK 64), 3 = (NC 2, CK 32), 4 = (NC 4, CK 64)
+  if (variant == 4) return glu ? launch_linear_dma<T, 4, true, 64>(p, st) : launch_linear_dma<T, 4, false, 64>(p, st);
+  if (variant == 3) return glu ? launch_linear_dma<T, 2, true, 32>(p, st) : launch_linear_dma<T, 2, false, 32>(p, st);
+  return glu ? launch_linear_dma<T, 2, true, 64>(p, st) : launch_linear_dma<T, 2, false, 64>(p, st);
+}
+
 }  // namespace pd
 
 using namespace pd;
@@ -587,6 +808,33 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a->kmax2_out == nullptr || (a->qkv_heads > 0 && a->dtype != PD_F32), PD_ERR_SHAPE,
            "pd_linear: kmax2_out needs the head-major q/k/v output and a 16-bit dtype");
   p.kmax2 = a->kmax2_out;
+  // DMA-staged 256-token kernel (round 3) for the plain layers with enough tiles to fill the chip: no GroupNorm prologue, dense
+  // output, no statistics, K a multiple of 64, a 16-byte-aligned row stride.  PD_LIN_DMA=0 / 2 / 3 / 4: diagnostic override (off / variant).
+  {
+    static const int dma_env = getenv("PD_LIN_DMA") ? atoi(getenv("PD_LIN_DMA")) : -1;
+    const bool plain = a->dtype != PD_F32 && !a->scale && a->qkv_heads == 0 && !a->stats_out && !a->kmax2_out && a->K % 64 == 0 &&
+                       a->x_stride % 8 == 0 && ((size_t)a->M * (glu ? a->N / 2 : a->N) * 2) < 0xC0000000ull;
+    if (plain && dma_env != 0) {
+      const int t256 = (int)((a->M + 255) / 256);
+      const int c4 = (a->N_pad + 255) / 256, c2 = (a->N_pad + 127) / 128;
+      const bool waste4_ok = (long long)c4 * 256 * 10 <= (long long)a->N_pad * 11;
+      int nc = 0;           // variant: 2 = (NC 2, CK 64), 3 = (NC 2, CK 32: two workgroups per CU), 4 = (NC 4, CK 64)
+      // measured on the SD-2.1 transformer shapes at B = 32 (scripts/bench_linear.py, same box, ms: linear_kernel / variant 2 / 3 / 4):
+      //   64^2 qkv 320->960 .156/.176/.152/.140   out 320->320 .056/.057/.047/.061   ff1+glu 320->2560 .330/.351/.305/.311   ff2 1280->320 .195/.171/.182/.180
+      //   32^2 qkv 640->1920 .111/.129/.100/.109  out .045/.045/.039/.048            ff1+glu .261/.306/.255/.269            ff2 2560->640 .145/.144/.132/.151
+      //   16^2 qkv 1280->3840 .100/.114/.100/.093 out .042/.051/.043/.044            ff1+glu .241/.263/.232/.223            ff2 5120->1280 .143/.173/.148/.142
+      // -> 256-channel tiles for wide outputs (N >= 960; behind the fused GEGLU only at K >= 1280), else the two-workgroups-per-CU form
+      if (dma_env >= 2 && dma_env <= 4) nc = dma_env;
+      else if ((long long)t256 * c4 >= 256 && waste4_ok && a->N_pad >= 960 && (!glu || a->K >= 1280)) nc = 4;
+      else if ((long long)t256 * c2 >= 256) nc = 3;
+      if (nc) {
+        p.t_tiles = t256; p.c_tiles = nc == 4 ? c4 : c2;
+        p.xbytes = (unsigned)xbytes; p.x = a->x; p.w = a->w_packed; p.bias = a->bias; p.residual = a->residual; p.y = a->y;
+        hipStream_t st = (hipStream_t)stream;
+        return a->dtype == PD_F16 ? dispatch_linear_dma<half_t>(p, nc, glu, st) : dispatch_linear_dma<bf16_t>(p, nc, glu, st);
+      }
+    }
+  }
   // 256-channel tiles (NC = 4): every staged token tile feeds twice the MFMAs (the activation stream is this kernel's larger cost,
   // DESIGN.md 9); two workgroups per CU.  PD_LIN_NC4=0/1: diagnostic override (same-box A/B).
   static const int nc4_env = getenv("PD_LIN_NC4") ? atoi(getenv("PD_LIN_NC4")) : -1;

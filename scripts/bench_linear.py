@@ -12,9 +12,12 @@ dev, lib = "cuda:0", L.lib()
 st = torch.cuda.current_stream().cuda_stream
 def run(fn, args, iters=20):
     for _ in range(3): L.check(fn(C.byref(args), st))
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(iters): fn(C.byref(args), st)
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters
+    best = float("inf")
+    for _ in range(4):                     # best of 4 x 20: single groups are hit by multi-millisecond hiccups on shared boxes
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(iters): fn(C.byref(args), st)
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / iters)
+    return best
 for hw, ch in ((64, 320), (32, 640), (16, 1280)):
     for name, K, N in (("qkv", ch, 3 * ch), ("out", ch, ch), ("ff1", ch, 8 * ch), ("ff2", 4 * ch, ch)):
         M = B * hw * hw

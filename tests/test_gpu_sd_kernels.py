@@ -203,7 +203,10 @@ def test_geglu_backward(env, mode):
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [(1024, 320, 960, 0, 0), (300, 64, 64, 1, 0), (2048, 1280, 10240, 0, 0), (77 * 3, 96, 256, 0, 0), (515, 5120, 1280, 1, 0),
-                                 (4096, 96, 320, 1, 32), (130, 32, 8, 0, 0), (65536 + 70, 128, 512, 1, 0)])
+                                 (4096, 96, 320, 1, 32), (130, 32, 8, 0, 0), (65536 + 70, 128, 512, 1, 0),
+                                 # round 3: shapes the 16-bit engines run on the DMA-staged 256-token kernel (linear_dma_kernel) -- NC = 2
+                                 # with a ragged 128-channel tile and ragged tokens, one K chunk, a strided input, NC = 4 at K = 1280
+                                 (32768 + 5, 320, 320, 1, 0), (70000, 64, 1280, 0, 0), (33000, 192, 384, 1, 64), (65536, 1280, 1280, 1, 0)])
 def test_linear_gemm(env, mode, cfg):
     """pd_linear against F.linear: full / ragged token tiles, K with a trailing half chunk (96, 32), N not a multiple of the
     128-channel tile, residual, strided input rows (a slice of a fused projection's output).  The (2048, 1280, 10240) and the
@@ -234,7 +237,8 @@ def test_linear_gemm(env, mode, cfg):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
-@pytest.mark.parametrize("cfg", [(1024, 320, 1280), (300, 64, 256), (515, 1280, 5120), (130, 96, 32)])
+@pytest.mark.parametrize("cfg", [(1024, 320, 1280), (300, 64, 256), (515, 1280, 5120), (130, 96, 32),
+                                 (70000, 320, 1280), (40000, 64, 96)])       # the last two: linear_dma_kernel (NC = 4 / NC = 2) in the 16-bit engines
 def test_linear_gemm_fused_geglu(env, mode, cfg):
     """pd_linear(glu = 1) = diffusers GEGLU: proj -> chunk(2) -> value * F.gelu(gate), with the value / gate weight rows
     interleaved per 32-row tile (two pd_pack_weight calls with a two-tile stride, as the re-pack after an optimizer step
