@@ -493,7 +493,7 @@ def main_sd_train(args, P, world, rank, dev, dist):
 
 # Kernel-selecting diagnostic overrides the library reads from the environment (conv_igemm.hip / linear_gemm.hip / attn_d8.hip /
 # unet.py): a bench line measured under one of them says so, and the default (driver) run is expected to carry none.
-DIAG_ENV = ("PD_LIB", "PD_ALLOW_ABI_MISMATCH", "PD_CONV_NCO", "PD_LIN_NC4", "PD_ATTN_NO_GLDS", "PD_ATTN_LDS_PAD", "PD_PREAPPLY_MIN_COUT", "PD_NO_LINEAR_GRADS",
+DIAG_ENV = ("PD_LIB", "PD_ALLOW_ABI_MISMATCH", "PD_BENCH_REHEARSAL", "PD_LIN_DMA", "PD_CONV_NCO", "PD_LIN_NC4", "PD_ATTN_NO_GLDS", "PD_ATTN_LDS_PAD", "PD_PREAPPLY_MIN_COUT", "PD_NO_LINEAR_GRADS",
             "EXTRA_HIPCC_FLAGS")
 
 
@@ -622,7 +622,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # PD_BENCH_REHEARSAL=1 (tests/test_gpu_bench_two_ranks.py): N ranks on the ONE GPU of a test box over gloo -- RCCL refuses two
+        # ranks per device -- so that the whole N > 1 control flow (barriers, the all_gather of the ranks' clocks, rank 0's line)
+        # is exercised before the driver's 8-GPU run.  The line says so (`rehearsal`); never a measurement.
+        if os.environ.get("PD_BENCH_REHEARSAL"):
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.dtype == "fp16" and args.workload in ("train", "sd_train"):
