@@ -10,7 +10,10 @@ region starts, output = float NHWC [0,1] images in HBM (PNG encode / dataset dec
         bench.py --gpus N --steps K --warmup W
 
 Images are independent: each rank transfers its own batches, no collective on the data path ("scaling": "weak").
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  At N = 1 (the driver's default run) that line also carries `side_workloads`: short legs of
+BASELINE.json's other configs -- configs[1] `train`, configs[3] `sd_train`, configs[4] `sd_img2img` in fp16 and bf16 -- each run as a
+child process AFTER the headline's fields are final, each with its own value / ms_per_step / roofline / cpu_baseline
+(`--no-side-workloads` skips them; `--workload X` runs one of them as the main workload).
 """
 import argparse
 import json

@@ -121,6 +121,10 @@ class UNetTrainPlan(UNetPlan):
         m, w, B, H, W = self.m, self.w, self.B, self.H, self.W
         self.tw, self.params, self.grads = tw, params, grads
         self.param_grads, self.input_grad = grads is not None, input_grad
+        if self.param_grads and getattr(w, "class_mode", None) is not None:
+            # class_embed_type "timestep" / "identity" (cond_unet_2d.py:146-153): inference plans only -- the class MLP / identity rows
+            # have no gradient launches (no shipped config sets them; every shipped config uses the nn.Embedding table or none)
+            raise NotImplementedError(f"the backward plan implements the nn.Embedding class table only (class_embed_type={w.class_mode!r})")
         self.dsample = self._f32(B, m.config.in_channels, H, W) if input_grad else None
         if self.param_grads:
             self._check_layout()
