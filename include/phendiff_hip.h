@@ -618,6 +618,19 @@ int pd_event_record(void* ev, void* stream);
 int pd_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int pd_event_destroy(void* ev);
 
+/* ------------------------------------------------------------------------------------------------
+ * pd_comm_*: the data-parallel gradient exchange -- DistributedDataParallel's bucketed all-reduce under accelerator.backward(loss)
+ * (train.py:311-326, utils_training.py:436) -- directly on RCCL (loaded at run time; PD_ERR_UNSUPPORTED when librccl.so is absent).
+ * One communicator per process / GPU, created on the current device.  Rank 0 draws the id (pd_comm_unique_id); the host program ships
+ * the 128 bytes to the other ranks; every rank calls pd_comm_init(id, rank, world, &comm).
+ * pd_allreduce_bucket: in-place fp32 sum (mean != 0: then divided by world) of one contiguous bucket on `stream`;
+ *   algo 0 = ncclAllReduce, algo 1 = reduce-scatter + all-gather over count / world shards (count % world == 0, else algo 0 is used). */
+typedef struct { char bytes[128]; } pd_comm_id;
+int pd_comm_unique_id(pd_comm_id* out);
+int pd_comm_init(const pd_comm_id* id, int rank, int world, void** comm_out);
+int pd_allreduce_bucket(void* comm, float* buf, size_t count, int mean, int algo, void* stream);
+int pd_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

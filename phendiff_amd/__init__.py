@@ -13,6 +13,9 @@ from .img2img import (inversion, ddib, inverted_regeneration, classifier_free_gu
                       CFGForwardStartGraph, SDDDIBGraph, shard_batches, swap_binary_labels, custom_guided_generation,
                       linear_interp_custom_guidance_inverted_start, encode_to_latents, decode_to_images, LDM_preprocess, tensor_to_PIL)
 from .configs import UNET_CONFIGS, SCHEDULER_CONFIGS  # noqa: F401
+from . import configs  # noqa: F401
+from . import diagnostics  # noqa: F401
+from .comm import NativeComm  # noqa: F401
 from . import training  # noqa: F401
 from .unet_train import UNetTrainer, UNetTrainPlan, training_param_order  # noqa: F401
 from . import train_state  # noqa: F401

@@ -168,6 +168,10 @@ class AttnWideArgs(C.Structure):
                 ("out_stride", C.c_int), ("lse", vp)]
 
 
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
 class AttnWideBwdArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("Nq", C.c_int), ("Nkv", C.c_int),
                 ("scale", C.c_float), ("q", vp), ("q_stride", C.c_int), ("k", vp), ("v", vp), ("kv_stride", C.c_int), ("o", vp),
@@ -293,6 +297,10 @@ SYMBOLS = {
     "pd_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "pd_attn_wide": (C.c_int, [C.POINTER(AttnWideArgs), vp]),
     "pd_attn_wide_bwd": (C.c_int, [C.POINTER(AttnWideBwdArgs), vp]),
+    "pd_comm_unique_id": (C.c_int, [C.POINTER(CommId)]),
+    "pd_comm_init": (C.c_int, [C.POINTER(CommId), C.c_int, C.c_int, C.POINTER(vp)]),
+    "pd_allreduce_bucket": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
+    "pd_comm_destroy": (C.c_int, [vp]),
     "pd_latent_sample": (C.c_int, [C.POINTER(LatentSampleArgs), vp]),
     "pd_attn_d64_bwd": (C.c_int, [C.POINTER(AttnD64BwdArgs), vp]),
     "pd_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdArgs), vp]),

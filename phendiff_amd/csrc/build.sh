@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 if [ "$1" = "--clean" ]; then rm -rf "$HERE/build"; rm -f "$OUT" "$OUT.manifest.json"; fi
 mkdir -p "$HERE/build"
 pids=()
-SRCS="conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels vae_kernels sd_bwd_kernels linear_gemm"
+SRCS="conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels vae_kernels sd_bwd_kernels linear_gemm comm_rccl"
 for f in $SRCS; do
   X=""
   # attention (forward d = 8, backward d = 64): keep MFMA accumulators in VGPRs (the softmax / its derivative work on them;
@@ -27,7 +27,7 @@ done
 for p in "${pids[@]}"; do wait $p; done
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $HERE/build/$f.o"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS -ldl
 # manifest: hash of every source the library was built from (bench.py / the profile collectors compare it with the tree).
 # Every object above carries the hash of its own inputs, so the set linked here IS the tree's.  No package / torch import.
 python3 - "$HERE" "$OUT" <<'PY'

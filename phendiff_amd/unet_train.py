@@ -811,10 +811,15 @@ class UNetTrainer:
         flat = self.opt.grad
         works, hooks = [], {}
 
+        native = getattr(self, "native_comm", None)      # phendiff_amd.comm.NativeComm: RCCL through the C ABI (pd_allreduce_bucket)
+
         def launch(start, end):
             ev = torch.cuda.Event()
             ev.record(cur)
             comm.wait_event(ev)
+            if native is not None:
+                native.allreduce_(flat[start:end], mean=False, algo=1, stream=comm)
+                return
             with torch.cuda.stream(comm):
                 works.append(dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=group, async_op=True))
 
@@ -827,6 +832,13 @@ class UNetTrainer:
         cur.wait_stream(comm)
         flat.div_(world)
         return loss
+
+    def use_native_comm(self, comm=None, group=None):
+        """Route the overlapped gradient exchange through ``pd_allreduce_bucket`` (reduce-scatter + all-gather on RCCL behind the C
+        ABI) instead of ``torch.distributed.all_reduce``.  ``comm``: a ``NativeComm``; default: one built over the process group."""
+        from .comm import NativeComm
+        self.native_comm = comm if comm is not None else NativeComm.from_process_group(group, self.device)
+        return self.native_comm
 
     def save_state(self, output_dir, **kw):
         """``accelerator.save_state`` layout (``train_state.py``): model, AdamW moments, LR-scheduler, RNG, EMA."""

@@ -11,11 +11,11 @@ for f in $(git -C "$ROOT" ls-tree --name-only "$REV" phendiff_amd/csrc/ | grep -
 git -C "$ROOT" show "$REV:include/phendiff_hip.h" > "$TMP/include/phendiff_hip.h"
 cd "$TMP/phendiff_amd/csrc"
 OBJS=""
-for f in conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels vae_kernels sd_bwd_kernels linear_gemm; do
+for f in $(ls *.hip | sed "s/\.hip$//"); do
   X=""; { [ "$f" = "attn_d8" ] || [ "$f" = "sd_bwd_kernels" ]; } && X="-mllvm -amdgpu-mfma-vgpr-form"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $X "$@" -c $f.hip -o $f.o 2>/dev/null &
   OBJS="$OBJS $f.o"
 done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build_ab/$NAME.so" $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build_ab/$NAME.so" $OBJS -ldl
 rm -rf "$TMP"
 echo "built build_ab/$NAME.so from $REV"

@@ -303,3 +303,28 @@ def test_attention_backward(env, mode, cfg):
     tol = 3e-5 if mode == "f32" else 2.5e-2       # bf16: P, dS and the outputs are rounded to 8 mantissa bits
     for name, gg, rr in (("dq", got[0], rq), ("dk", got[1], rk), ("dv", got[2], rv)):
         assert rel(gg, rr) < tol, name
+
+
+def test_native_comm_world_one_allreduce(env):
+    """pd_comm_* (RCCL behind the C ABI, csrc/comm_rccl.hip) on the one GPU a test box has: a one-rank communicator, where the sum /
+    mean of a bucket is the bucket itself, through both forms (ncclAllReduce; reduce-scatter + all-gather) and on a side stream --
+    id, init, collective, destroy.  Two ranks per device are refused by RCCL: the multi-rank exchange itself is covered through
+    torch.distributed (tests/test_gpu_two_rank_overlap.py, gloo) and stays unmeasured on hardware."""
+    from phendiff_amd.comm import NativeComm
+    cid = NativeComm.unique_id()
+    assert len(cid) == 128 and any(cid)
+    comm = NativeComm(0, 1, cid)
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(1 << 20, generator=g).cuda()
+    want = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for algo in (0, 1):
+        for mean in (False, True):
+            comm.allreduce_(x, mean=mean, algo=algo, stream=side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    with pytest.raises(Exception):
+        comm.allreduce_(x.half())
+    comm.close()

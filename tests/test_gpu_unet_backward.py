@@ -231,6 +231,14 @@ def test_overlapped_gradient_allreduce_path_single_rank():
         torch.cuda.synchronize()
         assert len(tr._buckets) >= 4 and float(loss) > 0
         assert torch.equal(tr.opt.grad, want)
+        # the same exchange through the C ABI (pd_allreduce_bucket: RCCL reduce-scatter + all-gather, a one-rank communicator)
+        from phendiff_amd.comm import NativeComm
+        tr.opt.grad.zero_()
+        tr.use_native_comm(NativeComm(0, 1))
+        tr._forward_backward_overlapped(*args, labels.cuda(), None, None, 1, 4 << 20)
+        torch.cuda.synchronize()
+        assert torch.equal(tr.opt.grad, want)
+        tr.native_comm.close()
     finally:
         dist.destroy_process_group()
 

@@ -71,6 +71,8 @@ def test_argument_validation_without_gpu():
     assert lib.pd_attn_wide(C.byref(L.AttnWideArgs(dtype=1, B=1, heads=1, D=512, Nq=0, Nkv=4)), None) == -2
     assert lib.pd_attn_d64_bwd(C.byref(L.AttnD64BwdArgs(dtype=1, B=1, heads=1, Nq=4, Nkv=4)), None) == -1
     assert lib.pd_attn_wide_bwd(C.byref(L.AttnWideBwdArgs(dtype=1, B=1, heads=1, D=512, Nq=4, Nkv=4)), None) == -1
+    assert lib.pd_allreduce_bucket(None, None, 16, 1, 1, None) == -1 and b"communicator" in lib.pd_last_error()
+    assert lib.pd_comm_init(None, 0, 1, None) == -1 and lib.pd_comm_destroy(None) == 0
     assert lib.pd_layernorm_bwd(C.byref(L.LayerNormBwdArgs(dtype=1, rows=4, C=12)), None) == -1
     assert lib.pd_layernorm_bwd_blocks(10) == 3 and lib.pd_layernorm_bwd_blocks(1 << 20) == 2048
     with pytest.raises(L.PhenDiffHipError):
