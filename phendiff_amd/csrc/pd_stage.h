@@ -26,11 +26,11 @@ template <typename T> struct Stage {
     u32x4 o = in.v;
     if constexpr (std::is_same<T, half_t>::value) {
       if (affine && silu) {
-        // fp16 engine: the GroupNorm affine in fp32 straight from the packed halves (v_fma_mixlo / mixhi_f16: the unpack and
-        // the re-pack are free), then SiLU on the packed pairs -- v_pk_mul / v_pk_add_f16 and the 16-bit transcendentals in
-        // place on each half.  36 vector instructions per 8 values instead of ~61 (fp32 math: 8 cvt + 16 packed + 16
-        // transcendental + 4 cvt_pk); the exponent argument carries fp16's 2^-11: |error of silu| <= 4e-3 |silu| where
-        // |silu| is tiny (y << 0) and ~1e-3 elsewhere, against the 5e-4 of the fp16 store that follows
+        // fp16 engine: the GroupNorm affine in fp32 straight from the packed halves, y kept as a packed fp16 pair (v_fma_mixlo / mixhi_f16:
+        // unpack and re-pack are free); the sigmoid's exponent argument, the exponential and the reciprocal in fp32 (v_fma_mix_f32 reads
+        // the fp16 halves directly); y * sigmoid back to packed fp16 by v_fma_mixlo / mixhi_f16.  A first version ran the whole SiLU on
+        // the packed halves (v_pk_mul_f16, v_exp_f16, v_rcp_f16): same instruction time (the 16-bit transcendentals issue at the fp32
+        // rate and need a v_pack_b32_f16 per pair) but the fp16 exponent argument raised the UNet's error from 1.5e-3 to 2.0e-3.
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -39,13 +39,12 @@ template <typename T> struct Stage {
           h2 y;
           y.x = (_Float16)__builtin_fmaf((float)x.x, sc[2 * j], sh[2 * j]);
           y.y = (_Float16)__builtin_fmaf((float)x.y, sc[2 * j + 1], sh[2 * j + 1]);
-          const h2 t = y * (h2)((_Float16)-1.4426950408889634f);
-          h2 e;
-          e.x = __builtin_exp2f16(t.x); e.y = __builtin_exp2f16(t.y);
-          const h2 d = e + (h2)((_Float16)1.0f);
-          h2 r;
-          r.x = __builtin_amdgcn_rcph(d.x); r.y = __builtin_amdgcn_rcph(d.y);
-          o[j] = __builtin_bit_cast(uint32_t, (h2)(y * r));
+          const float e0 = __builtin_amdgcn_exp2f((float)y.x * -1.4426950408889634f), e1 = __builtin_amdgcn_exp2f((float)y.y * -1.4426950408889634f);
+          const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
+          h2 o2;
+          o2.x = (_Float16)((float)y.x * r0);
+          o2.y = (_Float16)((float)y.y * r1);
+          o[j] = __builtin_bit_cast(uint32_t, o2);
         }
         if (ZERO && !valid) o = (u32x4)(0u);
         *(u32x4*)dst = o;
