@@ -32,6 +32,9 @@ from .unet import CustomCondUNet2DModel, UNetPlan, _Attention, _Op, _PackedWeigh
 
 # diagnostic (same-box A/B): route the 1x1 gradients through pd_conv / pd_conv_wgrad as the 3x3 ones
 _NO_LINEAR_GRADS = bool(os.environ.get("PD_NO_LINEAR_GRADS"))
+# diagnostic (same-box A/B): keep the GroupNorm-prologue 1x1 weight gradients on pd_conv_wgrad (round 3 routes them through
+# pd_gn_apply + pd_token_wgrad)
+_NO_PREAPPLY_WGRAD = bool(os.environ.get("PD_NO_PREAPPLY_WGRAD"))
 
 def training_param_order(m: CustomCondUNet2DModel) -> List[Tuple[str, torch.nn.Parameter]]:
     """(name, parameter) pairs in the order the flat training buffers use: all ``time_emb_proj`` weights (then biases)
@@ -246,6 +249,18 @@ class UNetTrainPlan(UNetPlan):
         go through the token-reduction GEMM ``pd_token_wgrad``."""
         if not self.param_grads:
             return
+        if (ksize == 1 and gn is not None and x1 is None and not cout_valid and not cin_valid and x0.shape[3] % 8 == 0 and dy.shape[3] % 8 == 0
+                and not _NO_LINEAR_GRADS and not _NO_PREAPPLY_WGRAD):
+            # a 1x1 layer behind a GroupNorm (the attention's fused q/k/v projection, Transformer2DModel.proj_in): pd_conv_wgrad's 1x1
+            # form rebuilds the normalised input while staging and runs at ~190 TF/s; materialising it once (pd_gn_apply: one
+            # bandwidth-bound pass over a tensor 1/16 .. 1/64 of the image-resolution ones) lets the token-reduction GEMM take it
+            ops, self.ops = self.ops, self.bwd_ops
+            try:
+                x0 = self._gn_apply(x0, None, gn, silu)
+            finally:
+                self.ops = ops
+            self.bwd_ops[-1].what = "gn_apply_bwd"
+            gn, silu = None, 0
         if (ksize == 1 and gn is None and x1 is None and not cout_valid and not cin_valid and x0.shape[3] % 8 == 0 and dy.shape[3] % 8 == 0
                 and not _NO_LINEAR_GRADS):
             B, h, w, K = x0.shape
