@@ -496,6 +496,125 @@ __global__ __launch_bounds__(256) void token_wgrad_kernel(const TwP p) {
     }
 }
 
+// token_wgrad_dma_kernel (round 3): the same GEMM with both operands staged by DMA (global_load_lds: no staging registers, no
+// ds_write, no VALU) and a larger register tile.  token_wgrad_kernel reads 1 KB of LDS per MFMA (4 fragments per 4 MFMAs) and its
+// 128 x 128 tiles waste 20 % of the MFMAs per 320-multiple dimension of the latent-diffusion UNet (320 -> 384).  Here a wave owns
+// FN x FK 32 x 32 tiles (5 x 2 or 2 x 5: 7 fragments per 10 MFMAs = 0.7 KB per MFMA, 160 accumulator registers), the four waves
+// 2 x 2 of them: workgroup tile 320 x 128 or 128 x 320 -- whichever wastes less of N x K (every width of the SD UNet is a multiple
+// of 320 = 5 x 64 on one side and of 128 on the other, except the 320 x 320 layers: 1.2 instead of 1.44).  Same LDS layout as above
+// (32-channel planes of 64-byte token rows, transposed fragment reads), one stage = TM = 32 tokens = 2 (FN + FK) planes of 2 KiB =
+// 28 one-KiB DMA pieces (16 token rows of 64 bytes: 4 lanes per row), 7 per wave.  NBUF buffers, DMA NBUF - 1 stages ahead, per
+// stage one counted `s_waitcnt vmcnt` + one barrier (as linear_dma_kernel).  Requires M % 32 == 0 (a partial stage would have to
+// be zero-filled: the reduction runs over the tokens) and N, K multiples of 32 (a tile's planes past N / K re-read the last valid
+// plane; those rows / columns of the slab are never read).
+template <typename T, int FN, int FK, int NBUF>
+__global__ __launch_bounds__(256, 2) void token_wgrad_dma_kernel(const TwP p) {
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  constexpr int ES = 2, TM = 32, PXB = 32 * ES;
+  constexpr int PLANE = TM * PXB;                        // 2 KiB
+  constexpr int NPL = 2 * (FN + FK);                     // planes per stage: [dY: 2 FN | X: 2 FK]
+  constexpr int BUF = NPL * PLANE;
+  constexpr int UPP = PLANE / 1024;                      // DMA pieces per plane (2)
+  constexpr int U = NPL * UPP;
+  static_assert(U % 4 == 0, "pieces must divide evenly over the four waves (one wait count for all)");
+  constexpr int UW = U / 4;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // [NBUF][BUF]
+
+  const int ncombo = p.n_tiles * p.k_tiles;
+  const int split = blockIdx.x / ncombo, combo = blockIdx.x - split * ncombo;
+  const int nt = combo / p.k_tiles, kt = combo - nt * p.k_tiles;
+  const int n0 = nt * (64 * FN), k0 = kt * (64 * FK);
+  const int c_begin = split * p.chunks_per_split, c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+  if (c_begin >= c_end) return;                          // (cannot happen: splits = ceil(nchunks / chunks_per_split))
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+
+  // ---- DMA sources: piece u = 4 j + wave -> plane u / UPP, 16-token block u % UPP; lane -> token row lane / 4, 16-byte slot lane % 4
+  const unsigned char* src[UW];
+  long long adv[UW];                                      // bytes per stage (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < UW; ++j) {
+    const int u = 4 * j + wave;
+    const int plane = u / UPP, tb = u % UPP;
+    const long long m = (long long)c_begin * TM + tb * 16 + (lane >> 2);
+    if (plane < 2 * FN) {
+      const int ch = min(n0 + plane * 32, p.N - 32) + (lane & 3) * 8;
+      src[j] = (const unsigned char*)p.dy + ((size_t)m * p.dy_stride + ch) * ES;
+      adv[j] = (long long)TM * p.dy_stride * ES;
+    } else {
+      const int ch = min(k0 + (plane - 2 * FN) * 32, p.K - 32) + (lane & 3) * 8;
+      src[j] = (const unsigned char*)p.x + ((size_t)m * p.x_stride + ch) * ES;
+      adv[j] = (long long)TM * p.x_stride * ES;
+    }
+  }
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto dma = [&](const unsigned char* s, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(s), "s"(dst) : "memory");
+  };
+  auto stage = [&](int b2) {                              // issues the NEXT stage of this workgroup's token range into buffer b2
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base + b2 * BUF);
+#pragma unroll
+    for (int j = 0; j < UW; ++j) {
+      dma(src[j], base + (4 * j + wave) * 1024);
+      src[j] += adv[j];
+    }
+  };
+
+  f32x16 acc[FN][FK];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FK; ++b) acc[a][b] = (f32x16)(0.f);
+  const unsigned lo = FragLd<T>::lane_off(lane, PXB);
+  const int a_off = (wn * FN) * PLANE + lo, b_off = (2 * FN + wk * FK) * PLANE + lo;
+
+  const int nst = c_end - c_begin;
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i)
+    if (i < nst) stage(i);
+  for (int st = 0; st < nst; ++st) {
+    // this stage's pieces have landed when at most min(NBUF - 2, stages left after this one) younger stages are in flight
+    const int younger = min(NBUF - 2, nst - 1 - st);
+    if (NBUF >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * UW) : "memory");
+    else if (NBUF >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(UW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // everybody's pieces landed AND everybody is done with the buffer re-filled next
+    if (st + NBUF - 1 < nst) stage((st + NBUF - 1) % NBUF);
+    const unsigned char* buf = lds + (st % NBUF) * BUF;
+#pragma unroll
+    for (int ks = 0; ks < TM / 16; ++ks) {
+      Frag fa[FN], fb[FK];
+#pragma unroll
+      for (int a = 0; a < FN; ++a) fa[a] = FragLd<T>::template load<PXB>(buf + a_off + a * PLANE + ks * 16 * PXB);
+#pragma unroll
+      for (int b = 0; b < FK; ++b) fb[b] = FragLd<T>::template load<PXB>(buf + b_off + b * PLANE + ks * 16 * PXB);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FK; ++b) acc[a][b] = E::mma(fa[a], fb[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // partial tile -> slab[split][n][k]: lane = column k, register g <-> row n = 8 (g>>2) + 4 h + (g&3)
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FK; ++b) {
+      float* out = p.slab + ((size_t)split * p.NP + n0 + (wn * FN + a) * 32) * p.KP + k0 + (wk * FK + b) * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) out[(size_t)((g & 3) + 8 * (g >> 2) + 4 * h) * p.KP] = acc[a][b][g];
+    }
+}
+
 // dw[n][k] (+)= sum over splits of slab[split][n][k] (splits added in order: bitwise reproducible); coalesced rows
 __global__ __launch_bounds__(256) void token_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int NP, int KP,
                                                                   int N, int K, int accumulate) {
@@ -512,16 +631,66 @@ __global__ __launch_bounds__(256) void token_wgrad_reduce_kernel(const float* __
   *o = accumulate ? *o + (s0 + s1) : (s0 + s1);
 }
 
-static void token_wgrad_plan(long long M, int K, int N, int* n_tiles, int* k_tiles, int* splits, int* cps, int* nchunks) {
+// Token splits: the grid (splits x tiles) should fill the resident workgroup slots ONCE -- a grid of 1.1 x the slots runs two rounds,
+// the second nearly empty (round 3: ceil() here cost up to 40 % on the 80-tile layers) -- unless the token range is long enough
+// for several full rounds to amortise the tail; each split writes one fp32 tile set to the slab, so splits are also bounded by
+// `min_stages` stages per split.
+static int token_wgrad_splits(int nchunks, int combos, int slots, int min_stages) {
+  int s = slots / combos;                                // one round, filled from below
+  if (s < 1) s = 1;
+  const int amort = nchunks / min_stages > 1 ? nchunks / min_stages : 1;
+  return s < amort ? s : amort;
+}
+static void token_wgrad_plan(long long M, int K, int N, int esz, int* n_tiles, int* k_tiles, int* splits, int* cps, int* nchunks) {
   *n_tiles = (N + 127) / 128; *k_tiles = (K + 127) / 128;
   *nchunks = (int)((M + 63) / 64);
-  const int combos = *n_tiles * *k_tiles;
-  int want = (768 + combos - 1) / combos;              // fill 256 CUs x up to 3 resident workgroups
-  int amort = *nchunks / 4 > 1 ? *nchunks / 4 : 1;     // >= 4 stages per slab tile written
-  int s = want < amort ? want : amort;
-  if (s < 1) s = 1;
+  // resident workgroups: 64 KiB of LDS each in bf16 = 2 per CU, 128 KiB in fp32 = 1 per CU
+  const int s = token_wgrad_splits(*nchunks, *n_tiles * *k_tiles, esz == 2 ? 512 : 256, 4);
   *cps = (*nchunks + s - 1) / s;
   *splits = (*nchunks + *cps - 1) / *cps;
+}
+// the DMA form: tiles of tn x tk channels, 32-token stages, two workgroups per CU
+static void token_wgrad_plan_dma(long long M, int K, int N, int tn, int tk, int* n_tiles, int* k_tiles, int* splits, int* cps, int* nchunks) {
+  *n_tiles = (N + tn - 1) / tn; *k_tiles = (K + tk - 1) / tk;
+  *nchunks = (int)(M / 32);
+  const int s = token_wgrad_splits(*nchunks, *n_tiles * *k_tiles, 512, 16);   // >= 16 stages (448 KB staged) per slab tile written (160 KB)
+  *cps = (*nchunks + s - 1) / s;
+  *splits = (*nchunks + *cps - 1) / *cps;
+}
+// which form: 0 = token_wgrad_kernel (128 x 128), 1 = DMA 320 (n) x 128 (k), 2 = DMA 128 x 320, 3 = DMA 128 x 128.  PD_TW_DMA overrides
+// (diagnostic).  The DMA forms need whole 32-token stages and 32-channel planes.
+static int token_wgrad_variant(const pd_token_wgrad_args* a) {
+  if (a->dtype != PD_BF16 || a->M % 32 != 0 || a->N % 32 != 0 || a->K % 32 != 0 || a->N < 32 || a->K < 32) return 0;
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("PD_TW_DMA"); forced = e ? atoi(e) : -1; }
+  if (forced >= 0 && forced <= 3) return forced;
+  auto padded = [&](int tn, int tk) { return (double)((a->N + tn - 1) / tn * tn) * (double)((a->K + tk - 1) / tk * tk); };
+  const double w0 = padded(128, 128), w1 = padded(320, 128), w2 = padded(128, 320);
+  if (a->M < 2048) return 0;                           // a handful of stages per workgroup: the DMA pipeline never fills
+  if (w1 <= w2 && w1 <= w0) return 1;
+  if (w2 <= w0) return 2;
+  return 3;
+}
+static void token_wgrad_tile(int variant, int* tn, int* tk) {
+  *tn = variant == 1 ? 320 : 128; *tk = variant == 2 ? 320 : 128;
+}
+
+template <typename T, int FN, int FK, int NBUF>
+static int launch_token_wgrad_dma(const TwP& p, hipStream_t st) {
+  constexpr int LDS = NBUF * 2 * (FN + FK) * 32 * 64;
+  auto kern = token_wgrad_dma_kernel<T, FN, FK, NBUF>;
+  if (LDS > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        set_error("pd_token_wgrad: cannot reserve %d bytes of LDS", LDS);
+        return PD_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.splits * p.n_tiles * p.k_tiles)), dim3(256), LDS, st, p);
+  return PD_OK;
 }
 
 template <typename T, int NC, bool GLU = false>
@@ -859,8 +1028,15 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
 extern "C" size_t pd_token_wgrad_workspace(const pd_token_wgrad_args* a) {
   if (!a || a->M < 1 || a->K < 1 || a->N < 1) return 0;
   int nt, kt, splits, cps, nch;
-  token_wgrad_plan(a->M, a->K, a->N, &nt, &kt, &splits, &cps, &nch);
-  return (size_t)splits * nt * 128 * kt * 128 * sizeof(float);
+  const int v = token_wgrad_variant(a);
+  if (v == 0) {
+    token_wgrad_plan(a->M, a->K, a->N, a->dtype == PD_F32 ? 4 : 2, &nt, &kt, &splits, &cps, &nch);
+    return (size_t)splits * nt * 128 * kt * 128 * sizeof(float);
+  }
+  int tn, tk;
+  token_wgrad_tile(v, &tn, &tk);
+  token_wgrad_plan_dma(a->M, a->K, a->N, tn, tk, &nt, &kt, &splits, &cps, &nch);
+  return (size_t)splits * nt * tn * kt * tk * sizeof(float);
 }
 
 extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
@@ -874,8 +1050,14 @@ extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
   PD_CHECK(xbytes < 0x80000000ull && dybytes < 0x80000000ull, PD_ERR_SHAPE, "pd_token_wgrad: operands must be < 2 GiB (32-bit buffer offsets)");
   TwP p{};
   p.M = a->M; p.K = a->K; p.N = a->N; p.x_stride = a->x_stride; p.dy_stride = a->dy_stride;
-  token_wgrad_plan(a->M, a->K, a->N, &p.n_tiles, &p.k_tiles, &p.splits, &p.chunks_per_split, &p.nchunks);
-  p.NP = p.n_tiles * 128; p.KP = p.k_tiles * 128;
+  const int variant = token_wgrad_variant(a);
+  int tn = 128, tk = 128;
+  if (variant == 0) token_wgrad_plan(a->M, a->K, a->N, (int)esz, &p.n_tiles, &p.k_tiles, &p.splits, &p.chunks_per_split, &p.nchunks);
+  else {
+    token_wgrad_tile(variant, &tn, &tk);
+    token_wgrad_plan_dma(a->M, a->K, a->N, tn, tk, &p.n_tiles, &p.k_tiles, &p.splits, &p.chunks_per_split, &p.nchunks);
+  }
+  p.NP = p.n_tiles * tn; p.KP = p.k_tiles * tk;
   const size_t per_split = (size_t)p.NP * p.KP * sizeof(float);
   if ((size_t)p.splits * per_split > a->slab_bytes) {
     const int s = (int)(a->slab_bytes / per_split);
@@ -887,7 +1069,11 @@ extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
   p.x = a->x; p.dy = a->dy; p.slab = a->slab;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(p.splits * p.n_tiles * p.k_tiles);
-  if (a->dtype == PD_BF16) {
+  if (variant != 0) {
+    const int rc = variant == 1 ? launch_token_wgrad_dma<bf16_t, 5, 2, 2>(p, st)
+                 : variant == 2 ? launch_token_wgrad_dma<bf16_t, 2, 5, 2>(p, st) : launch_token_wgrad_dma<bf16_t, 2, 2, 3>(p, st);
+    if (rc != PD_OK) return rc;
+  } else if (a->dtype == PD_BF16) {
     constexpr int LDS = 2 * 2 * 4 * 64 * 64;            // 64 KiB
     hipLaunchKernelGGL(token_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), LDS, st, p);
   } else {

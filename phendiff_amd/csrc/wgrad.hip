@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const pd_pack_we
 }
 
 static int pick_splits(int ntiles, int ncombo) {
-  int want = (512 + ncombo - 1) / ncombo;          // fill 256 CUs x 2 resident workgroups
+  // fill the 256 CUs x 2 resident workgroups ONCE, from below: rounding up (rounds 1-3) made grids of 513-528 workgroups for
+  // 3, 6, 12, 24 or 25 channel-tile combinations (the up path's concatenated inputs; every 320-wide SD layer) = a second,
+  // nearly empty round of workgroups
+  int want = 512 / ncombo;
   int amort = ntiles / 8 > 1 ? ntiles / 8 : 1;      // >= 8 pixel tiles per slab written
   int s = want < amort ? want : amort;
   if (s > ntiles) s = ntiles;

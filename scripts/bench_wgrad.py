@@ -7,6 +7,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import phendiff_amd._lib as L  # noqa: E402
+if os.environ.get("PD_LIB"):
+    L.LIB_PATH = os.environ["PD_LIB"]      # same-box A/B of two builds
 
 
 def bench(B, cin, cout, H, W, ksize=3, affine=True, reps=20, splits=None):
@@ -42,6 +44,8 @@ def bench(B, cin, cout, H, W, ksize=3, affine=True, reps=20, splits=None):
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     for cfg in [(64, 64, 128), (128, 64, 128), (192, 64, 128), (128, 128, 64), (256, 128, 64), (384, 128, 64), (256, 256, 32), (512, 256, 32), (384, 256, 32)]:
+        bench(B, cfg[0], cfg[1], cfg[2], cfg[2])
+    for cfg in [(320, 320, 64), (640, 320, 64), (640, 640, 32), (1280, 640, 32), (1280, 1280, 16), (2560, 1280, 16), (960, 640, 32)]:   # SD-2.1 UNet widths
         bench(B, cfg[0], cfg[1], cfg[2], cfg[2])
     bench(B, 256, 256, 32, 32, affine=False)
     for s in (1, 4, 16, 64):

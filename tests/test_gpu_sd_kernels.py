@@ -272,11 +272,14 @@ def test_linear_gemm_fused_geglu(env, mode, cfg):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [(4096, 320, 960, 0), (300, 64, 64, 0), (2048, 1280, 2560, 0), (77 * 3, 96, 256, 0), (8200, 640, 200, 24), (64, 8, 8, 0)])
+@pytest.mark.parametrize("cfg", [(4096, 320, 960, 0), (300, 64, 64, 0), (2048, 1280, 2560, 0), (77 * 3, 96, 256, 0), (8200, 640, 200, 24), (64, 8, 8, 0),
+                                 (2048, 256, 128, 8), (4096, 320, 320, 0), (65 * 32, 640, 320, 16), (2048 + 32, 96, 352, 0)])
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_token_wgrad(env, mode, cfg, accumulate):
     """pd_token_wgrad against dY^T X: ragged token chunks, channel counts that are not multiples of the 128 tile, strided rows,
-    a deliberately small slab (fewer splits), accumulation into an existing gradient."""
+    a deliberately small slab (fewer splits), accumulation into an existing gradient.  The bf16 cases with M % 32 == 0, M >= 2048 and
+    32-multiple channel counts run the DMA-staged forms (320 x 128: (2048, 1280, 2560), (4096, 320, 320); 128 x 320: (4096, 320, 960),
+    (2080, 640, 320); 128 x 128: (2048, 256, 128); planes past N / K clamped: (2080, 96, 352)), the others token_wgrad_kernel."""
     L, lib, _, dev = env
     code, tdt = DT[mode]
     M, K, N, pad = cfg
