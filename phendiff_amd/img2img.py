@@ -258,12 +258,30 @@ class DDIBGraph:
         B, S = self.B, self.S
         dev = self.device
         self.lib = L.lib()
-        if B > unet.max_batch(H, W):
-            raise ValueError(f"batch_size {B} exceeds what one launch plan holds at {H}x{W} ({unet.max_batch(H, W)} images: tensors are "
-                             f"addressed with 32-bit byte offsets); replay several DDIBGraph runners (shard_batches) instead")
+        cin = unet.config.in_channels
+        self._bounds = None
+        mb = unet.max_batch(H, W)
+        if B > mb:
+            # One launch plan addresses each tensor with 32-bit byte offsets (< 2 GiB: 127 images of 256 x 256 x 64 bf16 channels), so a
+            # larger batch (SURVEY 8(d) sweeps batch_size up to 128) is replayed as even slices -- the samples of a batch are independent
+            # (utils_Img2Img.py:566-612: no cross-sample op anywhere on the path).  Slices of equal size share ONE captured graph.
+            n_sl = -(-B // mb)
+            step = -(-B // n_sl)
+            self._bounds = [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
+            self._runners = {}
+            for b0, b1 in self._bounds:
+                if b1 - b0 not in self._runners:
+                    self._runners[b1 - b0] = DDIBGraph(pipe, b1 - b0, S, H, W, variant, dev, use_graph, private_plan)
+            first = self._runners[self._bounds[0][1] - self._bounds[0][0]]
+            self.plan, self.stream, self.inv_ts, self.gen_ts = first.plan, first.stream, first.inv_ts, first.gen_ts
+            self.inverted = torch.empty((B, cin, H, W), dtype=torch.float32, device=dev)
+            self.images = torch.empty((B, H, W, cin), dtype=torch.float32, device=dev)
+            self.images_u8 = torch.empty((B, H, W, cin), dtype=torch.uint8, device=dev)
+            self.graph = C.c_void_p(None)
+            self.use_graph = use_graph
+            return
         self.plan = unet.new_plan(B, H, W, dev) if private_plan else unet.plan_for(B, H, W, dev)
         _refuse_class_modes_in_graph(self.plan, "DDIBGraph")
-        cin = unet.config.in_channels
         # schedulers (host tables)
         self.inv = DDIMInverseScheduler.from_config(pipe.scheduler.config, variant=variant)
         self.inv.set_timesteps(S)
@@ -343,6 +361,19 @@ class DDIBGraph:
         """``join=False`` leaves the caller's stream un-joined (call ``self.join()`` before reading the outputs), so several
         runners can replay concurrently on their own streams."""
         B = self.B
+        if self._bounds is not None:
+            if tuple(clean_images.shape) != (B,) + tuple(self.inverted.shape[1:]):
+                raise ValueError(f"expected images of shape {tuple(self.inverted.shape)}, got {tuple(clean_images.shape)}")
+            for b0, b1 in self._bounds:
+                r = self._runners[b1 - b0]
+                r.run(clean_images[b0:b1], orig_class_labels[b0:b1], target_class_labels[b0:b1], join=False)
+                with torch.cuda.stream(r.stream):      # stream-ordered before the runner's next replay overwrites its outputs
+                    self.images[b0:b1].copy_(r.images, non_blocking=True)
+                    self.images_u8[b0:b1].copy_(r.images_u8, non_blocking=True)
+                    self.inverted[b0:b1].copy_(r.inverted, non_blocking=True)
+            if join:
+                self.join()
+            return self
         if clean_images.shape != self.x.shape:
             raise ValueError(f"expected images of shape {tuple(self.x.shape)}, got {tuple(clean_images.shape)}")
         n_inv, n_gen = len(self.inv_ts), len(self.gen_ts)
@@ -366,6 +397,10 @@ class DDIBGraph:
         return self
 
     def join(self):
+        if self._bounds is not None:
+            for r in self._runners.values():
+                r.join()
+            return self
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self
 

@@ -260,6 +260,31 @@ def test_ddib_eager_and_graph_vs_oracle(mode, tol):
     assert rel(out2.images, ref2) < tol
 
 
+def test_ddib_graph_slices_batches_beyond_one_plan(monkeypatch):
+    """SURVEY 8(d) sweeps batch_size up to 128; one launch plan holds <= 127 images at 256 x 256 (32-bit byte offsets).  DDIBGraph replays a
+    larger batch as even slices (equal slices share one captured graph): same result as the oracle, and per-sample identical to the
+    trajectories of the slices run on their own.  The plan limit is lowered to 3 images here (7 = 3 + 2 + 2: two graphs, three replays)."""
+    import phendiff_amd as P
+    from oracle import ddib_ref
+    pref, pgot = _pipes("f32")
+    monkeypatch.setattr(type(pgot.unet), "max_batch", lambda self, H, W: 3)
+    x, labels = synth_batch(7, 32, seed=5)
+    target = 1 - labels
+    g = P.DDIBGraph(pgot, batch_size=7, num_inference_steps=3)
+    assert [b1 - b0 for b0, b1 in g._bounds] == [3, 3, 1] or [b1 - b0 for b0, b1 in g._bounds] == [3, 2, 2]
+    out = g.run(x.cuda(), labels.cuda(), target.cuda())
+    torch.cuda.synchronize()
+    ref_img, ref_inv = ddib_ref(pref, x, labels, target, 3)
+    assert rel(out.images, ref_img) < 2e-5 and rel(out.inverted, ref_inv) < 2e-5
+    assert out.images_u8.shape == (7, 32, 32, 3) and int(np.abs(out.images_u8.cpu().numpy().astype(int) - (ref_img * 255).round().astype(int)).max()) <= 1
+    b0, b1 = g._bounds[1]
+    solo = P.DDIBGraph(pgot, batch_size=b1 - b0, num_inference_steps=3, private_plan=True).run(x[b0:b1].cuda(), labels[b0:b1].cuda(), target[b0:b1].cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(solo.images, out.images[b0:b1]) and torch.equal(solo.inverted, out.inverted[b0:b1])
+    with pytest.raises(ValueError):
+        g.run(x[:6].cuda(), labels[:6].cuda(), target[:6].cuda())
+
+
 def test_golden_fixture_ddib_f32():
     """Committed oracle vectors (tests/golden/make_golden.py): weights seed 0, super_small @32, S=4."""
     import phendiff_amd as P
