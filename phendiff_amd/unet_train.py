@@ -254,6 +254,7 @@ class UNetTrainPlan(UNetPlan):
             # a 1x1 layer behind a GroupNorm (the attention's fused q/k/v projection, Transformer2DModel.proj_in): pd_conv_wgrad's 1x1
             # form rebuilds the normalised input while staging and runs at ~190 TF/s; materialising it once (pd_gn_apply: one
             # bandwidth-bound pass over a tensor 1/16 .. 1/64 of the image-resolution ones) lets the token-reduction GEMM take it
+            first = len(self.bwd_ops)
             ops, self.ops = self.ops, self.bwd_ops
             try:
                 x0 = self._gn_apply(x0, None, gn, silu)
@@ -261,6 +262,12 @@ class UNetTrainPlan(UNetPlan):
                 self.ops = ops
             self.bwd_ops[-1].what = "gn_apply_bwd"
             gn, silu = None, 0
+            # `dw` came from _G(): "the NEXT emitted op writes this gradient" -- that op is now the pd_token_wgrad below, not the
+            # pd_gn_apply just emitted (the overlapped all-reduce would hand the bucket over one launch early: with two real
+            # ranks the reduced stale values then overwrite the gradient -- tests/test_gpu_two_rank_overlap.py)
+            for n, r in self.grad_ready.items():
+                if r >= first:
+                    self.grad_ready[n] = len(self.bwd_ops)
         if (ksize == 1 and gn is None and x1 is None and not cout_valid and not cin_valid and x0.shape[3] % 8 == 0 and dy.shape[3] % 8 == 0
                 and not _NO_LINEAR_GRADS):
             B, h, w, K = x0.shape

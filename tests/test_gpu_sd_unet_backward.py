@@ -135,6 +135,12 @@ def test_sd_training_step_bf16_reduces_loss_and_overlapped_path():
     names = list(tr.grads)
     assert all(n in plan.grad_ready for n in names)
     assert plan.grad_ready["class_embedding.inner_module.weight"] == len(plan.bwd_ops) - 1
+    # every completion point is a launch that writes into the flat gradient buffer (not a helper launch emitted before the writer)
+    lo, hi = tr.opt.grad.data_ptr(), tr.opt.grad.data_ptr() + tr.opt.grad.numel() * 4
+    for name, idx in plan.grad_ready.items():
+        op = plan.bwd_ops[idx]
+        ptrs = [getattr(op.args, f) for f, _ in op.args._fields_]
+        assert any(isinstance(v, int) and lo <= v < hi for v in ptrs), (name, idx, op.what)
 
 
 def test_sd_save_state_resume_continues_bitwise(tmp_path):

@@ -227,6 +227,14 @@ def test_overlapped_gradient_allreduce_path_single_rank():
         assert set(plan.grad_ready) == set(tr.grads)                      # every parameter has a completion point
         assert plan.grad_ready["conv_out.weight"] < plan.grad_ready["mid_block.resnets.0.conv1.weight"] \
             < plan.grad_ready["conv_in.weight"] <= plan.grad_ready["time_embedding.linear_1.weight"]
+        # ... and that point IS a launch that writes into the flat gradient buffer (a helper launch emitted between _G() and the writer --
+        # the GroupNorm pre-apply of the q/k/v weight gradient -- once made a bucket's hand-over one launch early: invisible at one rank,
+        # stale values reduced over the real gradient at two: tests/test_gpu_two_rank_overlap.py)
+        lo, hi = tr.opt.grad.data_ptr(), tr.opt.grad.data_ptr() + tr.opt.grad.numel() * 4
+        for name, idx in plan.grad_ready.items():
+            op = plan.bwd_ops[idx]
+            ptrs = [getattr(op.args, f) for f, _ in op.args._fields_]
+            assert any(isinstance(v, int) and lo <= v < hi for v in ptrs), (name, idx, op.what)
         loss = tr._forward_backward_overlapped(*args, labels.cuda(), None, None, 1, 4 << 20)
         torch.cuda.synchronize()
         assert len(tr._buckets) >= 4 and float(loss) > 0
