@@ -308,12 +308,22 @@ __device__ __forceinline__ void pack_weight_block(const pd_pack_weight_args& a, 
   // source block: forward rows o = co (ct), cols i = ci (chunk); input-gradient rows o = ci (chunk), cols i = co (ct)
   const int o0 = a.dgrad ? chunk * 32 : ct * 32, i0 = a.dgrad ? ct * 32 : chunk * 32;
   const int n_o = a.dgrad ? a.cin : a.cout, n_i = a.dgrad ? a.cout : a.cin;       // valid source rows / cols
-  for (int e = tid; e < 32 * run; e += 256) {
-    const int ro = e / run, c = e - ro * run;          // c = i_local * taps + t
-    const int i = i0 + c / taps;
-    float x = 0.f;
-    if (o0 + ro < n_o && i < n_i) x = a.src[((size_t)(o0 + ro) * a.src_in + i0) * taps + c];
-    tile[ro * pitch + c] = x;
+  if (taps == 1 && o0 + 32 <= n_o && i0 + 32 <= n_i && (a.src_in & 3) == 0 && (((size_t)a.src) & 15) == 0) {
+    // 1x1 / Linear weights, whole block valid (workgroup-uniform): the 32 x 32 block is 256 float4 = ONE 16-byte load per thread
+    // (round 3: four 4-byte loads per thread and a workgroup's worth of launch overhead per KiB made the re-pack of the SD UNet's
+    // Linear layers run at a quarter of the memory rate)
+    const int ro = tid >> 3, c4 = (tid & 7) * 4;
+    const f32x4 x = *(const f32x4*)(a.src + (size_t)(o0 + ro) * a.src_in + i0 + c4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[ro * pitch + c4 + j] = x[j];
+  } else {
+    for (int e = tid; e < 32 * run; e += 256) {
+      const int ro = e / run, c = e - ro * run;          // c = i_local * taps + t
+      const int i = i0 + c / taps;
+      float x = 0.f;
+      if (o0 + ro < n_o && i < n_i) x = a.src[((size_t)(o0 + ro) * a.src_in + i0) * taps + c];
+      tile[ro * pitch + c] = x;
+    }
   }
   __syncthreads();
   for (int f = tid; f < taps * 2 * 64; f += 256) {

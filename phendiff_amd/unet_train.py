@@ -596,22 +596,28 @@ def run_pack_jobs(lib, jobs, stream, cache, device):
         return
     st = cache.get("batch")
     if st is None:
-        n = len(jobs)
         for a in jobs:     # what pd_pack_weight would refuse
             if a.cout_pad % 32 or a.cin_pad % 32 or a.cout_pad < a.cout or a.cin_pad < a.cin or a.dtype != jobs[0].dtype:
                 raise L.PhenDiffHipError("pd_pack_weight_batch: inconsistent job descriptors")
-        raw = (L.PackWeightArgs * n)(*jobs)
         dev = torch.device(device)
-        table = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(dev)
-        starts, tot = [0], 0
-        for a in jobs:
-            tot += (a.cout_pad // 32) * (a.cin_pad // 32)
-            starts.append(tot)
-        starts_t = torch.tensor(starts, dtype=torch.int32, device=dev)
-        args = L.PackWeightBatchArgs(dtype=jobs[0].dtype, n=n, jobs=table.data_ptr(), starts=starts_t.data_ptr(), total_blocks=tot,
-                                     max_ksize=max(a.ksize for a in jobs))
-        st = cache["batch"] = (args, table, starts_t)
-    L.check(lib.pd_pack_weight_batch(C.byref(st[0]), stream), "pd_pack_weight_batch")
+        st = []
+        # one launch per kernel size: the workgroup's LDS tile is sized by the launch's largest kernel (37 KB for 3x3 against 4 KB for the
+        # Linear / 1x1 blocks, which are most of the latent-diffusion UNet's blocks and would run at a quarter of the occupancy beside them)
+        for ks in sorted({a.ksize for a in jobs}):
+            sel = [a for a in jobs if a.ksize == ks]
+            raw = (L.PackWeightArgs * len(sel))(*sel)
+            table = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(dev)
+            starts, tot = [0], 0
+            for a in sel:
+                tot += (a.cout_pad // 32) * (a.cin_pad // 32)
+                starts.append(tot)
+            starts_t = torch.tensor(starts, dtype=torch.int32, device=dev)
+            args = L.PackWeightBatchArgs(dtype=sel[0].dtype, n=len(sel), jobs=table.data_ptr(), starts=starts_t.data_ptr(), total_blocks=tot,
+                                         max_ksize=ks)
+            st.append((args, table, starts_t))
+        cache["batch"] = st
+    for args, _, _ in st:
+        L.check(lib.pd_pack_weight_batch(C.byref(args), stream), "pd_pack_weight_batch")
 
 
 class _Repacker:
