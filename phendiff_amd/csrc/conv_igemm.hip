@@ -617,7 +617,8 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
 
 // tile shape by output width: 32-wide rows when possible (bank-conflict-free), else squarer tiles
 static void tile_shape(int ksize, int stride, int hout, int wout, int* th, int* tw) {
-  const int tp = ((ksize == 3 && stride == 2) || (ksize == 3 && stride == 1 && wout < 16 && hout <= 16)) ? 128 : 256;
+  const int tp = (ksize == 3 && stride == 1 && wout <= 8 && hout <= 8) ? 64
+                 : ((ksize == 3 && stride == 2) || (ksize == 3 && stride == 1 && wout < 16 && hout <= 16)) ? 128 : 256;
   *tw = wout >= 32 ? 32 : (wout >= 16 ? 16 : 8);
   *th = tp / *tw;
 }
@@ -655,14 +656,19 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
       }
       if (nco2) return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 2>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 2>(p, st);
     }
+    // images of at most 8 x 8 pixels (the SD UNet's innermost level at 512 x 512): an 8 x 8 tile = two 32-pixel fragments, one per
+    // wave pair -- the 16 x 8 tile spent half of its MFMAs on rows below the image (round 3: 1 280 -> 1 280 @8x8 417 TF/s)
+    const bool one8 = p.Hout <= 8 && w <= 8;
     if (p.n_tail > 0) {
       if (w >= 32) return launch_conv<T, 3, 1, 8, 32, true>(p, st);
       if (w >= 16) return launch_conv<T, 3, 1, 16, 16, true>(p, st);
+      if (one8) return launch_conv<T, 3, 1, 8, 8, true>(p, st);
       if (tiny) return launch_conv<T, 3, 1, 16, 8, true>(p, st);
       return launch_conv<T, 3, 1, 32, 8, true>(p, st);
     }
     if (w >= 32) return launch_conv<T, 3, 1, 8, 32>(p, st);
     if (w >= 16) return launch_conv<T, 3, 1, 16, 16>(p, st);
+    if (one8) return launch_conv<T, 3, 1, 8, 8>(p, st);
     if (tiny) return launch_conv<T, 3, 1, 16, 8>(p, st);
     return launch_conv<T, 3, 1, 32, 8>(p, st);
   }
