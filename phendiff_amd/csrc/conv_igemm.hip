@@ -28,6 +28,11 @@
 #ifndef PD_CONV_PRIO_BASE
 #define PD_CONV_PRIO_BASE 0
 #endif
+// 16-bit 3x3 stride-1 double-buffered variants multiply with v_mfma_f32_16x16x32 instead of 32x32x16 (see M16 in conv_kernel).
+// -DPD_CONV_M16=0 builds the 32x32x16 form everywhere (same-box A/B).
+#ifndef PD_CONV_M16
+#define PD_CONV_M16 1
+#endif
 namespace pd {
 
 
@@ -56,7 +61,10 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 // halo tile -- every staged (GroupNorm + SiLU-transformed) activation and every LDS fragment read feeds twice the MFMAs, and the
 // grid of the 128 / 256-channel layers (4096 / 2048 workgroups of the NCO = 1 form on 768 slots = 5.33 / 2.67 rounds) becomes
 // 2048 / 1024 workgroups on 512 slots = whole rounds.  128 accumulator registers: two workgroups per CU instead of three.
-template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1>
+// PLAIN (compile time): no GroupNorm / SiLU prologue -- the input gradients of every convolution, the latent-diffusion UNet's convolutions
+// (its GroupNorms are applied by pd_gn_apply), the upsamplers.  The 16 scale / shift registers and the transform are gone, which is what lets
+// the 16x16x32 MFMA form (M16 below) fit the register budgets.
+template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1, bool PLAIN = false>
 __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2)) void conv_kernel(const ConvP p) {   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
   static_assert(NCO == 1 || (NCO == 2 && DB && KS == 3 && STRIDE == 1), "two output tiles per workgroup: 3x3 stride-1 double-buffered variant only");
@@ -72,8 +80,21 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   // double-buffered variants interleave the two buffers per pixel -- [chunk c: 32 ch | chunk c+1: 32 ch | 16 B pad] -- so both
   // share ONE pad: 144-byte pixels (bf16; an odd number of 16-B slots, conflict-free like the 80-byte single pitch) make the
   // 10 x 34 halo tile 48 960 B instead of 2 x 27 200 B, which (with the 168-register budget) admits a third workgroup per CU
+  // M16 (PLAIN, 16-bit, 3x3, stride 1, double-buffered, TW >= 16, one output tile per workgroup): the MFMAs are v_mfma_f32_16x16x32 -- per (32 co x 32 pixel) block and tap
+  // 4 MFMAs over K = 32 channels instead of 2 x 32x32x16 over K = 16: the same FLOPs, cycles, operand bytes and registers, but the
+  // chip holds a higher clock on this shape under the convolution's load (it runs at 1.9-2.0 GHz, profiles/r3_conv_clock.json;
+  // MI355X_MICROARCH.md "DVFS give-back" item 7; a timing-only build of this kernel with the shape swapped: -4.1 % on the sum of 3x3).
+  // The form needs 4 (NCO = 1) / 8 (NCO = 2) registers more for its A operands (a tap's two operands are prefetched a whole tap ahead) and
+  // spilled behind a GroupNorm prologue (16 scale / shift registers): shipped for the PLAIN instantiations only, where it fits (162 VGPRs,
+  // no scratch) -- same box: the SD UNet's 3x3 convolutions -4.3 % (16 x 16 levels -12 %), SD img2img +1.4...1.6 %, SD fine-tuning +1.1 %.
+  //   A: the PACKED weights are unchanged (32 co x 16 k fragments, lane (r, h) = 8 channels 16 half + 8 h of row r): lane (i, g) of the
+  //      16 co x 32 k operand ti reads the 16 bytes of old lane (16 ti + i, g & 1) of half g >> 1 -- four 256-byte runs per wave;
+  //   B: lane (i, g) reads pixel i of its 16-pixel run, channels 8 g .. 8 g + 7 (one ds_read_b128); pixel pitch 160 B (10 slots):
+  //      the 144-byte pitch is 2-way conflicted for this access, 160 is conflict-free (brute force over the ds_read_b128 lane groups);
+  //   D: acq[c][f][2 ti + tj]: lane (i, g) owns pixel 16 tj + i of fragment f and channels 16 ti + 4 g .. + 3 of tile c.
+  constexpr bool M16 = PD_CONV_M16 && PLAIN && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DB && TW >= 16;
   constexpr int CHB = 32 * E::BYTES;                 // bytes of one 32-channel chunk of a pixel
-  constexpr int PITCH = DB ? 2 * CHB + 16 : CHB + 16;
+  constexpr int PITCH = DB ? 2 * CHB + (M16 ? 32 : 16) : CHB + 16;
   constexpr int NIT = (NPIX * 4 + 255) / 256;
   constexpr int TAPS = KS * KS;
   constexpr int KSTEPS = TAPS * 2;
@@ -130,8 +151,8 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
     }
     spix[i] = v;
   }
-  const bool affine = p.scale != nullptr;
-  const bool do_silu = p.silu != 0;
+  const bool affine = !PLAIN && p.scale != nullptr;
+  const bool do_silu = !PLAIN && p.silu != 0;
   const int cin = p.C0 + p.C1;
 
   SR stage[NIT];
@@ -227,15 +248,23 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   };
 
   // ---- per-lane LDS read bases for the B (activation) fragments
+  const int li = lane & 15, lg = lane >> 4;          // M16: row / column within a 16 x 16 operand, k group
+  constexpr int TJ_STEP = (TW >= 32 ? 16 : IN_TW) * PITCH;   // M16: bytes from the first to the second 16-pixel run of a fragment
   int rbase[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int fi = wp * NF + f;
-    const int py = fi * RPF + r / TW, px = r % TW;
-    rbase[f] = ((py * STRIDE) * IN_TW + px * STRIDE) * PITCH + h * 8 * E::BYTES;
+    if constexpr (M16) {
+      // one VGPR: fragment f is a compile-time distance from fragment 0 (folded into the ds_read offset field)
+      rbase[f] = f == 0 ? ((wp * NF * RPF) * IN_TW + li) * PITCH + lg * 8 * E::BYTES : 0;
+    } else {
+      const int py = fi * RPF + r / TW, px = r % TW;
+      rbase[f] = ((py * STRIDE) * IN_TW + px * STRIDE) * PITCH + h * 8 * E::BYTES;
+    }
   }
 
-  f32x16 acc[NCO][NF];
+  f32x16 acc[NCO][NF];                    // 32x32x16 form
+  f32x4 acq[NCO][NF][4];                  // M16 form (the unused one of the two is dead code)
   const int main_ksteps = (TAIL ? p.n_main : p.nchunks) * KSTEPS;
   const int all_ksteps = main_ksteps + (TAIL ? p.n_tail * 2 : 0);
   // Weight fragments through a buffer resource: address = base + per-lane VGPR offset (fixed) + SGPR offset (k-step, tile):
@@ -256,6 +285,14 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   constexpr int AR = (KSTEPS % 3 == 0) ? 3 : 2;
   constexpr int AD = AR - 1;
   Frag aring[AR][NCO];
+  // M16: the two 16 co x 32 k operands of a tap, ring of two taps (tap t in entry t & 1, tap t + 1 prefetched at the start of tap t;
+  // a chunk has 9 taps, so the entry prefetched last moves to entry 0 at the end of a chunk: 8 NCO register moves)
+  static_assert(!M16 || NF % 2 == 0, "M16 walks a fragment pair per half-step");
+  Frag aq[2][NCO][2];
+  const unsigned wlane16 = (unsigned)(((lg >> 1) * 64 + (lg & 1) * 32 + li) * 16);
+  auto load_w16 = [&](int c, int tap_index, int ti) {
+    return E::load_buf(rw, wlane16 + (unsigned)ti * 256u, wtile + (unsigned)c * wstep + (unsigned)PD_WIDX(2 * tap_index) * wfrag);
+  };
 
   // one chunk of MFMAs out of `buf`; when DB, pieces of the NEXT chunk are transformed + written to `nbuf` in between
   auto mma_chunk = [&](int chunk, const unsigned char* buf, unsigned char* nbuf, auto have_next_c, auto active_c) {
@@ -269,7 +306,34 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 #endif
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      if constexpr (ACTIVE) {
+      if constexpr (ACTIVE && M16) {
+        // half-step ks = (tap, pixel half s): the tap's two A operands x the four 16-pixel runs of fragments 2 s', 2 s' + 1
+        const int tap = ks >> 1, s = ks & 1;
+        if (s == 0) {
+#pragma unroll
+          for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) aq[(tap + 1) & 1][c][ti] = load_w16(c, chunk * TAPS + tap + 1, ti);
+        }
+        constexpr int FH = NF >= 2 ? NF / 2 : 1;   // (NF = 1 tiles are never M16)
+        const int toff = ((tap / KS) * IN_TW + (tap % KS)) * PITCH;
+        Frag bq[FH][2];
+#pragma unroll
+        for (int f = 0; f < FH; ++f)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) bq[f][tj] = E::load(buf + rbase[0] + (s * FH + f) * (RPF * IN_TW * PITCH) + tj * TJ_STEP + toff);
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+          for (int f = 0; f < FH; ++f)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < 2; ++tj)
+                acq[c][s * FH + f][2 * ti + tj] = E::mma_16x16x32(aq[tap & 1][c][ti], bq[f][tj], acq[c][s * FH + f][2 * ti + tj]);
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE);
+      } else if constexpr (ACTIVE) {
 #pragma unroll
         for (int c = 0; c < NCO; ++c) aring[(ks + AD) % AR][c] = load_w(c, g0 + ks + AD);
         {
@@ -294,13 +358,42 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
         piece = due;
       }
     }
+    if constexpr (ACTIVE && M16) {       // TAPS is odd: the operands prefetched for the next chunk's tap 0 sit in entry 1
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) { aq[0][c][0] = aq[1][c][0]; aq[0][c][1] = aq[1][c][1]; }
+    }
   };
   // tail chunk (fused 1x1 shortcut): 2 k-steps at the centre tap; its two weight fragments are loaded up front
   auto mma_tail = [&](int chunk, const unsigned char* buf, unsigned char* nbuf, auto have_next_c, auto active_c) {
     constexpr bool HAVE_NEXT = decltype(have_next_c)::value;
     constexpr bool ACTIVE = decltype(active_c)::value;
     constexpr int CENTER = ((KS / 2) * IN_TW + (KS / 2)) * PITCH;
-    if constexpr (ACTIVE) {
+    if constexpr (ACTIVE && M16) {
+      const int tt = (main_ksteps >> 1) + (chunk - p.n_main);          // tap-pair index of this tail chunk in the packed k order
+      Frag ta[NCO][2];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) { ta[c][0] = load_w16(c, tt, 0); ta[c][1] = load_w16(c, tt, 1); }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        constexpr int FH = NF >= 2 ? NF / 2 : 1;   // (NF = 1 tiles are never M16)
+        Frag bq[FH][2];
+#pragma unroll
+        for (int f = 0; f < FH; ++f)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) bq[f][tj] = E::load(buf + rbase[0] + (s * FH + f) * (RPF * IN_TW * PITCH) + tj * TJ_STEP + CENTER);
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+          for (int f = 0; f < FH; ++f)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < 2; ++tj)
+                acq[c][s * FH + f][2 * ti + tj] = E::mma_16x16x32(ta[c][ti], bq[f][tj], acq[c][s * FH + f][2 * ti + tj]);
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE);
+      }
+    } else if constexpr (ACTIVE) {
       const int kt = main_ksteps + (chunk - p.n_main) * 2;
       Frag a0[NCO], a1[NCO];
 #pragma unroll
@@ -336,6 +429,21 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   // channels of a partial last tile lie beyond the resource and read zeros).
   f32x4 bt[NCO][4];
   u32x4 tv[NCO][4];
+  if constexpr (M16) {
+    // lane (i, g): registers r of quad (ti, tj) <-> co = 16 ti + 4 g + r: two (bias, temb) pairs per tile instead of four
+    if (wave_active) {
+      const __amdgpu_buffer_rsrc_t rtemb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.temb ? p.temb : p.bias), 0,
+          p.temb ? ((unsigned)n * (unsigned)p.temb_stride + (unsigned)p.Cout) * 4u : 0u, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < NCO; ++c)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          const int co = (ct32 + 2 * c) * 32 + 16 * ti + 4 * lg;
+          bt[c][ti] = *(const f32x4*)(p.bias + co);
+          tv[c][ti] = __builtin_amdgcn_raw_buffer_load_b128(rtemb, (unsigned)(n * p.temb_stride + co) * 4u, 0, 0);
+        }
+    }
+  } else
   if (wave_active) {
     const __amdgpu_buffer_rsrc_t rtemb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.temb ? p.temb : p.bias), 0,
         p.temb ? ((unsigned)n * (unsigned)p.temb_stride + (unsigned)p.Cout) * 4u : 0u, 0x00020000);   // up to the end of row n's slice
@@ -353,13 +461,25 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 #pragma unroll
     for (int c = 0; c < NCO; ++c)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < (M16 ? 2 : 4); ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bt[c][g][i] += __uint_as_float(tv[c][g][i]);
   }
   PD_STAMP(8);
   // accumulators start at bias[co] + temb[n][co] (lane (pixel, h), register i <-> co = 8(i>>2) + 4h + (i&3)):
   // the epilogue then has no per-channel loads at all
+  if constexpr (M16) {
+#pragma unroll
+    for (int c = 0; c < NCO; ++c)
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acq[c][f][q] = wave_active ? bt[c][q >> 1] : (f32x4)(0.f);
+    if (wave_active) {
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) { aq[0][c][0] = load_w16(c, 0, 0); aq[0][c][1] = load_w16(c, 0, 1); }
+    }
+  } else {
 #pragma unroll
   for (int c = 0; c < NCO; ++c) {
     f32x16 init = (f32x16)(0.f);
@@ -377,6 +497,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
     for (int i = 0; i < AD; ++i)
 #pragma unroll
       for (int c = 0; c < NCO; ++c) aring[i][c] = load_w(c, i);
+  }
   }
   PD_STAMP(9);
   if (!p.im2col3) zero_padding();
@@ -436,6 +557,24 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   if (p.out_mode == PD_OUT_NCHW_F32) {
     // conv_out: <= 4 real channels, fp32 planes; lanes (pixels) are contiguous along x
     if (!wave_active) return;
+    if constexpr (M16) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          const int fi = wp * NF + f, pp = tj * 16 + li;
+          const int oy = y0 + fi * RPF + pp / TW, ox = x0 + pp % TW;
+          if (oy >= p.Hout || ox >= p.Wout) continue;
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) {
+            const int co = co_w + 16 * ti + 4 * lg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (co + i < p.Cout) ((float*)p.y)[(((size_t)n * p.Cout + co + i) * p.Hout + oy) * p.Wout + ox] = acq[0][f][2 * ti + tj][i];
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int fi = wp * NF + f;
@@ -491,12 +630,23 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   }
   if (cth > 0) __syncthreads();
   if (wave_active) {
+    if constexpr (M16) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int plin = (wp * NF + f) * 32 + (q & 1) * 16 + li;
+          const f32x4 v = acq[cth][f][q];
+          store4((T*)(lds + plin * EP_PITCH) + wc * 32 + (q >> 1) * 16 + 4 * lg, v[0], v[1], v[2], v[3]);
+        }
+    } else {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int plin = (wp * NF + f) * 32 + r;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         store4((T*)(lds + plin * EP_PITCH) + wc * 32 + 8 * g + 4 * h, acc[cth][f][4 * g], acc[cth][f][4 * g + 1], acc[cth][f][4 * g + 2], acc[cth][f][4 * g + 3]);
+    }
     }
   }
   __syncthreads();
@@ -581,7 +731,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   PD_STAMP(6);
 }
 
-template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false, int NCO = 1>
+template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false, int NCO = 1, bool PLAIN = false>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int IN_TH = (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
@@ -589,13 +739,14 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   // double-buffer when two tiles fit comfortably -- and leave room for a second workgroup: the stride-2 halo tile (9 x 65 pixels)
   // double-buffered is 84 KB = ONE workgroup (4 waves) per CU; single-buffered 47 KB admits two, which overlap each other
   constexpr bool DB = 2 * LDS_TILE <= 100 * 1024 && !(STRIDE == 2 && PD_S2_SINGLE);
-  constexpr int LDS_DB = ((IN_TH * IN_TW * (2 * 32 * Elem<T>::BYTES + 16) + 15) / 16) * 16;   // interleaved buffers, one shared pad
+  constexpr bool M16 = PD_CONV_M16 && PLAIN && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && TW >= 16;        // (conv_kernel: 160-byte pixels)
+  constexpr int LDS_DB = ((IN_TH * IN_TW * (2 * 32 * Elem<T>::BYTES + (M16 ? 32 : 16)) + 15) / 16) * 16;   // interleaved buffers, one shared pad
   constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 256 * 64;   // output tile + stats scratch [256][2*EPC] fp32
   constexpr int LDS_MAIN = DB ? LDS_DB : LDS_TILE;
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
   static_assert(NCO == 1 || DB, "NCO = 2 is a double-buffered variant");
-  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO>;
+  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO, PLAIN>;
   if (LDS_BYTES > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -654,7 +805,15 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
         const double speed2 = (p.scale != nullptr && p.C0 + p.C1 >= 128) ? 1.05 : 0.84;
         nco2 = nco_env ? nco_env == 2 : eff(wgs2, 2ll * cus) * speed2 > eff(wgs1, 3ll * cus);
       }
+      // no GroupNorm / SiLU prologue (input gradients, the SD UNet's convolutions, upsamplers): the PLAIN instantiations = 16x16x32 MFMAs
+      static const bool plain_off = getenv("PD_CONV_PLAIN") && atoi(getenv("PD_CONV_PLAIN")) == 0;      // diagnostic: same-box A/B
+      const bool plain = !plain_off && p.scale == nullptr && !p.silu && !p.im2col3 && w >= 16;
+      // (the two-tile form keeps the 32x32x16 MFMAs: its 16x16x32 form needs 32 registers of A operands and spills at 256)
       if (nco2) return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 2>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 2>(p, st);
+      if (plain) {
+        if (p.n_tail > 0) return w >= 32 ? launch_conv<T, 3, 1, 8, 32, true, 1, true>(p, st) : launch_conv<T, 3, 1, 16, 16, true, 1, true>(p, st);
+        return w >= 32 ? launch_conv<T, 3, 1, 8, 32, false, 1, true>(p, st) : launch_conv<T, 3, 1, 16, 16, false, 1, true>(p, st);
+      }
     }
     // images of at most 8 x 8 pixels (the SD UNet's innermost level at 512 x 512): an 8 x 8 tile = two 32-pixel fragments, one per
     // wave pair -- the 16 x 8 tile spent half of its MFMAs on rows below the image (round 3: 1 280 -> 1 280 @8x8 417 TF/s)

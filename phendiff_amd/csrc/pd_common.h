@@ -118,6 +118,7 @@ template <> struct Elem<float> {
     for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[i], b.hi[i], c, 0, 0, 0);
     return c;
   }
+  static __device__ __forceinline__ f32x4 mma_16x16x32(const Frag&, const Frag&, f32x4 c) { return c; }   // (16-bit engines only; never called)
   static __device__ __forceinline__ float to_f(float v) { return v; }
   static __device__ __forceinline__ float from_f(float v) { return v; }
 };
@@ -145,6 +146,11 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ f32x16 mma16(s16x8 a, s16x8 b, f32x16 c) {      // D += A[32 x 16] . B[16 x 32] on raw 16-bit lanes
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  // D[16 x 16] += A[16 x 32] . B[32 x 16]: lane (i = lane % 16, g = lane / 16) holds row / column i, k = 8 g .. 8 g + 7; D: column i, rows 4 g .. 4 g + 3
+  static __device__ __forceinline__ f32x4 mma_16x16x32(const Frag& a, const Frag& b, f32x4 c) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
   }
   static __device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
   static __device__ __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
@@ -178,6 +184,10 @@ template <> struct Elem<half_t> {
   static __device__ __forceinline__ f32x16 mma16(s16x8 a, s16x8 b, f32x16 c) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mma_16x16x32(const Frag& a, const Frag& b, f32x4 c) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a.v), __builtin_bit_cast(h8, b.v), c, 0, 0, 0);
   }
   static __device__ __forceinline__ float to_f(half_t v) { return h2f(v); }
   static __device__ __forceinline__ half_t from_f(float v) { return f2h(v); }
