@@ -558,8 +558,11 @@ def test_conv_in_im2col_mode(env, mode, hw):
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 64, 96, 32, 64, 32, 32), (1, 128, 64, 0, 64, 16, 16), (2, 32, 32, 32, 96, 8, 8)])
-def test_conv3x3_with_fused_1x1_tail(env, mode, shape):
-    """ResnetBlock2D tail: conv2(silu(gn(h))) + conv_shortcut(cat[x0, x1]) in ONE pd_conv (tail chunks)."""
+@pytest.mark.parametrize("plain", [False, True])
+def test_conv3x3_with_fused_1x1_tail(env, mode, shape, plain):
+    """ResnetBlock2D tail: conv2(silu(gn(h))) + conv_shortcut(cat[x0, x1]) in ONE pd_conv (tail chunks).  plain: no GroupNorm / SiLU
+    prologue (the latent-diffusion UNet applies its GroupNorms with pd_gn_apply) -- in the 16-bit engines the prologue-free
+    instantiations multiply with 16x16x32 MFMAs on tiles of width >= 16."""
     L, lib, pack, dev = env
     code, tdt = DT[mode]
     B, cm, t0, t1, cout, h, w_ = shape
@@ -580,12 +583,13 @@ def test_conv3x3_with_fused_1x1_tail(env, mode, shape):
     sc, sh = scale.to(dev), shift.to(dev)
     y = torch.full((B, h, w_, cout), float("nan"), dtype=tdt, device=dev)
     a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=h, Wout=w_, C0=cm, C1=0, Cout=cout, Cout_pad=cout, ksize=3, stride=1, pad=1,
-                   upsample=0, silu=1, out_mode=0, heads=0, x0=H_.data_ptr(), x1=None, scale=sc.data_ptr(), shift=sh.data_ptr(),
+                   upsample=0, silu=0 if plain else 1, out_mode=0, heads=0, x0=H_.data_ptr(), x1=None,
+                   scale=None if plain else sc.data_ptr(), shift=None if plain else sh.data_ptr(),
                    w_packed=wp.data_ptr(), bias=bias.data_ptr(), temb=None, temb_stride=0, residual=None, y=y.data_ptr(),
                    stats_out=None, tail_x0=XA.data_ptr(), tail_x1=L.ptr(XB), tail_C0=t0, tail_C1=t1, im2col3=0)
     L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
     torch.cuda.synchronize()
-    hin = bf16_round(F.silu(bf16_round(hmid, mode) * scale[:, :, None, None] + shift[:, :, None, None]), mode)
+    hin = bf16_round(hmid, mode) if plain else bf16_round(F.silu(bf16_round(hmid, mode) * scale[:, :, None, None] + shift[:, :, None, None]), mode)
     xcat = torch.cat([bf16_round(xa, mode)] + ([bf16_round(xb, mode)] if xb is not None else []), 1)
     ref = F.conv2d(hin, bf16_round(w2, mode), b2, padding=1) + F.conv2d(xcat, bf16_round(ws, mode), bs)
     assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
