@@ -195,51 +195,71 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm over C per token: one wave per token, 8-element pieces
-template <typename T>
+// LayerNorm over C per token, 8-element pieces: a wave normalises TPW = 4 / MAXP tokens at once (MAXP = pieces per lane: 1 for C <= 512,
+// 2 for C <= 1024, 4 for C <= 2048) with every load issued before the first reduction -- one token per wave left a single 16-byte load
+// per lane in flight (3.4 TB/s at C = 320, round 3)
+template <typename T, int MAXP>
 __global__ __launch_bounds__(256) void layernorm_kernel(const pd_layernorm_args a) {
   using E = Elem<T>;
-  constexpr int MAXP = 4;                             // C <= 64 lanes * 8 * 4 = 2048
+  constexpr int TPW = 4 / MAXP;
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW;
+  if (row0 >= a.rows) return;
   const int pieces = a.C / 8;
-  const T* x = (const T*)a.x + row * a.C;
-  float v[MAXP][8];
-  float s = 0.f;
+  float v[TPW][MAXP][8];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const long long row = row0 + t < a.rows ? row0 + t : a.rows - 1;      // (a partial last group re-reads the last row; not stored)
+    const T* x = (const T*)a.x + row * a.C;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int pc = lane + 64 * i;
+      if (pc < pieces) E::unpack(E::load(x + pc * 8), v[t][i]);
+    }
+  }
+  float gm[MAXP][8], bt[MAXP][8];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     const int pc = lane + 64 * i;
     if (pc < pieces) {
-      E::unpack(E::load(x + pc * 8), v[i]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[i][j];
+      for (int j = 0; j < 8; ++j) { gm[i][j] = a.gamma[pc * 8 + j]; bt[i][j] = a.beta[pc * 8 + j]; }
     }
   }
 #pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk);
-  const float mean = s / (float)a.C;
-  float q = 0.f;
+  for (int t = 0; t < TPW; ++t) {
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    const int pc = lane + 64 * i;
-    if (pc < pieces) {
+    for (int i = 0; i < MAXP; ++i)
+      if (lane + 64 * i < pieces) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-    }
-  }
+        for (int j = 0; j < 8; ++j) s += v[t][i][j];
+      }
 #pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) q += __shfl_xor(q, msk);
-  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
-  T* y = (T*)a.y + row * a.C;
+    for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk);
+    const float mean = s / (float)a.C;
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    const int pc = lane + 64 * i;
-    if (pc < pieces) {
-      float o[8];
+    for (int i = 0; i < MAXP; ++i)
+      if (lane + 64 * i < pieces) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * a.gamma[pc * 8 + j] + a.beta[pc * 8 + j];
-      E::store(y + pc * 8, E::pack(o));
+        for (int j = 0; j < 8; ++j) { const float d = v[t][i][j] - mean; q += d * d; }
+      }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) q += __shfl_xor(q, msk);
+    const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+    if (row0 + t < a.rows) {
+      T* y = (T*)a.y + (row0 + t) * a.C;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        const int pc = lane + 64 * i;
+        if (pc < pieces) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (v[t][i][j] - mean) * rstd * gm[i][j] + bt[i][j];
+          E::store(y + pc * 8, E::pack(o));
+        }
+      }
     }
   }
 }
@@ -310,10 +330,19 @@ extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
 extern "C" int pd_layernorm(const pd_layernorm_args* a, void* stream) {
   PD_CHECK(a != nullptr && a->rows > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 2048 && a->x && a->y && a->gamma && a->beta, PD_ERR_ARG,
            "pd_layernorm: bad args (C must be a multiple of 8, <= 2048)");
-  const unsigned grid = (unsigned)((a->rows + 3) / 4);
-  if (a->dtype == PD_F32) hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
-  else if (a->dtype == PD_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
-  else if (a->dtype == PD_F16) hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  const int maxp = a->C <= 512 ? 1 : (a->C <= 1024 ? 2 : 4);
+  const int rows_per_wg = 4 * (4 / maxp);
+  const unsigned grid = (unsigned)((a->rows + rows_per_wg - 1) / rows_per_wg);
+  hipStream_t st = (hipStream_t)stream;
+#define PD_LN_LAUNCH(T)                                                                                             \
+  do {                                                                                                              \
+    if (maxp == 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(grid), dim3(256), 0, st, *a);                  \
+    else if (maxp == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(grid), dim3(256), 0, st, *a);             \
+    else hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(grid), dim3(256), 0, st, *a);                            \
+  } while (0)
+  if (a->dtype == PD_F32) PD_LN_LAUNCH(float);
+  else if (a->dtype == PD_BF16) PD_LN_LAUNCH(bf16_t);
+  else if (a->dtype == PD_F16) PD_LN_LAUNCH(half_t);
   else { set_error("pd_layernorm: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
