@@ -29,8 +29,9 @@ extern "C" {
 
 /* Bumped whenever an args struct grows or an entry point is added (a caller built against an older header passes shorter
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
- * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3. */
-#define PD_ABI_VERSION 3
+ * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query,
+ * pd_adamw_ema_args.frozen). */
+#define PD_ABI_VERSION 4
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
@@ -629,6 +630,8 @@ typedef struct { char bytes[128]; } pd_comm_id;
 int pd_comm_unique_id(pd_comm_id* out);
 int pd_comm_init(const pd_comm_id* id, int rank, int world, void** comm_out);
 int pd_allreduce_bucket(void* comm, float* buf, size_t count, int mean, int algo, void* stream);
+/* rank and size as the communicator itself reports them (ncclCommUserRank / ncclCommCount) -- what bench.py prints as `rccl_world_size` */
+int pd_comm_query(void* comm, int* rank_out, int* world_out);
 int pd_comm_destroy(void* comm);
 
 #ifdef __cplusplus

@@ -38,7 +38,7 @@ def library_is_current() -> bool:
 PD_F32, PD_BF16, PD_F16 = 0, 1, 2
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp = C.c_void_p
 
@@ -300,6 +300,7 @@ SYMBOLS = {
     "pd_comm_unique_id": (C.c_int, [C.POINTER(CommId)]),
     "pd_comm_init": (C.c_int, [C.POINTER(CommId), C.c_int, C.c_int, C.POINTER(vp)]),
     "pd_allreduce_bucket": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
+    "pd_comm_query": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pd_comm_destroy": (C.c_int, [vp]),
     "pd_latent_sample": (C.c_int, [C.POINTER(LatentSampleArgs), vp]),
     "pd_attn_d64_bwd": (C.c_int, [C.POINTER(AttnD64BwdArgs), vp]),

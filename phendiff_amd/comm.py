@@ -53,6 +53,12 @@ class NativeComm:
         L.check(self.lib.pd_allreduce_bucket(self._comm, flat.data_ptr(), flat.numel(), int(mean), int(algo), st), "pd_allreduce_bucket")
         return flat
 
+    def query(self):
+        """(rank, world) as the communicator itself reports them (ncclCommUserRank / ncclCommCount)."""
+        r, w = C.c_int(-1), C.c_int(-1)
+        L.check(self.lib.pd_comm_query(self._comm, C.byref(r), C.byref(w)), "pd_comm_query")
+        return r.value, w.value
+
     def close(self):
         if getattr(self, "_comm", None):
             self.lib.pd_comm_destroy(self._comm)

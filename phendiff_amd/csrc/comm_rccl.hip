@@ -7,9 +7,11 @@
 //   pd_allreduce_bucket in-place fp32 sum (or mean) of one contiguous gradient bucket on the given stream; algo 0 = ncclAllReduce (RCCL picks
 //                       ring / tree), algo 1 = reduce-scatter + all-gather over equal shards (the direct form SURVEY 5.8 asks for on the
 //                       7 point-to-point xGMI links: each rank reduces 1 / world of the bucket and broadcasts it; needs count % world == 0)
+//   pd_comm_query       rank / size of the communicator as RCCL reports them
 //   pd_comm_destroy
 // The Python trainers use torch.distributed (PyTorch is plumbing here); `phendiff_amd.comm.NativeComm` is the same exchange through this ABI.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
 #include "pd_common.h"
 
@@ -25,30 +27,43 @@ struct Rccl {
   int (*ReduceScatter)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, nccl_comm, hipStream_t) = nullptr;
   int (*CommDestroy)(nccl_comm) = nullptr;
+  int (*CommCount)(const nccl_comm, int*) = nullptr;
+  int (*CommUserRank)(const nccl_comm, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
-static Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+// Loaded once (thread-safe: function-local static initialiser); when the library or one of its symbols is missing the reason is kept
+// for the error message and the handle is closed again.
+struct RcclLoad {
+  Rccl r;
+  char why[256];
+  RcclLoad() {
+    why[0] = 0;
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
       r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (r.h) break;
+      const char* e = dlerror();                       // (one call: dlerror() clears the message it returns)
+      snprintf(why, sizeof(why), "%s", e ? e : "dlopen failed");
     }
-    if (r.h) {
-      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
-      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
-      r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
-      r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(r.h, "ncclReduceScatter");
-      r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
-      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
-      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
-      if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.ReduceScatter || !r.AllGather || !r.CommDestroy) r.h = nullptr;
+    if (!r.h) return;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+    r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(r.h, "ncclReduceScatter");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.h, "ncclCommUserRank");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.ReduceScatter || !r.AllGather || !r.CommDestroy || !r.CommCount || !r.CommUserRank) {
+      snprintf(why, sizeof(why), "librccl.so lacks one of the nccl* entry points this library binds");
+      dlclose(r.h);
+      r.h = nullptr;
     }
   }
-  return r.h ? &r : nullptr;
-}
+};
+static RcclLoad& rccl_load() { static RcclLoad l; return l; }
+static Rccl* rccl() { RcclLoad& l = rccl_load(); return l.r.h ? &l.r : nullptr; }
+static const char* rccl_why() { return rccl_load().why; }
 struct Comm { nccl_comm c; int rank, world; };
 constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;
 
@@ -72,7 +87,7 @@ using namespace pd;
 extern "C" int pd_comm_unique_id(pd_comm_id* out) {
   PD_CHECK(out != nullptr, PD_ERR_ARG, "pd_comm_unique_id: null output");
   Rccl* R = rccl();
-  PD_CHECK(R != nullptr, PD_ERR_UNSUPPORTED, "pd_comm: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+  PD_CHECK(R != nullptr, PD_ERR_UNSUPPORTED, "pd_comm: librccl.so could not be loaded (%s)", rccl_why());
   static_assert(sizeof(pd_comm_id) == sizeof(nccl_uid), "id size");
   PD_RCCL(R->GetUniqueId((nccl_uid*)out), "pd_comm_unique_id");
   return PD_OK;
@@ -82,7 +97,7 @@ extern "C" int pd_comm_init(const pd_comm_id* id, int rank, int world, void** co
   PD_CHECK(id != nullptr && comm_out != nullptr, PD_ERR_ARG, "pd_comm_init: null argument");
   PD_CHECK(world >= 1 && rank >= 0 && rank < world, PD_ERR_ARG, "pd_comm_init: rank %d of %d", rank, world);
   Rccl* R = rccl();
-  PD_CHECK(R != nullptr, PD_ERR_UNSUPPORTED, "pd_comm: librccl.so could not be loaded");
+  PD_CHECK(R != nullptr, PD_ERR_UNSUPPORTED, "pd_comm: librccl.so could not be loaded (%s)", rccl_why());
   nccl_uid u;
   memcpy(&u, id, sizeof(u));
   nccl_comm c = nullptr;
@@ -97,10 +112,12 @@ extern "C" int pd_allreduce_bucket(void* comm, float* buf, size_t count, int mea
   PD_CHECK(buf != nullptr && count > 0, PD_ERR_ARG, "pd_allreduce_bucket: empty bucket");
   PD_CHECK(algo == 0 || algo == 1, PD_ERR_ARG, "pd_allreduce_bucket: algo %d (0 = all-reduce, 1 = reduce-scatter + all-gather)", algo);
   Rccl* R = rccl();
-  PD_CHECK(R != nullptr, PD_ERR_UNSUPPORTED, "pd_comm: librccl.so could not be loaded");
+  PD_CHECK(R != nullptr, PD_ERR_UNSUPPORTED, "pd_comm: librccl.so could not be loaded (%s)", rccl_why());
   Comm* cm = (Comm*)comm;
   hipStream_t st = (hipStream_t)stream;
-  if (algo == 1 && cm->world > 1 && count % (size_t)cm->world == 0) {
+  // (no `world > 1` guard: RCCL runs both collectives at one rank too, so a one-rank communicator exercises this branch and its in-place
+  // pointer arithmetic -- ADVICE r3)
+  if (algo == 1 && count % (size_t)cm->world == 0) {
     const size_t shard = count / cm->world;
     PD_RCCL(R->ReduceScatter(buf, buf + (size_t)cm->rank * shard, shard, NCCL_FLOAT32, NCCL_SUM, cm->c, st), "pd_allreduce_bucket (reduce-scatter)");
     PD_RCCL(R->AllGather(buf + (size_t)cm->rank * shard, buf, shard, NCCL_FLOAT32, cm->c, st), "pd_allreduce_bucket (all-gather)");
@@ -112,6 +129,17 @@ extern "C" int pd_allreduce_bucket(void* comm, float* buf, size_t count, int mea
     hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, st, buf, count, 1.0f / (float)cm->world);
     PD_LAUNCH_CHECK();
   }
+  return PD_OK;
+}
+
+// rank / size as the COMMUNICATOR reports them (ncclCommUserRank / ncclCommCount), not as the caller passed them or the environment says
+extern "C" int pd_comm_query(void* comm, int* rank_out, int* world_out) {
+  PD_CHECK(comm != nullptr && rank_out != nullptr && world_out != nullptr, PD_ERR_ARG, "pd_comm_query: null argument");
+  Rccl* R = rccl();
+  PD_CHECK(R != nullptr, PD_ERR_UNSUPPORTED, "pd_comm: librccl.so could not be loaded (%s)", rccl_why());
+  Comm* cm = (Comm*)comm;
+  PD_RCCL(R->CommUserRank(cm->c, rank_out), "pd_comm_query (rank)");
+  PD_RCCL(R->CommCount(cm->c, world_out), "pd_comm_query (count)");
   return PD_OK;
 }
 

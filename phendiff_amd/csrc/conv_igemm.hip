@@ -14,6 +14,7 @@
 // LDS pixel pitch = 32 ch + 16 B pad: an odd number of 16-B slots, so a wave's 32 consecutive pixels hit 16
 // distinct slots per ds_read_b128 lane group (conflict-free for TW = 32).
 #include <type_traits>
+#include <utility>
 #include <stdio.h>
 #include <stdlib.h>
 #include "pd_common.h"
@@ -33,6 +34,34 @@
 #ifndef PD_CONV_M16
 #define PD_CONV_M16 1
 #endif
+// Experiment switches (round 4): the 16x16x32 form behind a GroupNorm prologue too; the wave-priority raise of the MFMA clusters.
+#ifndef PD_CONV_M16_GN
+#define PD_CONV_M16_GN 0
+#endif
+#ifndef PD_CONV_MFMA_PRIO
+#define PD_CONV_MFMA_PRIO 1
+#endif
+// PRO (compile-time GroupNorm + SiLU prologue, branch-free staging, MFMA / vector interleave by sched_group_barrier): which launches take it
+// (0 = none, 1 = the two-tile form, 2 = the one-tile form too), its waves per SIMD (register budget), the MFMA slot at which the staging
+// work of a chunk starts, and whether the activation fragments of the next k-step are read ahead.
+#ifndef PD_CONV_PRO
+#define PD_CONV_PRO 1
+#endif
+#ifndef PD_CONV_PRO_WPS
+#define PD_CONV_PRO_WPS 3
+#endif
+#ifndef PD_CONV_PRO_START
+#define PD_CONV_PRO_START 8
+#endif
+#ifndef PD_CONV_PRO_DSR
+#define PD_CONV_PRO_DSR 1
+#endif
+#ifndef PD_CONV_PRO_M16
+#define PD_CONV_PRO_M16 0     /* 16x16x32 MFMAs in the PRO launches: 0 = none, 1 = the two-tile form, 2 = the one-tile form too */
+#endif
+#ifndef PD_CONV_PRO_PV
+#define PD_CONV_PRO_PV 24     /* non-transcendental vector instructions of one staged piece (counted in the ISA) */
+#endif
 namespace pd {
 
 
@@ -43,6 +72,30 @@ namespace pd {
 #else
 #define PD_WIDX(i) (i)
 #endif
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int... I, typename F> __device__ __forceinline__ void pd_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void pd_static_for(F&& f) { pd_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+// PRO schedule (conv_kernel): a staged piece is PRO_OPS steps (2 halves x 9 stages x 2 channel pairs, then its LDS store); their issue
+// costs in tenths of a cycle (profiles/r3_exp_variants.log), and the number of steps -- over the NIT pieces of a chunk -- that are
+// emitted by the end of MFMA slot S of NS when the staging work starts at slot PS0 and is dealt out by cost
+constexpr int PRO_OPS = 37;
+constexpr int pro_op_cost(int k) {
+  if (k >= 36) return 100;
+  const int stg = (k % 18) >> 1;
+  return (stg == 3 || stg == 4 || stg == 6 || stg == 7) ? 87 : (stg == 0 ? 60 : (stg == 8 ? 106 : 58));
+}
+constexpr int pro_ops_done(int S, int NS, int PS0, int NIT) {
+  if (S < PS0) return 0;
+  if (S >= NS - 1) return NIT * PRO_OPS;
+  long long tot = 0;
+  for (int k = 0; k < PRO_OPS; ++k) tot += pro_op_cost(k);
+  tot *= NIT;
+  const long long target = (long long)(S - PS0 + 1) * tot / (NS - PS0);
+  int done = 0;
+  long long dc = 0;
+  while (done < NIT * PRO_OPS && dc + pro_op_cost(done % PRO_OPS) <= target) { dc += pro_op_cost(done % PRO_OPS); ++done; }
+  return done;
+}
 __device__ __forceinline__ unsigned pd_lin_block() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
 #ifdef PD_STAMPS   // diagnostic build only (scripts/stamp_conv.py): phase timestamps of the first workgroups
 __device__ unsigned long long pd_conv_stamps[4096 * 16];
@@ -64,8 +117,9 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 // PLAIN (compile time): no GroupNorm / SiLU prologue -- the input gradients of every convolution, the latent-diffusion UNet's convolutions
 // (its GroupNorms are applied by pd_gn_apply), the upsamplers.  The 16 scale / shift registers and the transform are gone, which is what lets
 // the 16x16x32 MFMA form (M16 below) fit the register budgets.
-template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1, bool PLAIN = false>
-__global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2)) void conv_kernel(const ConvP p) {   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
+template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1, bool PLAIN = false, int PRO = 0>
+__global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2))) void conv_kernel(const ConvP p) {
+  static_assert(PRO == 0 || (!PLAIN && DB && KS == 3 && STRIDE == 1 && sizeof(T) == 2), "compile-time prologue: 16-bit 3x3 stride-1 double-buffered launches");   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
   static_assert(NCO == 1 || (NCO == 2 && DB && KS == 3 && STRIDE == 1), "two output tiles per workgroup: 3x3 stride-1 double-buffered variant only");
   using E = Elem<T>;
@@ -92,7 +146,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   //   B: lane (i, g) reads pixel i of its 16-pixel run, channels 8 g .. 8 g + 7 (one ds_read_b128); pixel pitch 160 B (10 slots):
   //      the 144-byte pitch is 2-way conflicted for this access, 160 is conflict-free (brute force over the ds_read_b128 lane groups);
   //   D: acq[c][f][2 ti + tj]: lane (i, g) owns pixel 16 tj + i of fragment f and channels 16 ti + 4 g .. + 3 of tile c.
-  constexpr bool M16 = PD_CONV_M16 && PLAIN && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DB && TW >= 16;
+  constexpr bool M16 = PD_CONV_M16 && (PLAIN || (PD_CONV_M16_GN && (NCO == 1 || PD_CONV_M16_GN >= 2)) || (PRO && PD_CONV_PRO_M16 >= (NCO == 2 ? 1 : 2))) && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DB && TW >= 16;
   constexpr int CHB = 32 * E::BYTES;                 // bytes of one 32-channel chunk of a pixel
   constexpr int PITCH = DB ? 2 * CHB + (M16 ? 32 : 16) : CHB + 16;
   constexpr int NIT = (NPIX * 4 + 255) / 256;
@@ -133,26 +187,30 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   const int Hc = p.upsample ? p.Hin * 2 : p.Hin;
   const int Wc = p.upsample ? p.Win * 2 : p.Win;
   int spix[NIT];   // linear source pixel index (n, sy, sx) or -1 (zero padding / no such piece)
+  constexpr int TAIL_CENTRE = 1 << 30;
+  // branch-free (round 4: the nested `if`s were 16 divergent branches = 2.2k cycles of every workgroup's prologue, s_memtime stamps)
+  // upsample 1: nearest x2 (Upsample2D);  upsample 2: zero-stuffed x2 (the stride-2 conv's input gradient is a stride-1 conv over dY
+  // with zeros between its samples: samples at the EVEN positions for a pad-1 forward);  upsample 3: at the ODD positions
+  // (Downsample2D(padding=0)'s (0,1,0,1)-padded forward)
+  const int ups = p.upsample ? 1 : 0;                     // source coordinate = conv coordinate >> ups
+  const int ph_mask = p.upsample >= 2 ? 1 : 0, ph_want = p.upsample == 3 ? 1 : 0;   // zero-stuffing: both coordinates' low bit must equal ph_want
+  const int iy_base = y0 * STRIDE - p.pad, ix_base = x0 * STRIDE - p.pad, n_base = n * p.Hin;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int pix = (tid + 256 * i) >> 2;
-    int v = -1;
-    if (pix < NPIX) {
-      const int u = pix / IN_TW, vv = pix - u * IN_TW;
-      const int iy = y0 * STRIDE - p.pad + u, ix = x0 * STRIDE - p.pad + vv;
-      // upsample 1: nearest x2 (Upsample2D);  upsample 2: zero-stuffed x2 (the stride-2 conv's input gradient is a
-      // stride-1 conv over dY with zeros between its samples: samples at the EVEN positions for a pad-1 forward,
-      // upsample 3: at the ODD positions for Downsample2D(padding=0)'s (0,1,0,1)-padded forward)
-      const bool phase_ok = p.upsample < 2 || (p.upsample == 2 ? ((iy | ix) & 1) == 0 : ((iy & ix) & 1) == 1);
-      if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && phase_ok) {
-        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-        v = (n * p.Hin + sy) * p.Win + sx;
-      }
-    }
-    spix[i] = v;
+    const int u = pix / IN_TW, vv = pix - u * IN_TW;
+    const int iy = iy_base + u, ix = ix_base + vv;
+    const bool ok = (pix < NPIX) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc)
+                    & (((iy & ph_mask) == (ph_want & ph_mask)) & ((ix & ph_mask) == (ph_want & ph_mask)));
+    int v = (n_base + (iy >> ups)) * p.Win + (ix >> ups);
+    // fused 1x1 tail: its chunks multiply the CENTRE tap only, so they need the tile's own pixels, not the halo ring around them
+    // (a third more pixels: 10 x 34 against 8 x 32) -- bit 30 marks the pixels a tail chunk loads (an index is < 2^26: the tensors
+    // are < 2 GiB at >= 64 bytes per pixel)
+    if (TAIL) v |= (((unsigned)(u - KS / 2) < (unsigned)TH) & ((unsigned)(vv - KS / 2) < (unsigned)TW)) ? TAIL_CENTRE : 0;
+    spix[i] = ok ? v : -1;
   }
-  const bool affine = !PLAIN && p.scale != nullptr;
-  const bool do_silu = !PLAIN && p.silu != 0;
+  const bool affine = PRO || (!PLAIN && p.scale != nullptr);
+  const bool do_silu = PRO || (!PLAIN && p.silu != 0);
   const int cin = p.C0 + p.C1;
 
   SR stage[NIT];
@@ -173,12 +231,13 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 #ifdef PD_ABL_X0
       const unsigned off = OOB_OFF;   // ablation: no activation traffic
 #else
-      const unsigned off = spix[i] >= 0 ? (unsigned)spix[i] * cs * E::BYTES + cbytes : OOB_OFF;
+      const bool want = TAIL ? (stage_plain ? spix[i] >= TAIL_CENTRE : spix[i] >= 0) : spix[i] >= 0;
+      const unsigned off = want ? (unsigned)(TAIL ? spix[i] & (TAIL_CENTRE - 1) : spix[i]) * cs * E::BYTES + cbytes : OOB_OFF;
 #endif
       stage[i] = src == 0 ? Stage<T>::load(rs0, off) : (src == 1 ? Stage<T>::load(rs1, off)
                  : (src == 2 ? Stage<T>::load(rt0, off) : Stage<T>::load(rt1, off)));
     }
-    if (affine && !stage_plain) {
+    if ((PRO && !stage_plain) || (!PRO && affine && !stage_plain)) {
       const int cg = chunk * 32 + sub * 8;          // channel index in the concatenated main input
       const float* ps = p.scale + (size_t)n * cin + cg;
       const float* pb = p.shift + (size_t)n * cin + cg;
@@ -191,8 +250,19 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   // Padding pixels (spix < 0) hold zeros in BOTH LDS buffers from the start of the kernel (zero_padding below) and are never
   // written again: the per-piece "if (!valid) zero the 8 transformed values" (5 vector instructions per piece, ~6 % of the
   // kernel's vector work by the round-3 instruction counters) becomes an exec-masked store.
-  auto write_piece = [&](int i, unsigned char* buf) {
+  auto write_piece = [&](int i, unsigned char* buf, bool tail_piece = false) {
     const int pix = (tid + 256 * i) >> 2;
+    if constexpr (PRO) {
+      if (TAIL && tail_piece) {          // (compile-time at every call site) a fused-tail chunk is staged as it is
+        if (pix < NPIX && spix[i] >= 0) *(u32x4*)(buf + pix * PITCH + sub * 8 * E::BYTES) = Stage<T>::raw(stage[i]);
+        return;
+      }
+      // no branch: a lane without a pixel to write (padding, past the tile) stores to the dump slot behind the tile, so that a piece is
+      // straight-line code in the same basic block as the wave's MFMAs (sched_group_barrier below places it between them)
+      const u32x4 o = Stage<T>::xform_gs(stage[i], sc, sh);
+      const bool ok = pix < NPIX && spix[i] >= 0;
+      *(u32x4*)(ok ? buf + pix * PITCH + sub * 8 * E::BYTES : lds + NPIX * PITCH) = o;
+    } else
     if (pix < NPIX && spix[i] >= 0)
       Stage<T>::template xform_store<false>(buf + pix * PITCH + sub * 8 * E::BYTES, stage[i], sc, sh, affine && !stage_plain,
                                             do_silu && !stage_plain, true);
@@ -296,14 +366,123 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 
   // one chunk of MFMAs out of `buf`; when DB, pieces of the NEXT chunk are transformed + written to `nbuf` in between
   auto mma_chunk = [&](int chunk, const unsigned char* buf, unsigned char* nbuf, auto have_next_c, auto active_c) {
-    constexpr bool HAVE_NEXT = decltype(have_next_c)::value;
+    constexpr int NEXT = (int)decltype(have_next_c)::value;       // 0: last chunk; 1: stage the next chunk; 2 (PRO): the next chunk is a fused-tail chunk (staged as it is)
+    constexpr bool HAVE_NEXT = NEXT != 0, NEXT_PLAIN = NEXT == 2;
     constexpr bool ACTIVE = decltype(active_c)::value;
     const int g0 = chunk * KSTEPS;
     Frag bc[NF];                           // activation fragments of the current k-step (3 waves per SIMD cover the LDS latency)
     int piece = 0;
 #ifndef PD_NO_IGLP
-    __builtin_amdgcn_iglp_opt(0);          // interleave the region's LDS reads / staging VALU work with the MFMAs (same-box A/B: -1 % per forward)
+    if constexpr (!PRO) __builtin_amdgcn_iglp_opt(0);          // interleave the region's LDS reads / staging VALU work with the MFMAs (same-box A/B: -1 % per forward)
 #endif
+    if constexpr (PRO && ACTIVE) {
+      // PRO: the chunk is ONE basic block whose instruction order is written out slot by slot (a slot = one MFMA = 32 matrix-pipe
+      // cycles during which the vector issue port is free for ~24) and pinned by sched_barrier(0): after every MFMA the LDS read that
+      // refills the fragment it just consumed with the NEXT k-step's (four slots ahead of its use), then this slot's share of the
+      // staging work of the next chunk.  A piece (8 channels of one pixel) is 9 steps per channel pair -- unpack, affine, scale,
+      // exp, exp, +1, rcp, rcp, multiply + pack -- walked two pairs at a time so that consecutive instructions are independent;
+      // steps are dealt to the slots from PD_CONV_PRO_START on by their issue cost (transcendentals 8.7 cycles, packed fp32 5.8,
+      // the rest ~3-5: profiles/r3_exp_variants.log).  Without this order every piece was a block of ~45 vector instructions BEHIND
+      // its three k-steps of MFMAs: an in-order wave ran them one after the other (matrix and vector pipes co-executed in 18 % of the
+      // matrix-busy cycles, r3_conv64_inst_mix.txt).
+      constexpr int NM = NCO * NF;                    // MFMAs per k-step
+      constexpr int NS = KSTEPS * NM;                 // MFMA slots per chunk
+      constexpr int PS0 = PD_CONV_PRO_START < NS - 8 ? PD_CONV_PRO_START : 0;
+      constexpr int NS16 = 2 * NS, PS16 = 2 * PS0;    // the 16x16x32 form: twice the slots of half the length
+      f32x2 py[4], pw[4];
+      u32x4 po;
+      auto piece_op = [&](auto ic, auto kc) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, k = decltype(kc)::value;
+        if constexpr (k < 36) {
+          constexpr int half = k / 18, kk = k % 18, stg = kk >> 1, j = half * 2 + (kk & 1);
+          if constexpr (stg == 0) { const uint32_t wj = Stage<T>::word(stage[i], j); float lo, hi; Pack16<T>::unpack(wj, lo, hi); pw[j].x = lo; pw[j].y = hi; }
+          else if constexpr (stg == 1) py[j] = pw[j] * (f32x2){sc[2 * j], sc[2 * j + 1]} + (f32x2){sh[2 * j], sh[2 * j + 1]};
+          else if constexpr (stg == 2) pw[j] = py[j] * (f32x2)(-1.4426950408889634f);
+          else if constexpr (stg == 3) pw[j].x = __builtin_amdgcn_exp2f(pw[j].x);
+          else if constexpr (stg == 4) pw[j].y = __builtin_amdgcn_exp2f(pw[j].y);
+          else if constexpr (stg == 5) pw[j] = pw[j] + (f32x2)(1.0f);
+          else if constexpr (stg == 6) pw[j].x = __builtin_amdgcn_rcpf(pw[j].x);
+          else if constexpr (stg == 7) pw[j].y = __builtin_amdgcn_rcpf(pw[j].y);
+          else { const f32x2 o = py[j] * pw[j]; po[j] = Pack16<T>::pack(o.x, o.y); }
+          // pin the step to its slot: the values are pure arithmetic, which instruction selection otherwise sinks to its user (the piece's LDS
+          // store) -- an empty volatile asm that "modifies" the step's result keeps it above the slot's sched_barrier
+          if constexpr (stg == 1) asm volatile("" : "+v"(py[j]));
+          else if constexpr (stg == 8) { uint32_t w = po[j]; asm volatile("" : "+v"(w)); po[j] = w; }
+          else asm volatile("" : "+v"(pw[j]));
+        } else {
+          const int pix = (tid + 256 * i) >> 2;
+          const bool ok = pix < NPIX && spix[i] >= 0;
+          *(u32x4*)(ok ? nbuf + pix * PITCH + sub * 8 * E::BYTES : lds + NPIX * PITCH) = NEXT_PLAIN ? Stage<T>::raw(stage[i]) : po;
+        }
+      };
+      // steps [lo, hi) of the chunk's staging work that slot S of NSL runs (a fused-tail chunk: only the NIT stores, spread evenly)
+      auto run_ops = [&](auto s_c, auto nsl_c, auto ps_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value, NSL = decltype(nsl_c)::value, PS = decltype(ps_c)::value;
+        if constexpr (NEXT_PLAIN) {
+          constexpr int lo = (S * NIT) / NSL, hi = ((S + 1) * NIT) / NSL;
+          pd_static_for<hi - lo>([&](auto gc) __attribute__((always_inline)) {
+            piece_op(std::integral_constant<int, lo + decltype(gc)::value>{}, std::integral_constant<int, 36>{});
+          });
+        } else if constexpr (HAVE_NEXT) {
+          constexpr int lo = S == 0 ? 0 : pro_ops_done(S - 1, NSL, PS, NIT), hi = pro_ops_done(S, NSL, PS, NIT);
+          pd_static_for<hi - lo>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = lo + decltype(gc)::value;
+            piece_op(std::integral_constant<int, g / PRO_OPS>{}, std::integral_constant<int, g % PRO_OPS>{});
+          });
+        }
+      };
+      if constexpr (!M16) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) bc[f] = E::load(buf + rbase[f]);                    // k-step 0: tap 0, first half
+        __builtin_amdgcn_sched_barrier(0);
+        pd_static_for<NS>([&](auto sc_) __attribute__((always_inline)) {
+          constexpr int S = decltype(sc_)::value, ks = S / NM, m = S % NM, f = m / NCO, c = m % NCO;
+          constexpr int tapn = (ks + 1) >> 1, sn = (ks + 1) & 1;
+          constexpr int toffn = ((tapn / KS) * IN_TW + (tapn % KS)) * PITCH + sn * 16 * E::BYTES;
+          if constexpr (m == 0) {
+  #pragma unroll
+            for (int cc = 0; cc < NCO; ++cc) aring[(ks + AD) % AR][cc] = load_w(cc, g0 + ks + AD);
+          }
+          acc[c][f] = E::mma(aring[ks % AR][c], bc[f], acc[c][f]);
+          if constexpr (c == NCO - 1 && ks + 1 < KSTEPS) bc[f] = E::load(buf + rbase[f] + toffn);
+          run_ops(sc_, std::integral_constant<int, NS>{}, std::integral_constant<int, PS0>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+  } else {
+        // 16x16x32 form: a slot is one 16-cycle MFMA; half-step hs = (tap, pixel half s) = 16 NCO / 2 MFMAs over the tap's A operands
+        // aq[tap & 1][c][ti] (the next tap's are loaded at s == 0) and the B operands bq[f][tj] of fragments 2 s, 2 s + 1 -- each
+        // bq is consumed by NCO x 2 consecutive MFMAs and then refilled with the NEXT half-step's fragment (>= 6 slots ahead of its use)
+        constexpr int FH = NF / 2;
+        constexpr int MH = NCO * FH * 4;                // MFMAs per half-step
+        static_assert(NS16 == KSTEPS * MH, "slot count");
+        Frag bq[FH][2];
+#pragma unroll
+        for (int f = 0; f < FH; ++f)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) bq[f][tj] = E::load(buf + rbase[0] + f * (RPF * IN_TW * PITCH) + tj * TJ_STEP);
+        __builtin_amdgcn_sched_barrier(0);
+        pd_static_for<NS16>([&](auto sc_) __attribute__((always_inline)) {
+          constexpr int S = decltype(sc_)::value, hs = S / MH, m = S % MH, tap = hs >> 1, s2 = hs & 1;
+          // slot order inside a half-step: (f, tj) outer -- one B operand --, (c, ti) inner
+          constexpr int f = m / (2 * NCO * 2), tj = (m / (NCO * 2)) % 2, c = (m / 2) % NCO, ti = m % 2;
+          constexpr int tapn = (hs + 1) >> 1, sn = (hs + 1) & 1;
+          constexpr int toffn = ((tapn / KS) * IN_TW + (tapn % KS)) * PITCH;
+          if constexpr (m == 0 && s2 == 0) {
+#pragma unroll
+            for (int cc = 0; cc < NCO; ++cc)
+#pragma unroll
+              for (int t2 = 0; t2 < 2; ++t2) aq[(tap + 1) & 1][cc][t2] = load_w16(cc, chunk * TAPS + tap + 1, t2);
+          }
+          acq[c][s2 * FH + f][2 * ti + tj] = E::mma_16x16x32(aq[tap & 1][c][ti], bq[f][tj], acq[c][s2 * FH + f][2 * ti + tj]);
+          if constexpr (c == NCO - 1 && ti == 1 && hs + 1 < KSTEPS)
+            bq[f][tj] = E::load(buf + rbase[0] + (sn * FH + f) * (RPF * IN_TW * PITCH) + tj * TJ_STEP + toffn);
+          run_ops(sc_, std::integral_constant<int, NS16>{}, std::integral_constant<int, PS16>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) { aq[0][c][0] = aq[1][c][0]; aq[0][c][1] = aq[1][c][1]; }      // (TAPS is odd: see the general form below)
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if constexpr (ACTIVE && M16) {
@@ -322,7 +501,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
         for (int f = 0; f < FH; ++f)
 #pragma unroll
           for (int tj = 0; tj < 2; ++tj) bq[f][tj] = E::load(buf + rbase[0] + (s * FH + f) * (RPF * IN_TW * PITCH) + tj * TJ_STEP + toff);
-        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + PD_CONV_MFMA_PRIO);
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
 #pragma unroll
@@ -342,7 +521,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
 #pragma unroll
           for (int f = 0; f < NF; ++f) bc[f] = E::load(buf + rbase[f] + toff);
         }
-        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);   // keeps the 4-MFMA cluster together and ahead of the other wave's VALU work (+5 %)
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + PD_CONV_MFMA_PRIO);   // keeps the 4-MFMA cluster together and ahead of the other wave's VALU work (+5 %)
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
 #pragma unroll
@@ -381,7 +560,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
         for (int f = 0; f < FH; ++f)
 #pragma unroll
           for (int tj = 0; tj < 2; ++tj) bq[f][tj] = E::load(buf + rbase[0] + (s * FH + f) * (RPF * IN_TW * PITCH) + tj * TJ_STEP + CENTER);
-        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);
+        __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + PD_CONV_MFMA_PRIO);
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
 #pragma unroll
@@ -401,7 +580,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
       Frag b0[NF], b1[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) { b0[f] = E::load(buf + rbase[f] + CENTER); b1[f] = E::load(buf + rbase[f] + CENTER + 16 * E::BYTES); }
-      __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + 1);
+      __builtin_amdgcn_s_setprio(PD_CONV_PRIO_BASE + PD_CONV_MFMA_PRIO);
 #pragma unroll
       for (int c = 0; c < NCO; ++c) {
 #pragma unroll
@@ -413,7 +592,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
     }
     if constexpr (HAVE_NEXT) {
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) write_piece(i, nbuf);
+      for (int i = 0; i < NIT; ++i) write_piece(i, nbuf, true);
     }
   };
   // chunk driver: the last chunk is peeled (HAVE_NEXT = false) so the accumulators flow through two call sites
@@ -515,16 +694,24 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
     __syncthreads();
     PD_STAMP(2);
     int chunk = 0;
-    const int main_loop_end = TAIL ? p.n_main : p.nchunks - 1;   // with a tail every main chunk has a successor
+    // with a tail every main chunk has a successor; PRO: the last main chunk (which stages the first tail chunk as it is) is peeled below
+    const int main_loop_end = TAIL ? (PRO ? p.n_main - 1 : p.n_main) : p.nchunks - 1;
     for (; chunk < main_loop_end; ++chunk) {
       unsigned char* buf = lds + (chunk & 1) * LDS_TILE;
       unsigned char* nbuf = lds + ((chunk + 1) & 1) * LDS_TILE;
-      if (wave_active) mma_chunk(chunk, buf, nbuf, true_type{}, true_type{});
+      if constexpr (PRO) mma_chunk(chunk, buf, nbuf, true_type{}, true_type{});      // (PRO launches have no idle wave: Cout_pad % 64 == 0)
+      else if (wave_active) mma_chunk(chunk, buf, nbuf, true_type{}, true_type{});
       else mma_chunk(chunk, buf, nbuf, true_type{}, false_type{});
       if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
       if (chunk == 0) PD_STAMP(3);
       __syncthreads();
       if (chunk == 0) PD_STAMP(4);
+    }
+    if constexpr (TAIL && PRO) {
+      mma_chunk(chunk, lds + (chunk & 1) * LDS_TILE, lds + ((chunk + 1) & 1) * LDS_TILE, std::integral_constant<int, 2>{}, true_type{});
+      if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+      __syncthreads();
+      ++chunk;
     }
     if constexpr (TAIL) {
       for (; chunk + 1 < p.nchunks; ++chunk) {
@@ -731,7 +918,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (((KS == 1 || (KS == 3 && STRID
   PD_STAMP(6);
 }
 
-template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false, int NCO = 1, bool PLAIN = false>
+template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false, int NCO = 1, bool PLAIN = false, int PRO = 0>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int IN_TH = (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
@@ -739,14 +926,14 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   // double-buffer when two tiles fit comfortably -- and leave room for a second workgroup: the stride-2 halo tile (9 x 65 pixels)
   // double-buffered is 84 KB = ONE workgroup (4 waves) per CU; single-buffered 47 KB admits two, which overlap each other
   constexpr bool DB = 2 * LDS_TILE <= 100 * 1024 && !(STRIDE == 2 && PD_S2_SINGLE);
-  constexpr bool M16 = PD_CONV_M16 && PLAIN && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && TW >= 16;        // (conv_kernel: 160-byte pixels)
+  constexpr bool M16 = PD_CONV_M16 && (PLAIN || (PD_CONV_M16_GN && (NCO == 1 || PD_CONV_M16_GN >= 2)) || (PRO && PD_CONV_PRO_M16 >= (NCO == 2 ? 1 : 2))) && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && TW >= 16;        // (conv_kernel: 160-byte pixels)
   constexpr int LDS_DB = ((IN_TH * IN_TW * (2 * 32 * Elem<T>::BYTES + (M16 ? 32 : 16)) + 15) / 16) * 16;   // interleaved buffers, one shared pad
   constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 256 * 64;   // output tile + stats scratch [256][2*EPC] fp32
-  constexpr int LDS_MAIN = DB ? LDS_DB : LDS_TILE;
+  constexpr int LDS_MAIN = (DB ? LDS_DB : LDS_TILE) + (PRO ? 16 : 0);          // PRO: + the dump slot behind the tile
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
   static_assert(NCO == 1 || DB, "NCO = 2 is a double-buffered variant");
-  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO, PLAIN>;
+  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO, PLAIN, PRO>;
   if (LDS_BYTES > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -809,6 +996,13 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
       static const bool plain_off = getenv("PD_CONV_PLAIN") && atoi(getenv("PD_CONV_PLAIN")) == 0;      // diagnostic: same-box A/B
       const bool plain = !plain_off && p.scale == nullptr && !p.silu && !p.im2col3 && w >= 16;
       // (the two-tile form keeps the 32x32x16 MFMAs: its 16x16x32 form needs 32 registers of A operands and spills at 256)
+      // GroupNorm + SiLU prologue known at compile time (PRO): branch-free staging interleaved with the MFMAs.  PD_CONV_PRO=0 / 1 / 2: diagnostic override (none / the two-tile form / the one-tile form too)
+      static const int pro_lvl = getenv("PD_CONV_PRO") ? atoi(getenv("PD_CONV_PRO")) : PD_CONV_PRO;
+      const bool gs = p.scale != nullptr && p.silu != 0 && !p.im2col3 && w >= 32 && p.Cout_pad % 64 == 0 && p.out_mode != PD_OUT_NCHW_F32;
+      if (nco2 && gs && pro_lvl >= 1)
+        return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 2, false, 1>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 2, false, 1>(p, st);
+      if (!nco2 && gs && pro_lvl >= 2)
+        return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 1, false, 1>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 1, false, 1>(p, st);
       if (nco2) return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 2>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 2>(p, st);
       if (plain) {
         if (p.n_tail > 0) return w >= 32 ? launch_conv<T, 3, 1, 8, 32, true, 1, true>(p, st) : launch_conv<T, 3, 1, 16, 16, true, 1, true>(p, st);

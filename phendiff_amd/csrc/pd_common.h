@@ -64,6 +64,10 @@ template <> struct Pack16<half_t> {
     return __builtin_bit_cast(uint32_t, v);
   }
 };
+template <> struct Pack16<float> {     // (lets code shared with the fp32 engine compile; never called)
+  static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) { lo = hi = __uint_as_float(w); }
+  static __device__ __forceinline__ uint32_t pack(float lo, float) { return __float_as_uint(lo); }
+};
 __device__ __forceinline__ float h2f(half_t v) { return (float)__builtin_bit_cast(_Float16, v.bits); }
 __device__ __forceinline__ half_t f2h(float f) { half_t h; h.bits = __builtin_bit_cast(unsigned short, (_Float16)f); return h; }
 

@@ -14,8 +14,48 @@ constexpr unsigned OOB_OFF = 0xC0000000u;   // > any tensor we accept (< 2 GiB):
 // primary template: the 16-bit element types (bf16, fp16); fp32 is the specialisation below
 template <typename T> struct Stage {
   struct R { u32x4 v; };
+  static __device__ __forceinline__ uint32_t word(const R& r, int j) { return r.v[j]; }      // channel pair j of the piece
+  static __device__ __forceinline__ u32x4 raw(const R& r) { return r.v; }
   static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
     R r; r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); return r;
+  }
+  // silu(x * sc + sh) of one 8-channel piece, unconditionally: no branch, no store (conv_kernel's compile-time prologue form calls it directly).
+  // fp16 engine: the GroupNorm affine in fp32 straight from the packed halves, y kept as a packed fp16 pair (v_fma_mixlo / mixhi_f16:
+  // unpack and re-pack are free); the sigmoid's exponent argument, the exponential and the reciprocal in fp32 (v_fma_mix_f32 reads
+  // the fp16 halves directly); y * sigmoid back to packed fp16 by v_fma_mixlo / mixhi_f16.  A first version ran the whole SiLU on
+  // the packed halves (v_pk_mul_f16, v_exp_f16, v_rcp_f16): same instruction time (the 16-bit transcendentals issue at the fp32
+  // rate and need a v_pack_b32_f16 per pair) but the fp16 exponent argument raised the UNet's error from 1.5e-3 to 2.0e-3.
+  static __device__ __forceinline__ u32x4 xform_gs(const R& in, const float (&sc)[8], const float (&sh)[8]) {
+    u32x4 o;
+    if constexpr (std::is_same<T, half_t>::value) {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t wj = in.v[j];          // (a bit_cast straight from the vector ELEMENT reads element 0 for every j: hipcc 7.2)
+        const h2 x = __builtin_bit_cast(h2, wj);
+        h2 y;
+        y.x = (_Float16)__builtin_fmaf((float)x.x, sc[2 * j], sh[2 * j]);
+        y.y = (_Float16)__builtin_fmaf((float)x.y, sc[2 * j + 1], sh[2 * j + 1]);
+        const float e0 = __builtin_amdgcn_exp2f((float)y.x * -1.4426950408889634f), e1 = __builtin_amdgcn_exp2f((float)y.y * -1.4426950408889634f);
+        const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
+        h2 o2;
+        o2.x = (_Float16)((float)y.x * r0);
+        o2.y = (_Float16)((float)y.y * r1);
+        o[j] = __builtin_bit_cast(uint32_t, o2);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 x;                                     // packed fp32 math: one VALU slot per channel pair
+        float xl, xh;
+        const uint32_t wj = in.v[j];
+        Pack16<T>::unpack(wj, xl, xh);
+        x.x = xl; x.y = xh;
+        x = silu_fast2(x * (f32x2){sc[2 * j], sc[2 * j + 1]} + (f32x2){sh[2 * j], sh[2 * j + 1]});
+        o[j] = Pack16<T>::pack(x.x, x.y);
+      }
+    }
+    return o;
   }
   // y = silu?(x*sc + sh) on 8 packed 16-bit values, zeroed when !valid.  `affine` / `silu` are kernel-uniform: the two common
   // forms (GroupNorm + SiLU; plain copy) are whole separate paths -- written as per-element `if`s the compiler turned both flags
@@ -24,43 +64,8 @@ template <typename T> struct Stage {
   static __device__ __forceinline__ void xform_store(unsigned char* dst, const R& in, const float (&sc)[8], const float (&sh)[8],
                                                      bool affine, bool silu, bool valid) {
     u32x4 o = in.v;
-    if constexpr (std::is_same<T, half_t>::value) {
-      if (affine && silu) {
-        // fp16 engine: the GroupNorm affine in fp32 straight from the packed halves, y kept as a packed fp16 pair (v_fma_mixlo / mixhi_f16:
-        // unpack and re-pack are free); the sigmoid's exponent argument, the exponential and the reciprocal in fp32 (v_fma_mix_f32 reads
-        // the fp16 halves directly); y * sigmoid back to packed fp16 by v_fma_mixlo / mixhi_f16.  A first version ran the whole SiLU on
-        // the packed halves (v_pk_mul_f16, v_exp_f16, v_rcp_f16): same instruction time (the 16-bit transcendentals issue at the fp32
-        // rate and need a v_pack_b32_f16 per pair) but the fp16 exponent argument raised the UNet's error from 1.5e-3 to 2.0e-3.
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t wj = in.v[j];          // (a bit_cast straight from the vector ELEMENT reads element 0 for every j: hipcc 7.2)
-          const h2 x = __builtin_bit_cast(h2, wj);
-          h2 y;
-          y.x = (_Float16)__builtin_fmaf((float)x.x, sc[2 * j], sh[2 * j]);
-          y.y = (_Float16)__builtin_fmaf((float)x.y, sc[2 * j + 1], sh[2 * j + 1]);
-          const float e0 = __builtin_amdgcn_exp2f((float)y.x * -1.4426950408889634f), e1 = __builtin_amdgcn_exp2f((float)y.y * -1.4426950408889634f);
-          const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
-          h2 o2;
-          o2.x = (_Float16)((float)y.x * r0);
-          o2.y = (_Float16)((float)y.y * r1);
-          o[j] = __builtin_bit_cast(uint32_t, o2);
-        }
-        if (ZERO && !valid) o = (u32x4)(0u);
-        *(u32x4*)dst = o;
-        return;
-      }
-    }
     if (affine && silu) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x2 x;                                     // packed fp32 math: one VALU slot per channel pair
-        float xl, xh;
-        Pack16<T>::unpack(in.v[j], xl, xh);
-        x.x = xl; x.y = xh;
-        x = silu_fast2(x * (f32x2){sc[2 * j], sc[2 * j + 1]} + (f32x2){sh[2 * j], sh[2 * j + 1]});
-        o[j] = Pack16<T>::pack(x.x, x.y);
-      }
+      o = xform_gs(in, sc, sh);
       if (ZERO && !valid) o = (u32x4)(0u);
     } else if (affine || silu) {
 #pragma unroll
@@ -80,6 +85,8 @@ template <typename T> struct Stage {
 };
 template <> struct Stage<float> {
   struct R { u32x4 a, b; };
+  static __device__ __forceinline__ uint32_t word(const R& r, int j) { return r.a[j]; }      // (16-bit engines only; never called)
+  static __device__ __forceinline__ u32x4 raw(const R& r) { return r.a; }
   static __device__ __forceinline__ R load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
     R r; r.a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); r.b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
     return r;

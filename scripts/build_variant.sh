@@ -1,4 +1,4 @@
-# build conv_igemm.hip with extra flags and link with the tree's other objects into build_ab/$1.so
+# build conv_igemm.hip with extra flags and link with the tree's other objects into build_ab/$1.so (the tree's objects must be current: build.sh)
 set -e
 NAME=$1; shift
 cd /root/repo/phendiff_amd/csrc
