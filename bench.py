@@ -754,17 +754,23 @@ def main():
         else:
             ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         # HBM bytes / pipe occupancy per launch of that kernel come from committed rocprofv3 --pmc passes (counters cannot be read
-        # from inside the process): profiles/r3_hbm_traffic.json, r3_mfma_busy.json, written by scripts/collect_profiles.sh keyed
+        # from inside the process): profiles/r4_hbm_traffic.json, r4_mfma_busy.json (r3_* as fallback), written by scripts/collect_profiles.sh keyed
         # by plan kind.  They are only quoted for the workload they were measured on AND while the library sources are the ones
         # they were measured with (sources_sha256); otherwise traffic stays null and the line says why.
         traffic, traffic_src, pipes, pmc_note = None, None, {}, None
         from phendiff_amd._lib import source_hash
         same_workload = B == 32 and args.dtype == "bf16" and size == 256 and args.model == "super_small"
-        for fname, field in (("r3_hbm_traffic.json", "traffic"), ("r3_mfma_busy.json", "pipes")):
-            try:
-                j = json.load(open(os.path.join(ROOT, "profiles", fname)))
-            except (OSError, ValueError):
-                pmc_note = f"profiles/{fname} missing"
+        for stem, field in (("hbm_traffic.json", "traffic"), ("mfma_busy.json", "pipes")):
+            j = None
+            for rnd in ("r4", "r3"):          # the newest collection whose file exists (the source hash decides whether it is quoted)
+                fname = f"{rnd}_{stem}"
+                try:
+                    j = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                    break
+                except (OSError, ValueError):
+                    continue
+            if j is None:
+                pmc_note = f"profiles/r4_{stem} missing"
                 continue
             if j.get("sources_sha256") != source_hash():
                 pmc_note = f"profiles/{fname} was measured on other kernel sources (re-run scripts/collect_profiles.sh head)"
@@ -799,6 +805,12 @@ def main():
                                              "clock_source": "profiles/r3_clock.json"})
             except (OSError, ValueError, KeyError):
                 pass
+        if kind == "attn_d8":
+            # the roofline that BINDS this kernel leads -- the shared VALU / transcendental issue port
+            # (16 v_exp_f32 per 32x32 tile) -- and the MFMA figure, which does not bind, is carried second
+            ib = extra["issue_bound"]
+            extra.update({"mfma_frac": round(ach / peak, 4), "mfma_achieved_tflops": round(ach, 2), "mfma_peak_tflops": peak})
+            bound, ach, peak, unit = "valu_transcendental_issue", ib["achieved_Texp_per_s"], ib["peak_Texp_per_s"], "Texp/s"
         res["roofline"] = {**extra, **pipes, "kernel": kind, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
@@ -822,9 +834,8 @@ def main():
             del_runner = P.DDIBGraph(pipe, batch_size=Bx, num_inference_steps=S)
             xs, ls = synth_batch(Bx, size, 77)
             xs, ls = xs.to(dev), ls.to(dev)
-            if Bx <= unet.max_batch(size, size):     # (a sliced batch replays the already warm B / 2 graph: no separate warm-up)
-                del_runner.run(xs, ls, 1 - ls)
-            torch.cuda.synchronize(dev)
+            del_runner.run(xs, ls, 1 - ls)           # untimed first replay of EVERY point (graph upload, first touch): a sliced batch's
+            torch.cuda.synchronize(dev)              # sub-runner is a freshly captured graph too
             t0 = time.perf_counter()
             del_runner.run(xs, ls, 1 - ls)
             torch.cuda.synchronize(dev)

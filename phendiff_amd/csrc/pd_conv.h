@@ -1,5 +1,4 @@
-// Launch parameters of the implicit-GEMM convolution kernel (conv_igemm.hip; also used by the shelved persistent variant under
-// scripts/experiments/).
+// Launch parameters of the implicit-GEMM convolution kernel (conv_igemm.hip).
 #pragma once
 #include "pd_common.h"
 
