@@ -29,8 +29,7 @@ extern "C" {
 
 /* Bumped whenever an args struct grows or an entry point is added (a caller built against an older header passes shorter
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
- * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query,
- * pd_adamw_ema_args.frozen). */
+ * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query). */
 #define PD_ABI_VERSION 4
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .packing import pack_conv_weight
+from .training import mark_requires_grad_calls
 from .unet import UNet2DOutput, UNetPlan, _Block, _DT, _Op, _Resnet, _Sampler, _TimestepEmbedding
 
 SD21_UNET_CONFIG = dict(
@@ -78,6 +79,7 @@ class _Transformer2D(nn.Module):
         self.proj_out = nn.Linear(inner, in_channels)
 
 
+@mark_requires_grad_calls
 class CustomEmbedding(nn.Module):
     """``src/custom_embedding/custom_embedding.py``: ``inner_module = nn.Embedding(num_classes, class_embedding_dim)``."""
 
@@ -99,6 +101,7 @@ def class_emb_to_encoder_hidden_states(class_emb: torch.Tensor, seq_len: int = 7
 _SD_DEFAULTS = dict(SD21_UNET_CONFIG)
 
 
+@mark_requires_grad_calls
 class SDUNet2DConditionModel(nn.Module):
     """Drop-in for diffusers ``UNet2DConditionModel`` in the SD-2.1 configuration (``use_linear_projection=True``, one
     transformer layer per block, head_dim 64).  ``compute_dtype``: "bf16" (fast) or "f32" (exact-fp32 MFMA, parity mode)."""
@@ -169,7 +172,7 @@ class SDUNet2DConditionModel(nn.Module):
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
         self._plans, self._weights = {}, None
-        self.requires_grad_(False)
+        nn.Module.requires_grad_(self, False)
 
     @classmethod
     def from_config(cls, config, compute_dtype="bf16", **overrides):

@@ -97,10 +97,10 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
     ``EMB_NAME`` -> the ``CustomEmbedding`` table (optional).  ``backward`` ACCUMULATES into ``grads``."""
 
     def __init__(self, m: SDUNet2DConditionModel, w: _SDPackedWeights, tw: SDTrainWeights, B, H, W, tokens, device,
-                 params: Optional[Dict[str, torch.Tensor]] = None, grads: Optional[Dict[str, torch.Tensor]] = None):
+                 params: Optional[Dict[str, torch.Tensor]] = None, grads: Optional[Dict[str, torch.Tensor]] = None, frozen=()):
         self.train = True
         SDUNetPlan.__init__(self, m, w, B, H, W, tokens, device)
-        self._init_train(tw, params, grads, False)
+        self._init_train(tw, params, grads, False, frozen)
 
     # ---- layout checks -----------------------------------------------------------------------------------------------
     def _check_layout(self):
@@ -149,7 +149,7 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         self.bufs.append(self._dehs[0])
         self._token_grad_args = None
         super()._build_backward()
-        if self.param_grads and EMB_NAME in self.grads:
+        if self._want_ehs_grad():
             dehs, dt = self._dehs[0], self.grads[EMB_NAME]
             a = L.TokenEmbeddingGradArgs(dtype=self.code, rows=self.B, dim=dt.shape[1], num_classes=dt.shape[0],
                                          row_stride=self.tokens * dt.shape[1], labels=None, d=dehs.data_ptr(),
@@ -175,11 +175,11 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         rows = B * h * w
         dx = self._tmp((B, h, w, ch), tag)
         partial = None
-        if self.param_grads:
+        dgam, dbet = self._G2(pname + ".weight", pname + ".bias")
+        if dgam is not None:
             partial = self._tmp((self.lib.pd_layernorm_bwd_blocks(rows) * 2 * ch,), "lnpart", torch.float32)
         a = L.LayerNormBwdArgs(dtype=self.code, rows=rows, C=ch, eps=eps, x=x.data_ptr(), dy=dy.data_ptr(), gamma=gamma.data_ptr(),
-                               res=L.ptr(res), dx=dx.data_ptr(), dgamma=L.ptr(self._G(pname + ".weight")),
-                               dbeta=L.ptr(self._G(pname + ".bias")), partial=L.ptr(partial))
+                               res=L.ptr(res), dx=dx.data_ptr(), dgamma=L.ptr(dgam), dbeta=L.ptr(dbet), partial=L.ptr(partial))
         self._b(self.lib.pd_layernorm_bwd, a, "layernorm_bwd", 0.0, (3 + (res is not None)) * x.numel() * self._esz())
         return dx
 
@@ -248,7 +248,7 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         self._gn_bwd(rec.gn, dz, 0, res=dout, wname=n + ".norm")
 
     def _want_ehs_grad(self):
-        return self.param_grads and EMB_NAME in self.grads
+        return self.param_grads and EMB_NAME in self.grads and EMB_NAME not in self.frozen
 
 
 class _SDRepacker:
@@ -349,17 +349,31 @@ class SDUNetTrainer(UNetTrainer):
     + EMA -> re-pack.  Call ``step(noisy_latents, timesteps, clean_latents, noise, class_labels, unconditional=False)``."""
 
     def __init__(self, model: SDUNet2DConditionModel, class_embedding: CustomEmbedding, scheduler, lr: float, *, device=None,
-                 train_class_embedding: bool = True, use_ema: bool = True, max_grad_norm: Optional[float] = 1.0, group=None, **adamw):
-        from .training import DiffusionLoss, FlatAdamWEMA, broadcast_from_rank0_
+                 train_class_embedding: bool = True, use_ema: bool = True, max_grad_norm: Optional[float] = 1.0, group=None,
+                 trainable=None, **adamw):
+        """``trainable``: as for :class:`UNetTrainer` (names carry ``EMB_NAME`` for the class table); default: the ``requires_grad``
+        flags of the UNet's parameters decide for the UNet (``components_to_train`` / ``--attention_fine_tuning``, train.py:189-220),
+        ``train_class_embedding`` and the table's own flag for the ``CustomEmbedding``."""
+        from .training import DiffusionLoss, FlatAdamWEMA, broadcast_from_rank0_, resolve_trainable
         self.model, self.class_embedding, self.scheduler = model, class_embedding, scheduler
         dev = device or model.device
         if torch.device(dev).type != "cuda":
             raise L.PhenDiffHipError("phendiff_amd trains on MI355X only (no CPU fallback): move the model to 'cuda'")
         order = sd_training_param_order(model)
+        if trainable is None:
+            flags = resolve_trainable(order, model)
+            if train_class_embedding:
+                flags = flags + resolve_trainable([(EMB_NAME, class_embedding.inner_module.weight)], class_embedding)
         if train_class_embedding:
             order = order + [(EMB_NAME, class_embedding.inner_module.weight)]
+        if trainable is not None:
+            flags = resolve_trainable(order, None, trainable)
+        if not any(flags):
+            raise ValueError("SDUNetTrainer: no trainable parameter (every parameter is frozen)")
+        self.frozen = frozenset(n for (n, _), f in zip(order, flags) if not f)
         self.opt = FlatAdamWEMA([p for _, p in order], lr, use_ema=use_ema, max_grad_norm=max_grad_norm, **adamw)
-        if train_class_embedding:
+        self.opt.set_trainable(flags)
+        if train_class_embedding and flags[-1]:
             self.opt.set_tail(class_embedding.inner_module.weight.numel(), (EMB_NAME,))
         # DDP's wrap-time broadcast (train.py:311-326): rank 0's parameters everywhere; the EMA shadow starts from them
         broadcast_from_rank0_(self.opt.flat, group)
@@ -398,7 +412,7 @@ class SDUNetTrainer(UNetTrainer):
 
     def _make_plan(self, key):
         m = self.model
-        return SDUNetTrainPlan(m, m._weights, self._tw, *key, self.device, self.params, self.grads)
+        return SDUNetTrainPlan(m, m._weights, self._tw, *key, self.device, self.params, self.grads, frozen=self.frozen)
 
     def plan_for(self, B, H, W, tokens=77):
         self._bind_weights()

@@ -68,6 +68,48 @@ def sample_training_inputs(clean_images: torch.Tensor, scheduler, cpu_generator:
     return noise, timesteps, scheduler.add_noise(clean_images, noise, timesteps)
 
 
+# ---- which parameters train (train.py:189-220) -----------------------------------------------------------------------
+def mark_requires_grad_calls(cls):
+    """Class decorator for the engine's model classes: remember that ``requires_grad_`` was CALLED on the model (the reference
+    freezes components with ``pipeline.unet.requires_grad_(False)`` and re-enables sub-modules with
+    ``module.attentions.requires_grad_(True)``, train.py:189-220).  The engine's parameters are built with ``requires_grad=False``
+    (there is no autograd graph; gradients come from the HIP backward plan), so "all False" alone cannot tell a freshly built model
+    -- everything trains, as with diffusers' default of True -- from one the caller froze."""
+    orig = cls.requires_grad_
+
+    def requires_grad_(self, requires_grad: bool = True):
+        self._requires_grad_explicit = True
+        return orig(self, requires_grad)
+
+    cls.requires_grad_ = requires_grad_
+    return cls
+
+
+def resolve_trainable(named_params, module=None, trainable=None) -> List[bool]:
+    """One flag per (name, parameter) pair of a trainer's flat buffers -- what ``torch.optim.AdamW`` would update in the reference:
+    every parameter whose ``.grad`` is not None after ``accelerator.backward`` = every parameter with ``requires_grad``.
+
+    ``trainable``: an explicit choice (iterable of names, or ``f(name, parameter) -> bool``).  Otherwise the parameters'
+    ``requires_grad`` flags decide: if ANY is set, exactly those train (``--attention_fine_tuning``: ``unet.requires_grad_(False)``
+    then ``module.attentions.requires_grad_(True)``); if none is set and ``requires_grad_`` was never called on ``module``, all of
+    them train (a freshly built engine model); if it was called (the caller froze the whole component), none does."""
+    named_params = list(named_params)
+    if trainable is not None:
+        if callable(trainable):
+            return [bool(trainable(n, p)) for n, p in named_params]
+        names = set(trainable)
+        unknown = names - {n for n, _ in named_params}
+        if unknown:
+            raise ValueError(f"trainable: unknown parameter names {sorted(unknown)[:5]}")
+        return [n in names for n, _ in named_params]
+    flags = [bool(p.requires_grad) for _, p in named_params]
+    if any(flags):
+        return flags
+    if module is not None and getattr(module, "_requires_grad_explicit", False):
+        return flags
+    return [True] * len(flags)
+
+
 # ---- device-side wrappers ------------------------------------------------------------------------------------------
 class DiffusionLoss:
     """``loss, dloss/dout = DiffusionLoss(scheduler)(model_out, clean, noise, timesteps)`` (utils_training.py:415-433)."""
@@ -130,6 +172,7 @@ class FlatAdamWEMA:
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.ema_kwargs = ema_kwargs or {}
         self.t = 0
+        self.runs = None            # [(offset, numel, trainable)] when some parameters are frozen (see set_trainable), else None
         self.tail = None            # (offset, numel): a trailing segment with its own AdamW step count (see set_tail)
         self.tail_names = ()
         self.t_tail = 0
@@ -144,6 +187,36 @@ class FlatAdamWEMA:
         self.tail = (self.flat.numel() - numel, numel)
         self.tail_names = tuple(names)        # state_dict names of the tail parameters (checkpoints record their own step count)
 
+    def set_trainable(self, flags):
+        """``flags[i]``: parameter ``i`` trains.  Frozen parameters get what ``torch.optim.AdamW`` gives a parameter whose ``.grad`` is
+        None (train.py:189-220 freezes with ``requires_grad_(False)``): no decay, no moment update, no step; their gradient segment is
+        zeroed before the global norm, so they do not enter ``clip_grad_norm_`` either (a launch that writes several parameters'
+        gradients at once -- the fused q/k/v projection, the stacked ``time_emb_proj`` -- may have written them); the EMA shadow of
+        a frozen parameter is the parameter itself (diffusers ``EMAModel.step`` copies it).  Adjacent parameters of equal status
+        are one run = one ``pd_adamw_ema`` launch."""
+        flags = [bool(f) for f in flags]
+        if len(flags) != len(self.params):
+            raise ValueError("set_trainable: one flag per parameter")
+        self.trainable = flags
+        if all(flags):
+            self.runs = None
+            return
+        runs, off = [], 0
+        for p, f in zip(self.params, flags):
+            k = p.numel()
+            if runs and runs[-1][2] == f:
+                runs[-1][1] += k
+            else:
+                runs.append([off, k, f])
+            off += k
+        self.runs = [tuple(r) for r in runs]
+
+    def trainable_ranges(self):
+        """[(offset, numel)] of the flat buffers' trainable runs (the whole buffer when nothing is frozen)."""
+        if self.runs is None:
+            return [(0, self.flat.numel())]
+        return [(o, k) for o, k, f in self.runs if f]
+
     def step(self, lr: Optional[float] = None, zero_grad: bool = True, tail_active: bool = True):
         """clip_grad_norm_ -> optimizer.step -> zero_grad -> EMA.step (utils_training.py:438-454, 553-556). No host sync:
         the gradient norm stays on the device (``self.grad_norm``)."""
@@ -152,6 +225,10 @@ class FlatAdamWEMA:
         self.t += 1
         lr = self.lr if lr is None else lr
         b1, b2 = self.betas
+        if self.runs is not None:
+            for off, k, f in self.runs:
+                if not f:
+                    self.grad[off:off + k].zero_()
         if self.max_grad_norm is not None:
             L.check(lib.pd_grad_norm(self.grad.data_ptr(), self.grad.numel(), self.partial.data_ptr(), float(self.max_grad_norm),
                                      self.grad_norm.data_ptr(), self.clip_coef.data_ptr(), st), "pd_grad_norm")
@@ -167,11 +244,19 @@ class FlatAdamWEMA:
                                ema=(self.ema.data_ptr() + 4 * off) if self.ema is not None else None, ema_only=ema_only)
             L.check(lib.pd_adamw_ema(C.byref(a), st), "pd_adamw_ema")
 
+        body_end = self.flat.numel() if self.tail is None else self.tail[0]
+        if self.runs is None:
+            launch(0, body_end, self.t)
+        else:
+            for off, k, f in self.runs:
+                k = min(off + k, body_end) - off         # (the tail segment, when it trains, is stepped below with its own count)
+                if f and k > 0:
+                    launch(off, k, self.t)
         if self.tail is None:
-            launch(0, self.flat.numel(), self.t)
             return
         off, n = self.tail
-        launch(0, off, self.t)
+        if self.runs is not None and not self.trainable[-1]:
+            return                                        # a frozen tail parameter: nothing to do
         if tail_active:
             self.t_tail += 1
             launch(off, n, self.t_tail)

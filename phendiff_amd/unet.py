@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .packing import pack_conv_weight
+from .training import mark_requires_grad_calls
 
 # compute_dtype -> (pd_dtype, storage dtype).  "fp16": the reference's `--mixed_precision fp16` (args_parser.py:381-390; img2img_comparison.py:57):
 # fp16 storage + MFMA, fp32 accumulate / statistics / softmax -- an inference mode here (training keeps bf16's fp32 range, no GradScaler)
@@ -118,6 +119,7 @@ _CONFIG_DEFAULTS = dict(
     add_attention=True, class_embed_type=None, num_class_embeds=None)
 
 
+@mark_requires_grad_calls
 class CustomCondUNet2DModel(nn.Module):
     """Drop-in for ``src.cond_unet_2d.CustomCondUNet2DModel`` (constructor kwargs = its ``register_to_config``
     keys, ``cond_unet_2d.py:74-107``).  ``compute_dtype``: ``"bf16"`` (bf16 activations/weights on MFMA, fp32
@@ -199,7 +201,7 @@ class CustomCondUNet2DModel(nn.Module):
         self._plans = {}
         self._weights = None
         self._grad_weights = None
-        self.requires_grad_(False)  # no autograd graph: gradients come from the HIP backward plan (phendiff_amd.unet_train)
+        nn.Module.requires_grad_(self, False)  # no autograd graph: gradients come from the HIP backward plan (phendiff_amd.unet_train)
 
     # ---- diffusers-like conveniences ------------------------------------------------------------
     @classmethod

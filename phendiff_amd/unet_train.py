@@ -113,17 +113,22 @@ class UNetTrainPlan(UNetPlan):
 
     def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, tw: TrainWeights, B, H, W, device,
                  params: Optional[Dict[str, torch.Tensor]] = None, grads: Optional[Dict[str, torch.Tensor]] = None,
-                 input_grad: bool = False):
+                 input_grad: bool = False, frozen=()):
         """``grads`` = None: no parameter gradients (weight / bias / GroupNorm / embedding launches are not emitted);
-        ``input_grad``: also produce d loss / d sample (fp32 NCHW, ``self.dsample``) -- the gradient-guided transfer."""
+        ``input_grad``: also produce d loss / d sample (fp32 NCHW, ``self.dsample``) -- the gradient-guided transfer;
+        ``frozen``: names of parameters that do not train (train.py:189-220): their gradient launches are not emitted."""
         self.train = True
         super().__init__(m, w, B, H, W, device)
-        self._init_train(tw, params, grads, input_grad)
+        self._init_train(tw, params, grads, input_grad, frozen)
 
-    def _init_train(self, tw, params, grads, input_grad):
+    def _init_train(self, tw, params, grads, input_grad, frozen=()):
         m, w, B, H, W = self.m, self.w, self.B, self.H, self.W
         self.tw, self.params, self.grads = tw, params, grads
         self.param_grads, self.input_grad = grads is not None, input_grad
+        self.frozen = frozenset(frozen)
+        # the time-embedding chain (d proj -> time_emb_proj -> time_embedding MLP -> class table) runs iff one of its parameters trains
+        self._temb_trains = self.param_grads and any(
+            n not in self.frozen for n in (grads or {}) if ".time_emb_proj." in n or n.startswith("time_embedding.") or n == "class_embedding.weight")
         if self.param_grads and getattr(w, "class_mode", None) is not None:
             # class_embed_type "timestep" / "identity" (cond_unet_2d.py:146-153): inference plans only -- the class MLP / identity rows
             # have no gradient launches (no shipped config sets them; every shipped config uses the nn.Embedding table or none)
@@ -213,12 +218,28 @@ class UNetTrainPlan(UNetPlan):
 
     def _G(self, name, span=()):
         """Gradient tensor of a parameter, noting that the NEXT emitted op writes it (and the parameters fused behind it:
-        ``span``) -- the schedule the overlapped data-parallel all-reduce follows."""
+        ``span``) -- the schedule the overlapped data-parallel all-reduce follows.  None when the parameter (and everything fused
+        behind it) is frozen: the emitters then skip the launch (a fused launch with one trainable member still runs and writes the
+        frozen members' segments too -- ``FlatAdamWEMA.step`` zeroes those before the norm)."""
         if not self.param_grads:
             return None
-        for n in (name,) + tuple(span):
-            self.grad_ready[n] = len(self.bwd_ops)
+        names = (name,) + tuple(span)
+        if all(n in self.frozen for n in names):
+            return None
+        for n in names:
+            if n not in self.frozen:
+                self.grad_ready[n] = len(self.bwd_ops)
         return self.grads[name]
+
+    def _G2(self, wname, bname):
+        """(weight, bias) gradient tensors of a normalisation layer: both, or neither when both are frozen (one launch writes the two;
+        a frozen member of a half-frozen pair is written too and zeroed by ``FlatAdamWEMA.step``)."""
+        if not self.param_grads or (wname in self.frozen and bname in self.frozen):
+            return None, None
+        for n in (wname, bname):
+            if n not in self.frozen:
+                self.grad_ready[n] = len(self.bwd_ops)
+        return self.grads[wname], self.grads[bname]
 
     def _esz(self):
         return 4 if self.code == L.PD_F32 else 2
@@ -226,6 +247,10 @@ class UNetTrainPlan(UNetPlan):
     def _bias_grad(self, dy, total, valid=None, per_sample=None, per_stride=None):
         if not self.param_grads:
             return
+        if total is None:                       # a frozen bias
+            if per_sample is None or not self._temb_trains:
+                return
+            total = self._tmp((dy.shape[3],), "frozen_bias_sink", torch.float32)     # the per-sample sums still feed the time-embedding chain
         B, h, w, ch = dy.shape
         out = per_sample if per_sample is not None else self._tmp((B, ch), "chsum", torch.float32)
         fused = self._fused_sums.get(id(dy))
@@ -247,7 +272,7 @@ class UNetTrainPlan(UNetPlan):
     def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0):
         """Weight gradient of a convolution (``pd_conv_wgrad``); plain Linear layers (1x1, one dense source, no fused GroupNorm)
         go through the token-reduction GEMM ``pd_token_wgrad``."""
-        if not self.param_grads:
+        if not self.param_grads or dw is None:          # (dw None: a frozen weight)
             return
         if (ksize == 1 and gn is not None and x1 is None and not cout_valid and not cin_valid and x0.shape[3] % 8 == 0 and dy.shape[3] % 8 == 0
                 and not _NO_LINEAR_GRADS and not _NO_PREAPPLY_WGRAD):
@@ -324,12 +349,13 @@ class UNetTrainPlan(UNetPlan):
         splits = max(1, min(64, (h * w) // 64, -(-1024 // B)))
         partial = self._tmp((B * splits * (c0 + c1) * 2,), "gnpart", torch.float64)
         coef = self._tmp((B, self.groups, 2), "gncoef", torch.float32)
+        dgam, dbet = self._G2(wname + ".weight", wname + ".bias")
         a = L.GnBwdArgs(dtype=self.code, B=B, HW=h * w, C0=c0, C1=c1, groups=self.groups, silu=silu, x0=x0.data_ptr(),
                         x1=L.ptr(x1), dz0=dz.data_ptr(), dz1=None, mean=s.mean.data_ptr(), rstd=s.rstd.data_ptr(),
                         gamma=s.gamma.data_ptr(), beta=s.beta.data_ptr(), partial=partial.data_ptr(), splits=splits,
                         coef=coef.data_ptr(), dx0=g0[0].data_ptr(), dx1=(g1[0].data_ptr() if g1 else None),
                         accumulate0=int(g0[1]), accumulate1=int(g1[1]) if g1 else 0,
-                        dgamma=L.ptr(self._G(wname + ".weight")), dbeta=L.ptr(self._G(wname + ".bias")),
+                        dgamma=L.ptr(dgam), dbeta=L.ptr(dbet),
                         dz_combined=1 if (combined and c1) else 0, res=L.ptr(res))
         g0[1] = True
         if g1:
@@ -366,10 +392,11 @@ class UNetTrainPlan(UNetPlan):
             return
         self._temb_bwd()
         # one slab serves every weight-gradient launch (they run back to back on one stream)
-        need = max(self.lib.pd_conv_wgrad_workspace(C.byref(a)) for a in self._wgrad_args)
-        self.slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
-        for a in self._wgrad_args:
-            a.slab, a.slab_bytes = self.slab.data_ptr(), need
+        if self._wgrad_args:            # (none when every convolution weight is frozen: attention-only fine-tuning)
+            need = max(self.lib.pd_conv_wgrad_workspace(C.byref(a)) for a in self._wgrad_args)
+            self.slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
+            for a in self._wgrad_args:
+                a.slab, a.slab_bytes = self.slab.data_ptr(), need
         if self._twgrad_args:       # likewise for the token-reduction weight gradients of the Linear layers
             need = max(self.lib.pd_token_wgrad_workspace(C.byref(a)) for a in self._twgrad_args)
             self.slab_tokens = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
@@ -434,6 +461,8 @@ class UNetTrainPlan(UNetPlan):
             if not self.param_grads:
                 return
             self._bias_grad(dout, G("conv_in.bias"))
+            if "conv_in.weight" in self.frozen:
+                return
             cols = self._tmp((B, H, W, 32), "im2col")
             a = L.Im2col3Args(dtype=self.code, B=B, H=H, W=W, C=c.in_channels, x=None, out=cols.data_ptr())
             self._sample_ptr_args.append(a)
@@ -522,8 +551,16 @@ class UNetTrainPlan(UNetPlan):
         self._gn_bwd(rec.gn, dz, 0, res=dout, wname=n + ".group_norm")
 
     def _temb_bwd(self):
+        if not self._temb_trains:
+            return
         m, w, P = self.m, self.w, self.params
-        G = self._G
+        # (this chain's launches write weight and bias of a layer together and the projections of all ResNet blocks as one stacked
+        # matrix: a partially frozen chain runs whole, FlatAdamWEMA.step zeroes the frozen members' gradient segments)
+        def G(name, span=()):
+            for n in (name,) + tuple(span):
+                if n not in self.frozen:
+                    self.grad_ready[n] = len(self.bwd_ops)
+            return self.grads[name]
         B, tdim, c0, pd = self.B, m.time_embed_dim, m.config.block_out_channels[0], w.proj_dim
         res = [n for n, mod in m.named_modules() if isinstance(mod, _Resnet)]
         first = res[0]
@@ -535,7 +572,7 @@ class UNetTrainPlan(UNetPlan):
                 db=G(first + ".time_emb_proj.bias", [r + ".time_emb_proj.bias" for r in res[1:]]).data_ptr()), "linear_wgrad")
         self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=pd, dy=self.dproj.data_ptr(),
                 w=P[first + ".time_emb_proj.weight"].data_ptr(), pre=self.t_emb.data_ptr(), dx=demb.data_ptr()), "linear_dgrad")
-        if getattr(m, "class_embedding", None) is not None:
+        if getattr(m, "class_embedding", None) is not None and "class_embedding.weight" not in self.frozen:
             self._emb_grad_args = L.EmbeddingGradArgs(rows=B, dim=tdim, num_classes=m.class_embedding.weight.shape[0], labels=None,
                                                       d=demb.data_ptr(), dtable=G("class_embedding.weight").data_ptr())
             self._emb_grad_at = len(self.bwd_ops)
@@ -711,15 +748,24 @@ class UNetTrainer:
     forward -> loss (+ d loss / d out) -> backward -> [gradient all-reduce] -> clip + AdamW + EMA -> re-pack weights."""
 
     def __init__(self, model: CustomCondUNet2DModel, scheduler, lr: float, *, device=None, use_ema: bool = True,
-                 max_grad_norm: Optional[float] = 1.0, group=None, **adamw):
-        from .training import DiffusionLoss, FlatAdamWEMA, broadcast_from_rank0_
+                 max_grad_norm: Optional[float] = 1.0, group=None, trainable=None, **adamw):
+        """``trainable``: which parameters train -- names, a predicate ``f(name, parameter)``, or None = what the parameters'
+        ``requires_grad`` flags say (:func:`phendiff_amd.training.resolve_trainable`: the reference freezes with
+        ``requires_grad_(False)`` and ``--attention_fine_tuning`` re-enables ``module.attentions``, train.py:189-220).  Frozen
+        parameters get no gradient launches, no AdamW / EMA update, and stay out of the global norm and of the all-reduce buckets."""
+        from .training import DiffusionLoss, FlatAdamWEMA, broadcast_from_rank0_, resolve_trainable
         self.model, self.scheduler = model, scheduler
         dev = device or model.device
         if torch.device(dev).type != "cuda":
             raise L.PhenDiffHipError("phendiff_amd trains on MI355X only (no CPU fallback): move the model to 'cuda'")
         order = training_param_order(model)
+        flags = resolve_trainable(order, model, trainable)
+        if not any(flags):
+            raise ValueError("UNetTrainer: no trainable parameter (every parameter is frozen)")
+        self.frozen = frozenset(n for (n, _), f in zip(order, flags) if not f)
         self.opt = FlatAdamWEMA([p for _, p in order], lr, use_ema=use_ema, max_grad_norm=max_grad_norm, **adamw)
-        if order[-1][0] == "class_embedding.weight":
+        self.opt.set_trainable(flags)
+        if order[-1][0] == "class_embedding.weight" and flags[-1]:
             self.opt.set_tail(order[-1][1].numel(), ("class_embedding.weight",))
         self._cond = True
         # DDP's wrap-time broadcast (train.py:311-326): rank 0's parameters everywhere; the EMA shadow starts from them
@@ -749,7 +795,7 @@ class UNetTrainer:
 
     def _make_plan(self, key):
         m = self.model
-        return UNetTrainPlan(m, m._weights, self._tw, *key, self.device, self.params, self.grads)
+        return UNetTrainPlan(m, m._weights, self._tw, *key, self.device, self.params, self.grads, frozen=self.frozen)
 
     def _bind_weights(self) -> bool:
         """Make the trainer's caches refer to the model's CURRENT packed weights; returns True when they had to be rebuilt
@@ -809,7 +855,8 @@ class UNetTrainer:
         elif not overlap:
             from .training import allreduce_mean_
             loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb)
-            allreduce_mean_(self.opt.grad, group)
+            for off, k in self.opt.trainable_ranges():
+                allreduce_mean_(self.opt.grad[off:off + k], group)
         else:
             loss = self._forward_backward_overlapped(noisy, timesteps, clean, noise, class_labels, class_emb, group, world,
                                                      bucket_bytes)
@@ -830,8 +877,23 @@ class UNetTrainer:
         if getattr(self, "_bucket_key", None) != key:
             names = list(self.grads)
             last = len(plan.bwd_ops) - 1
-            self._buckets = plan_grad_buckets([self.grads[n].numel() for n in names],
-                                              [plan.grad_ready.get(n, last) for n in names], max(1, bucket_bytes // 4))
+            # buckets are cut inside each run of trainable parameters: a frozen parameter's gradient segment is not exchanged
+            self._buckets, off, run = [], 0, [0, [], []]
+            frozen = getattr(self, "frozen", frozenset())
+            for n in names + [None]:
+                if n is None or n in frozen:
+                    if run[1]:
+                        self._buckets += [(run[0] + a, run[0] + b, r) for a, b, r in plan_grad_buckets(run[1], run[2], max(1, bucket_bytes // 4))]
+                    if n is None:
+                        break
+                    off += self.grads[n].numel()
+                    run = [off, [], []]
+                    continue
+                k = self.grads[n].numel()
+                run[1].append(k)
+                run[2].append(plan.grad_ready.get(n, last))
+                off += k
+            self._buckets.sort(key=lambda b: b[2])
             self._bucket_key = key
             self._comm_stream = torch.cuda.Stream(device=self.device)
         cur = torch.cuda.current_stream(self.device)

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .packing import pack_conv_weight
+from .training import mark_requires_grad_calls
 from .unet import UNetPlan, _Attention, _Block, _DT, _Op, _Sampler
 
 SD_VAE_CONFIG = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
@@ -138,6 +139,7 @@ class DecoderOutput(SimpleNamespace):
     """``.sample``"""
 
 
+@mark_requires_grad_calls
 class AutoencoderKL(nn.Module):
     """Drop-in for diffusers ``AutoencoderKL`` (SD configuration: ``DownEncoderBlock2D`` / ``UpDecoderBlock2D`` stages, one
     single-head attention in each mid block).  ``compute_dtype``: "bf16" (fast) or "f32" (exact-fp32 MFMA, parity mode)."""
@@ -171,7 +173,7 @@ class AutoencoderKL(nn.Module):
         self.quant_conv = nn.Conv2d(2 * c.latent_channels, 2 * c.latent_channels, 1)
         self.post_quant_conv = nn.Conv2d(c.latent_channels, c.latent_channels, 1)
         self._plans, self._weights = {}, None
-        self.requires_grad_(False)
+        nn.Module.requires_grad_(self, False)
 
     # ---- diffusers conveniences ------------------------------------------------------------------------------------
     @classmethod

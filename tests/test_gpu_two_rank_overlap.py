@@ -45,3 +45,8 @@ def test_two_rank_overlapped_step_pixel_unet():
 
 def test_two_rank_overlapped_step_sd_unet():
     _run_two_ranks("sd")
+
+
+def test_two_rank_attention_fine_tuning_exchanges_trainable_runs_only():
+    """--attention_fine_tuning (train.py:201-220) with two ranks: buckets are cut inside the runs of trainable parameters."""
+    _run_two_ranks("pixel_frozen")

@@ -103,6 +103,53 @@ def pixel(rank):
     assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5                  # == torch's AdamW on the full batch
 
 
+def pixel_frozen(rank):
+    """--attention_fine_tuning with two ranks (train.py:201-220 + 311-326): only the attention parameters are exchanged and stepped;
+    frozen parameters still take rank 0's values at wrap time and never move."""
+    from test_gpu_frozen_params import adamw, attention_fine_tuning, check_against_oracle, oracle_step
+    from test_gpu_unet_backward import batch
+    from test_gpu_unet_ddib import make_pair
+    from phendiff_amd.unet_train import UNetTrainer
+    r, m = make_pair("super_small", 32, "f32")
+    attention_fine_tuning(r, verbatim=False)
+    attention_fine_tuning(m)
+    before = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}       # rank 0's weights = the oracle's
+    if rank == 1:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.01)
+    sched, clean, noise, ts, labels, noisy, target = batch(4, 32)
+    tr = UNetTrainer(m, sched, lr=2e-4, use_ema=True)
+    trainable = set(tr.grads) - tr.frozen
+    assert len(trainable) == 60
+    _same_on_both_ranks(tr.opt.flat, "parameters after the wrap-time broadcast")
+    _slow_hooks(tr, rank)
+    sl = slice(2 * rank, 2 * rank + 2)
+    half = [t[sl].cuda() for t in (noisy, ts, clean, noise)]
+    opt = adamw(r, 2e-4)
+    for k in range(3):
+        loss_ref = oracle_step(r, opt, noisy, ts, target, class_labels=labels)
+        if rank == 1:
+            time.sleep(0.15)
+        loss = tr.step(*half, class_labels=labels[sl].cuda(), overlap=True, bucket_bytes=64 << 10)
+        torch.cuda.synchronize()
+        both = [torch.zeros(1) for _ in range(2)]
+        dist.all_gather(both, loss.detach().float().cpu().reshape(1))
+        assert abs(float(sum(both)) / 2 - loss_ref) < 2e-4 * abs(loss_ref), (k, both, loss_ref)
+    # every bucket lies inside a run of trainable parameters
+    off, spans = 0, []
+    for n in tr.grads:
+        kk = tr.grads[n].numel()
+        if n in tr.frozen:
+            spans.append((off, off + kk))
+        off += kk
+    assert len(tr._buckets) >= 4
+    for a, b, _ in tr._buckets:
+        assert not any(a < hi and lo < b for lo, hi in spans), (a, b)
+    _same_on_both_ranks(tr.opt.flat, "parameters after 3 overlapped steps")
+    check_against_oracle(r, m, before, trainable)
+
+
 def sd(rank):
     import phendiff_amd as P
     from test_gpu_sd_unet import TINY, make_pair
@@ -161,7 +208,7 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
-        {"pixel": pixel, "sd": sd}[which](rank)
+        {"pixel": pixel, "sd": sd, "pixel_frozen": pixel_frozen}[which](rank)
         dist.barrier()
         print(f"two_rank_overlap_worker {which} rank {rank}: OK", flush=True)
     finally:
