@@ -25,7 +25,8 @@ from .sd_unet_ref import (  # noqa: F401
     UNet2DConditionRef, CustomEmbeddingRef, SD21_UNET_CONFIG, class_emb_to_encoder_hidden_states)
 from .vae_ref import AutoencoderKLRef, SD_VAE_CONFIG, vae_preprocess_ref, vae_postprocess_ref  # noqa: F401
 from .sd_pipeline_ref import (  # noqa: F401
-    SDImg2ImgPipelineRef, hack_class_embedding_ref, encode_to_latents_ref, sd_inversion_ref, sd_ddib_ref, sd_cfg_forward_start_ref)
+    SDImg2ImgPipelineRef, hack_class_embedding_ref, encode_to_latents_ref, sd_inversion_ref, sd_ddib_ref, sd_cfg_forward_start_ref,
+    sd_linear_interp_custom_guidance_inverted_start_ref)
 from .training_ref import TrainingLoopRef, TINY_CONFIG0_UNET, synthetic_two_class_batch, cosine_lr_lambda, ema_decay_ref  # noqa: F401
 from .pipeline_ref import (  # noqa: F401
     ConditionalDDIMPipelineRef,

@@ -149,3 +149,25 @@ def sd_cfg_forward_start_ref(pipe, clean_images, target_class_labels, guidance_s
     return pipe(image=clean_images, class_labels=target_class_labels, strength=frac_diffusion_skipped,
                 num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, generator=generator,
                 output_type=output_type)
+
+
+def sd_linear_interp_custom_guidance_inverted_start_ref(pipe, clean_images, orig_class_labels, target_class_labels, p,
+                                                        guidance_loss_scale, num_inference_steps, generator=None, variant="0.18.2"):
+    """``_linear_interp_custom_guidance_inverted_start``, ``CustomStableDiffusionImg2ImgPipeline`` branch
+    (utils_Img2Img.py:651-696): ``_LDM_preprocess`` (VAE-encode, both label tensors -> 77-token embeddings), inversion under the
+    original class embedding, gradient-guided generation IN LATENT SPACE under the target class embedding
+    (``pipe.unet(images, t, target_class_embeds)``, :718-726; the Lp target is the inverted latent), ``_decode_to_images`` and the
+    min-max renormalisation to [-1, 1] (:689-695).  Returns (images in [-1, 1], guided latents, inverted latents)."""
+    from .pipeline_ref import custom_guided_generation_ref
+    with torch.no_grad():
+        latents = encode_to_latents_ref(pipe, clean_images, generator)
+        ehs_orig = hack_class_embedding_ref(pipe._encode_class(orig_class_labels, False))
+        ehs_target = hack_class_embedding_ref(pipe._encode_class(target_class_labels, False))
+        inverted = sd_inversion_ref(pipe, latents, ehs_orig, num_inference_steps, variant)
+    guided = custom_guided_generation_ref(pipe, inverted, ehs_target, p, guidance_loss_scale, num_inference_steps)
+    with torch.no_grad():
+        image = pipe.vae.decode(guided / pipe.vae.config.scaling_factor, return_dict=False)[0]
+        image = image - image.min()
+        image = image / image.max()
+        image = image * 2 - 1
+    return image, guided, inverted

@@ -107,13 +107,16 @@ def classifier_free_guidance_forward_start(pipe, clean_images, target_class_labe
 @torch.no_grad()
 def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labels: torch.Tensor, p: float,
                              guidance_loss_scale: float, num_inference_steps: int, return_losses: bool = False):
-    """``_custom_guided_generation`` (utils_Img2Img.py:699-760), ConditionalDDIMPipeline branch.  Per step: UNet forward
+    """``_custom_guided_generation`` (utils_Img2Img.py:699-760), both pipeline branches (latent diffusion: ``input_images`` are latents,
+    ``target_class_labels`` the (B, 77, D) class embeddings, :663-671).  Per step: UNet forward
     (statistics kept), ``x0 = scheduler.step(...).pred_original_sample``, per-image ``Lp_loss(x0, input_images, p)``
     (``:245-270``), its gradient w.r.t. the image THROUGH the UNet (what ``torch.autograd.grad(losses_seq, images)`` returns:
     ``pd_lp_guidance`` -> input-gradient-only UNet backward), ``images -= guidance_loss_scale * grad``, then the scheduler
     step with the model output computed before the push.  No autograd graph exists: the backward is the HIP plan."""
-    if not isinstance(pipe, ConditionalDDIMPipeline):
-        raise NotImplementedError("only the ConditionalDDIMPipeline branch is implemented")
+    from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline
+    ldm = isinstance(pipe, CustomStableDiffusionImg2ImgPipeline)
+    if not ldm and not isinstance(pipe, ConditionalDDIMPipeline):
+        raise NotImplementedError(type(pipe))
     if not input_images.is_cuda:
         raise L.PhenDiffHipError("phendiff_amd runs on MI355X only (no CPU fallback): move the inputs to 'cuda'")
     if isinstance(p, str) or not (1.0 <= float(p) < 1e6):
@@ -122,11 +125,21 @@ def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labe
     unet, sched = pipe.unet, pipe.scheduler
     dev = input_images.device
     B, _, H, W = input_images.shape
-    plan = unet.input_grad_plan(B, H, W, dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     target = input_images.detach().contiguous().float()
     images = target.clone()
-    labels = target_class_labels.to(device=dev, dtype=torch.int64).contiguous()
+    if ldm:
+        # latent-diffusion branch (:718-726): `target_class_labels` IS the (B, 77, D) class embedding `_LDM_preprocess` made, handed to
+        # `pipe.unet(images, t, target_class_embeds)` as encoder_hidden_states; `images` are latents
+        ehs = target_class_labels.to(device=dev, dtype=torch.float32).contiguous()
+        if ehs.ndim != 3 or ehs.shape[0] != B:
+            raise ValueError(f"latent-diffusion branch: target_class_labels must be the (B, tokens, D) class embeddings, got {tuple(ehs.shape)}")
+        plan = unet.input_grad_plan(B, H, W, ehs.shape[1], dev)
+        run_forward = lambda ts: plan.forward(images, ts, ehs, model_out, st)
+    else:
+        labels = target_class_labels.to(device=dev, dtype=torch.int64).contiguous()
+        plan = unet.input_grad_plan(B, H, W, dev)
+        run_forward = lambda ts: plan.forward(images, ts, labels, None, model_out, st)
     model_out, d_out, d_direct, pushed = (torch.empty_like(images) for _ in range(4))
     splits = max(1, min(64, images[0].numel() // 4096))
     partial = torch.empty(B * splits, dtype=torch.float64, device=dev)
@@ -136,7 +149,7 @@ def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labe
     sched.set_timesteps(num_inference_steps)
     for t in sched.timesteps:
         ts = torch.full((B,), float(t), dtype=torch.float32, device=dev)
-        plan.forward(images, ts, labels, None, model_out, st)
+        run_forward(ts)
         sa, sb, _, _, _ = sched.step_coefficients(t)
         a = L.LpGuidanceArgs(numel=images.numel(), per_sample=images[0].numel(), pred_type=L.PD_PRED[c.prediction_type],
                              clip=int(bool(c.clip_sample)), clip_range=float(c.clip_sample_range), sqrt_a=sa, sqrt_b=sb,
@@ -157,13 +170,24 @@ def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labe
 @torch.no_grad()
 def linear_interp_custom_guidance_inverted_start(pipe, clean_images, orig_class_labels, target_class_labels, p: float,
                                                  guidance_loss_scale: float, num_inference_steps: int,
-                                                 variant: str = "0.18.2", output_type: str = "numpy"):
-    """``_linear_interp_custom_guidance_inverted_start`` (utils_Img2Img.py:651-696): inversion under the original class,
+                                                 variant: str = "0.18.2", output_type: str = "numpy", generator=None):
+    """``_linear_interp_custom_guidance_inverted_start`` (utils_Img2Img.py:651-696), both pipeline branches (``generator`` seeds the
+    VAE posterior draw of the latent-diffusion branch; the reference draws it unseeded): inversion under the original class,
     then gradient-guided generation under the target class (``p`` / ``guidance_loss_scale``: the method's config keys,
     defaults 2 / 0.001).  ``output_type``: "pt" = the [-1, 1] tensor the reference hands to ``tensor_to_PIL``; "numpy" =
     NHWC float in [0, 1]; "pil"."""
+    from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline
+    ldm = isinstance(pipe, CustomStableDiffusionImg2ImgPipeline)
+    target_cond = target_class_labels
+    if ldm:      # :663-671: images -> latents, both label tensors -> 77-token class embeddings
+        clean_images, (orig_class_labels, target_cond) = LDM_preprocess(pipe, clean_images, [orig_class_labels, target_class_labels], generator)
     inverted = inversion(pipe, clean_images, orig_class_labels, num_inference_steps, None, variant)
-    image = custom_guided_generation(pipe, inverted, target_class_labels, p, guidance_loss_scale, num_inference_steps)
+    image = custom_guided_generation(pipe, inverted, target_cond, p, guidance_loss_scale, num_inference_steps)
+    if ldm:      # :689-695: decode, then min-max renormalisation back to [-1, 1]
+        image = decode_to_images(pipe, image)
+        image = image - image.min()
+        image = image / image.max()
+        image = image * 2 - 1
     if output_type == "pt":
         return image
     arr = (image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy()

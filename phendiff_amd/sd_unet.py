@@ -221,7 +221,23 @@ class SDUNet2DConditionModel(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def invalidate(self):
-        self._plans, self._weights = {}, None
+        self._plans, self._weights, self._grad_weights = {}, None, None
+
+    def input_grad_plan(self, B, H, W, tokens, device):
+        """Forward + input-gradient-only backward plan (d loss / d latents through the UNet, no parameter gradients): what
+        ``torch.autograd.grad(losses_seq, images)`` needs in the gradient-guided transfer with a latent-diffusion pipeline
+        (utils_Img2Img.py:718-745)."""
+        from .sd_unet_train import SDTrainWeights, SDUNetTrainPlan
+        key = ("input_grad", B, H, W, tokens, str(device), self.compute_dtype)
+        p = self._plans.get(key)
+        if p is None:
+            if self._weights is None:
+                self._weights = _SDPackedWeights(self, device)
+            if getattr(self, "_grad_weights", None) is None:
+                self._grad_weights = SDTrainWeights(self, device, self._weights.tdt)
+            p = SDUNetTrainPlan(self, self._weights, self._grad_weights, B, H, W, tokens, device, input_grad=True)
+            self._plans[key] = p
+        return p
 
     def plan_for(self, B, H, W, tokens, device):
         """The launch plan (every buffer + pre-filled argument structs) of one UNet evaluation at this shape."""

@@ -89,6 +89,8 @@ class SDTrainWeights:
         wo = torch.zeros((((co + 31) // 32) * 32,) + tuple(m.conv_out.weight.shape[1:]), dtype=torch.float32, device=device)
         wo[:co] = m.conv_out.weight.detach().to(device=device, dtype=torch.float32)
         self.conv_out_d = pk(wo)
+        # conv_in's input gradient (the latent gradient of the gradient-guided transfer): block_out_channels[0] -> 4 channels (pad 32)
+        self.conv_in_d = pk(m.conv_in.weight, 32)
 
 
 class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
@@ -97,10 +99,13 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
     ``EMB_NAME`` -> the ``CustomEmbedding`` table (optional).  ``backward`` ACCUMULATES into ``grads``."""
 
     def __init__(self, m: SDUNet2DConditionModel, w: _SDPackedWeights, tw: SDTrainWeights, B, H, W, tokens, device,
-                 params: Optional[Dict[str, torch.Tensor]] = None, grads: Optional[Dict[str, torch.Tensor]] = None, frozen=()):
+                 params: Optional[Dict[str, torch.Tensor]] = None, grads: Optional[Dict[str, torch.Tensor]] = None, frozen=(),
+                 input_grad: bool = False):
+        """``input_grad``: also produce d loss / d latents (fp32 NCHW, ``self.dsample``) -- the gradient-guided transfer's
+        ``torch.autograd.grad(losses_seq, images)`` through the UNet (utils_Img2Img.py:718-745, latent-diffusion branch)."""
         self.train = True
         SDUNetPlan.__init__(self, m, w, B, H, W, tokens, device)
-        self._init_train(tw, params, grads, False, frozen)
+        self._init_train(tw, params, grads, input_grad, frozen)
 
     # ---- layout checks -----------------------------------------------------------------------------------------------
     def _check_layout(self):
@@ -161,6 +166,15 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         if rec.kind == "transformer":
             self._transformer_bwd(rec)
         elif rec.kind == "sd_conv_in":
+            if self.input_grad:
+                dout = self._g(rec.out)[0]
+                ops, self.ops = self.ops, self.bwd_ops
+                try:
+                    self._conv(dout, None, self.tw.conv_in_d, self._zero_bias, self.m.config.in_channels, out_mode=L.PD_OUT_NCHW_F32,
+                               cout_pad=32, y=self.dsample, stats=False)
+                finally:
+                    self.ops = ops
+                self.bwd_ops[-1].what = "dgrad3x3"
             if not self.param_grads:
                 return
             dout = self._g(rec.out)[0]
@@ -276,6 +290,7 @@ class _SDRepacker:
 
         ci, c0 = m.conv_in.weight.shape[1], m.conv_in.weight.shape[0]
         job(w.conv_in_w, m.conv_in.weight, c0, ci, 3, cin_pad=32)
+        job(tw.conv_in_d, m.conv_in.weight, ci, c0, 3, dgrad=1, cout_pad=32)
         for name, mod in m.named_modules():
             if isinstance(mod, _Resnet):
                 e, t = w.resnets[name], tw.resnets[name]

@@ -65,6 +65,19 @@ def main_sd():
     print("wrote sd_tiny_32_s4.npz")
 
 
+def main_sd_guided():
+    """Gradient-guided transfer, latent-diffusion branch (utils_Img2Img.py:651-760 with a CustomStableDiffusionImg2ImgPipeline):
+    tiny stack, 32x32 images (16x16 latents), S = 3, p = 2; loss scale 0.5 so the gradient term is visible."""
+    from oracle import sd_linear_interp_custom_guidance_inverted_start_ref
+    pipe = sd_tiny_pipe()
+    x, labels = synth_batch(2, 32)
+    image, guided, inverted = sd_linear_interp_custom_guidance_inverted_start_ref(pipe, x, labels, 1 - labels, 2, 0.5, 3,
+                                                                                  generator=torch.Generator().manual_seed(13))
+    np.savez_compressed(os.path.join(HERE, "guided_sd_tiny_32_s3.npz"), images=x.numpy(), labels=labels.numpy(), p=np.float32(2),
+                        guidance_loss_scale=np.float32(0.5), out=image.numpy(), guided_latents=guided.numpy(), inverted=inverted.numpy())
+    print("wrote guided_sd_tiny_32_s3.npz")
+
+
 def main():
     torch.manual_seed(0)
     unet = CondUNet2DRef(**dict(UNET_CONFIGS["super_small"], sample_size=32)).eval()
@@ -124,6 +137,8 @@ def main_sd21_denoiser():
 if __name__ == "__main__":
     if "--sd21-denoiser" in sys.argv:
         main_sd21_denoiser()
+    elif "--sd-guided" in sys.argv:
+        main_sd_guided()
     elif "--sd" in sys.argv:
         main_sd()
     elif "--google" in sys.argv:
@@ -131,5 +146,6 @@ if __name__ == "__main__":
     else:
         main()
         main_sd()
+        main_sd_guided()
         main_google()
         main_sd21_denoiser()

@@ -226,3 +226,78 @@ def test_sd_ddib_graph_replays_the_eager_transfer_bit_for_bit(mode):
     out2 = g.run(x2, 1 - labels, labels, generator=torch.Generator().manual_seed(5))
     torch.cuda.synchronize()
     assert torch.equal(out2.images.cpu(), torch.from_numpy(eager2))
+
+
+# ---- gradient-guided transfer, latent-diffusion branch (utils_Img2Img.py:651-760 with a CustomStableDiffusionImg2ImgPipeline) ----------
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+def test_sd_guidance_gradient_through_unet_matches_autograd(mode, tol):
+    """d Lp(x0_pred, target) / d latents through the SD UNet (input-gradient-only backward plan) and the scheduler's x0 formula, one
+    step: what ``torch.autograd.grad(losses_seq, images)`` returns with ``pipe.unet(images, t, target_class_embeds)`` (:718-745)."""
+    import ctypes as C
+    import phendiff_amd as P
+    import phendiff_amd._lib as L
+    from oracle import hack_class_embedding_ref, lp_loss_ref
+    ref, pipe = make_pipe(mode)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 4, 16, 16, generator=g)
+    target = lat + 0.3 * torch.randn(lat.shape, generator=g)
+    labels = torch.tensor([0, 1])
+    ehs = hack_class_embedding_ref(ref._encode_class(labels, False)).detach()
+    images = lat.clone().requires_grad_(True)
+    ref.scheduler.set_timesteps(4)
+    t = ref.scheduler.timesteps[1]
+    mo = ref.unet(images, t, ehs).sample
+    x0 = ref.scheduler.step(mo, t, images).pred_original_sample
+    losses = lp_loss_ref(x0, target, 2)
+    (want,) = torch.autograd.grad([losses[0], losses[1]], images)
+
+    dev = torch.device("cuda:0")
+    plan = pipe.unet.input_grad_plan(2, 16, 16, 77, dev)
+    st = torch.cuda.current_stream().cuda_stream
+    im, tg = lat.to(dev).contiguous(), target.to(dev)
+    out, d_out, d_dir = (torch.empty_like(im) for _ in range(3))
+    pipe.scheduler.set_timesteps(4)
+    plan.forward(im, torch.full((2,), float(t), device=dev), ehs.to(dev), out, st)
+    sa, sb, _, _, _ = pipe.scheduler.step_coefficients(t)
+    c = pipe.scheduler.config
+    partial = torch.empty(2 * 2, dtype=torch.float64, device=dev)
+    ls = torch.empty(2, device=dev)
+    a = L.LpGuidanceArgs(numel=im.numel(), per_sample=im[0].numel(), pred_type=L.PD_PRED[c.prediction_type], clip=int(bool(c.clip_sample)),
+                         clip_range=float(c.clip_sample_range), sqrt_a=sa, sqrt_b=sb, p=2.0, sample=im.data_ptr(), model_out=out.data_ptr(),
+                         target=tg.data_ptr(), partial=partial.data_ptr(), splits=2, d_model_out=d_out.data_ptr(),
+                         d_sample_direct=d_dir.data_ptr(), losses=ls.data_ptr())
+    L.check(L.lib().pd_lp_guidance(C.byref(a), st), "pd_lp_guidance")
+    plan.backward(d_out, st)
+    torch.cuda.synchronize()
+    assert rel(out, mo.detach()) < (2e-5 if mode == "f32" else 3e-2)
+    assert rel(ls, losses.detach()) < (1e-5 if mode == "f32" else 2e-2)
+    assert rel(d_dir + plan.dsample, want) < tol
+
+
+@pytest.mark.parametrize("mode,tol_lat,tol_img", [("f32", 2e-3, 2e-3), ("bf16", 8e-2, 1e-1)])
+def test_sd_gradient_guided_transfer_matches_golden(mode, tol_lat, tol_img):
+    """_linear_interp_custom_guidance_inverted_start with the latent-diffusion pipeline, end to end, against the committed oracle
+    vectors (tests/golden/make_golden.py --sd-guided: tiny stack, 32x32 images = 16x16 latents, S = 3, p = 2, loss scale 0.5 -- raised
+    from the reference default 1e-3 so that a wrong gradient could not hide inside the tolerance): _LDM_preprocess -> inversion ->
+    per-step UNet forward + input-gradient backward + Lp push in latent space -> _decode_to_images -> min-max renormalisation."""
+    import phendiff_amd as P
+    d = np.load(os.path.join(GOLDEN, "guided_sd_tiny_32_s3.npz"))
+    _, pipe = make_pipe(mode)
+    x, labels = torch.from_numpy(d["images"]).cuda(), torch.from_numpy(d["labels"]).cuda()
+    S, p, scale = 3, float(d["p"]), float(d["guidance_loss_scale"])
+    # the pieces (utils_Img2Img.py:663-696)
+    lat, (c_orig, c_target) = P.LDM_preprocess(pipe, x, [labels, 1 - labels], generator=torch.Generator().manual_seed(13))
+    inv = P.inversion(pipe, lat, c_orig, S)
+    assert rel(inv, torch.from_numpy(d["inverted"])) < tol_lat
+    guided, step_losses = P.custom_guided_generation(pipe, inv, c_target, p, scale, S, return_losses=True)
+    assert rel(guided, torch.from_numpy(d["guided_latents"])) < tol_lat
+    assert len(step_losses) == S and all(float(l.min()) >= 0 for l in step_losses)
+    unguided = P.custom_guided_generation(pipe, inv, c_target, p, 0.0, S)                    # the guidance must have had an effect
+    assert rel(guided, unguided) > 0.15
+    # ... and the whole function
+    out = P.linear_interp_custom_guidance_inverted_start(pipe, x, labels, 1 - labels, p, scale, S, output_type="pt",
+                                                         generator=torch.Generator().manual_seed(13))
+    assert tuple(out.shape) == (2, 3, 32, 32) and float(out.min()) == -1.0 and float(out.max()) == 1.0      # min-max renormalised
+    assert rel(out, torch.from_numpy(d["out"])) < tol_img
+    arr = P.linear_interp_custom_guidance_inverted_start(pipe, x, labels, 1 - labels, p, scale, S, generator=torch.Generator().manual_seed(13))
+    assert isinstance(arr, np.ndarray) and arr.shape == (2, 32, 32, 3) and arr.min() >= 0 and arr.max() <= 1
