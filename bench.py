@@ -305,6 +305,8 @@ def main_train(args, P, world, rank, dev, dist):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_train(args.model, size, state_dict, args.cpu_baseline_seconds)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+    if dist is not None:
+        res["data_parallel"] = comm_step_stats(args, dev, dist, tr, step)
     if rank == 0:
         res["diagnostic_env"] = diagnostic_env()
         print(json.dumps(res), flush=True)
@@ -323,6 +325,9 @@ def _sd_stack(P, args, dev, latent_only=False):
     return unet, vae, emb, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["SD_orig_config"])
 
 
+_SELFTEST = {}      # comm_selftest()'s result (world > 1), attached to the line by reduce_elapsed
+
+
 def reduce_elapsed(dist, elapsed, dev, units_per_rank):
     """MAX of the ranks' elapsed time (the contract's clock) + what each rank did: per-rank units/s and the size of the process
     group RCCL actually formed."""
@@ -333,7 +338,125 @@ def reduce_elapsed(dist, elapsed, dev, units_per_rank):
     every = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(every, mine)
     times = [float(t.item()) for t in every]
-    return max(times), {"rccl_world_size": world, "per_rank_units_per_s": [round(units_per_rank / t, 4) for t in times]}
+    st = _SELFTEST.get("result") or {}
+    return max(times), {"rccl_world_size": st.get("rccl_world_size", world), "rccl_world_size_source": st.get("rccl_world_size_source", "torch.distributed.get_world_size()"),
+                        "per_rank_units_per_s": [round(units_per_rank / t, 4) for t in times],
+                        **({"allreduce_selftest": st} if st else {})}
+
+
+def comm_selftest(dist, dev, nbytes=64 << 20, native_timeout_s=90.0):
+    """world > 1, before anything is timed: one 64 MB fp32 bucket all-reduced three ways --
+    ``torch.distributed.all_reduce`` (RCCL through PyTorch), ``pd_allreduce_bucket`` algo 0 (ncclAllReduce through the C ABI) and
+    algo 1 (reduce-scatter + all-gather) -- each checked bit for bit against the analytic sum and timed; the bus bandwidth
+    2 (W - 1) / W x bytes / t of each goes on the JSON line, with the size of the communicator as RCCL itself reports it
+    (``pd_comm_query``: ncclCommCount).  The first execution of this code with more than one RCCL rank is the driver's 8-GPU run: if
+    the curve bends, this says what the exchange can do on that node.  The native communicator is built in a worker thread with a
+    time limit: a failure or a stall there is recorded on the line and costs the run nothing else (the trainers' default exchange
+    is ``torch.distributed``)."""
+    import threading
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = nbytes // 4
+    n -= n % (world * 256)
+    base = (torch.arange(n, device=dev, dtype=torch.float32) % 1024) / 1024          # exact dyadic fractions
+    want = base * float(world * (world + 1) // 2)                                   # sum over ranks of (rank + 1) * base: exact in fp32
+    out = {"bytes": n * 4, "world": world, "busbw_GBs": {}, "exact": {}}
+    rehearsal = bool(os.environ.get("PD_BENCH_REHEARSAL"))
+
+    def timed(fn, reps=3):
+        buf = base * float(rank + 1)
+        fn(buf)                                                                     # warm-up (and the checked result)
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(buf, want))
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        bufs = [base * float(rank + 1) for _ in range(reps)]
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for b in bufs:
+            fn(b)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        return ok, round(2.0 * (world - 1) / world * n * 4 / (ms * 1e-3) / 1e9, 2)
+
+    out["exact"]["torch"], out["busbw_GBs"]["torch"] = timed(lambda b: dist.all_reduce(b, op=dist.ReduceOp.SUM))
+    out["rccl_world_size"], out["rccl_world_size_source"] = world, "torch.distributed.get_world_size()"
+    if rehearsal:
+        out["native"] = "skipped: rehearsal over gloo on one device (RCCL refuses two ranks per device)"
+        return out
+    box = {}
+
+    def build():
+        try:
+            from phendiff_amd.comm import NativeComm
+            box["comm"] = NativeComm.from_process_group(None, dev)
+        except Exception as e:                                                     # noqa: BLE001 -- recorded, never fatal
+            box["error"] = repr(e)
+
+    th = threading.Thread(target=build, daemon=True)
+    th.start()
+    th.join(native_timeout_s)
+    flag = torch.tensor([1 if "comm" in box else 0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                                     # every rank agrees on whether the native part runs
+    if not int(flag.item()):
+        out["native"] = box.get("error", f"pd_comm_init did not return within {native_timeout_s:.0f} s on some rank")
+        return out
+    comm = box["comm"]
+    try:
+        r_, w_ = comm.query()
+        out["rccl_world_size"], out["rccl_world_size_source"] = w_, "pd_comm_query (ncclCommCount)"
+        out["rccl_rank_matches"] = bool(r_ == rank)
+        out["exact"]["rccl_allreduce"], out["busbw_GBs"]["rccl_allreduce"] = timed(lambda b: comm.allreduce_(b, mean=False, algo=0))
+        out["exact"]["rs_ag"], out["busbw_GBs"]["rs_ag"] = timed(lambda b: comm.allreduce_(b, mean=False, algo=1))
+    except Exception as e:                                                         # noqa: BLE001
+        out["native"] = repr(e)
+    finally:
+        try:
+            comm.close()
+        except Exception:                                                          # noqa: BLE001
+            pass
+    return out
+
+
+def comm_step_stats(args, dev, dist, tr, step, steps=3):
+    """world > 1, after the timed region of a training workload: (i) `allreduce_overlap_frac` -- the same step with events around every
+    bucket's collective on the comm stream: comm-stream busy time hidden under the backward / comm time; (ii) `step_ms_no_comm` --
+    the same step with the exchange left out (ranks then drift apart: these steps run last and their weights are discarded)."""
+    out = {}
+
+    def run(k):
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize(dev)
+        return 1e3 * (time.perf_counter() - t0) / k
+    tr.comm_timing = True
+    step()
+    torch.cuda.synchronize(dev)
+    stats = []
+    for _ in range(steps):
+        step()
+        torch.cuda.synchronize(dev)
+        stats.append(tr.comm_overlap_stats())
+    tr.comm_timing = False
+    stats = [s for s in stats if s]
+    if stats:
+        mid = sorted(stats, key=lambda s: s["overlap_frac"] or 0.0)[len(stats) // 2]
+        out["allreduce_overlap_frac"] = mid["overlap_frac"]
+        out["allreduce"] = mid
+    out["step_ms_with_comm"] = round(run(steps), 3)
+    tr.skip_collectives = True
+    step()
+    out["step_ms_no_comm"] = round(run(steps), 3)
+    tr.skip_collectives = False
+    mine = torch.tensor([out.get("allreduce_overlap_frac") or 0.0, out["step_ms_with_comm"], out["step_ms_no_comm"]], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    out["per_rank"] = {"allreduce_overlap_frac": [round(float(t[0]), 4) for t in every], "step_ms_with_comm": [round(float(t[1]), 3) for t in every],
+                       "step_ms_no_comm": [round(float(t[2]), 3) for t in every]}
+    return out
 
 
 def _timed_steps(args, dev, dist, step, units_per_rank):
@@ -486,6 +609,8 @@ def main_sd_train(args, P, world, rank, dev, dist):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_sd_train(P, size)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+    if dist is not None:
+        res["data_parallel"] = comm_step_stats(args, dev, dist, tr, step)
     if rank == 0:
         res["diagnostic_env"] = diagnostic_env()
         print(json.dumps(res), flush=True)
@@ -635,6 +760,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if dist is not None and not os.environ.get("PD_BENCH_NO_SELFTEST"):
+        try:
+            _SELFTEST["result"] = comm_selftest(dist, dev)
+        except Exception as e:                                                     # noqa: BLE001 -- the self-test never takes the run down
+            _SELFTEST["result"] = {"failed": repr(e)}
     if args.dtype == "fp16" and args.workload in ("train", "sd_train"):
         print("bench.py: fp16 is an inference mode of this engine (training runs bf16: fp32 exponent range, no GradScaler)", file=sys.stderr)
         sys.exit(2)

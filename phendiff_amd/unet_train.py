@@ -903,25 +903,62 @@ class UNetTrainer:
 
         native = getattr(self, "native_comm", None)      # phendiff_amd.comm.NativeComm: RCCL through the C ABI (pd_allreduce_bucket)
 
+        timing = getattr(self, "comm_timing", False)      # bench.py: events around every bucket's collective on the comm stream
+        skip = getattr(self, "skip_collectives", False)   # bench.py: the same step with the exchange left out (`step_ms_no_comm`)
+        if timing:
+            self._comm_events = []
+
         def launch(start, end):
             ev = torch.cuda.Event()
             ev.record(cur)
             comm.wait_event(ev)
+            if skip:
+                return
+            if timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(comm)
             if native is not None:
                 native.allreduce_(flat[start:end], mean=False, algo=1, stream=comm)
-                return
-            with torch.cuda.stream(comm):
-                works.append(dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            else:
+                with torch.cuda.stream(comm):
+                    wk = dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=group, async_op=True)
+                    if timing:
+                        wk.wait()                  # the COMM stream waits for the collective (RCCL runs it on a stream of its own)
+                    else:
+                        works.append(wk)
+            if timing:
+                e1.record(comm)
+                self._comm_events.append((e0, e1, (end - start) * 4))
 
         for start, end, rdy in self._buckets:
             prev = hooks.get(rdy)
             hooks[rdy] = (lambda s=start, e=end, p=prev: ((p() if p else None), launch(s, e)))
         loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb, after_op=hooks)
+        if timing:
+            self._bwd_end_event = torch.cuda.Event(enable_timing=True)
+            self._bwd_end_event.record(cur)
         for wk in works:
             wk.wait()                      # the compute stream waits for the collectives, the host does not
         cur.wait_stream(comm)
         flat.div_(world)
         return loss
+
+    def comm_overlap_stats(self):
+        """After a step run with ``comm_timing = True`` (and a device synchronisation): how much of the gradient exchange ran under the
+        backward.  comm_ms = busy time of the comm stream (sum over the buckets' collectives, which run one after the other on it);
+        exposed_ms = what was left of it when the backward's last launch finished (the optimizer waits that long); overlap_frac =
+        (comm_ms - exposed_ms) / comm_ms -- SURVEY 8(d) cfg4's "all-reduce overlap fraction"."""
+        evs = getattr(self, "_comm_events", None)
+        if not evs:
+            return None
+        comm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        exposed = max(0.0, self._bwd_end_event.elapsed_time(evs[-1][1]))
+        exposed = min(exposed, comm_ms)
+        nbytes = sum(b for _, _, b in evs)
+        return {"comm_ms": round(comm_ms, 3), "exposed_ms": round(exposed, 3),
+                "overlap_frac": round((comm_ms - exposed) / comm_ms, 4) if comm_ms > 0 else None,
+                "buckets": len(evs), "bytes": nbytes,
+                "algbw_GBs": round(nbytes / (comm_ms * 1e-3) / 1e9, 2) if comm_ms > 0 else None}
 
     def use_native_comm(self, comm=None, group=None):
         """Route the overlapped gradient exchange through ``pd_allreduce_bucket`` (reduce-scatter + all-gather on RCCL behind the C

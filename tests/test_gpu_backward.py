@@ -307,13 +307,15 @@ def test_attention_backward(env, mode, cfg):
 
 def test_native_comm_world_one_allreduce(env):
     """pd_comm_* (RCCL behind the C ABI, csrc/comm_rccl.hip) on the one GPU a test box has: a one-rank communicator, where the sum /
-    mean of a bucket is the bucket itself, through both forms (ncclAllReduce; reduce-scatter + all-gather) and on a side stream --
+    mean of a bucket is the bucket itself, through both forms (ncclAllReduce; reduce-scatter + all-gather: since round 4 the one-rank
+    communicator really takes the reduce-scatter + all-gather branch and its in-place pointer arithmetic) and on a side stream --
     id, init, collective, destroy.  Two ranks per device are refused by RCCL: the multi-rank exchange itself is covered through
     torch.distributed (tests/test_gpu_two_rank_overlap.py, gloo) and stays unmeasured on hardware."""
     from phendiff_amd.comm import NativeComm
     cid = NativeComm.unique_id()
     assert len(cid) == 128 and any(cid)
     comm = NativeComm(0, 1, cid)
+    assert comm.query() == (0, 1)               # rank / size as the communicator reports them (pd_comm_query: ncclCommUserRank / ncclCommCount)
     g = torch.Generator().manual_seed(71)
     x = torch.randn(1 << 20, generator=g).cuda()
     want = x.clone()

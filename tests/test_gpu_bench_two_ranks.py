@@ -38,9 +38,27 @@ def test_bench_two_ranks_img2img():
     # whole-job value = units of all ranks / the slowest rank's time
     assert abs(j["value"] - 2 * 4 * j["steps"] / (j["ms_per_step"] * j["steps"] / 1e3)) < 1e-2 * j["value"]
     assert j["value"] <= sum(j["per_rank_units_per_s"]) * 1.001 and j["diagnostic_env"].get("PD_BENCH_REHEARSAL") == "1"
+    # the start-up self-test of the exchange: 64 MB all-reduced and checked bit for bit against the analytic sum
+    st = j["allreduce_selftest"]
+    assert st["world"] == 2 and st["bytes"] >= 60 << 20 and st["exact"]["torch"] is True and st["busbw_GBs"]["torch"] > 0
+    assert "rehearsal" in st["native"] and j["rccl_world_size_source"].startswith("torch.distributed")   # (RCCL cannot form here)
 
 
 def test_bench_two_ranks_training():
     j = _run(["--workload", "train", "--batch", "8", "--size", "32"])
     assert j["n_gpus"] == 2 and j["rccl_world_size"] == 2 and j["config"]["global_batch"] == 16
     assert j["config"]["final_loss"] == j["config"]["final_loss"] and j["value"] > 0
+    # what would explain a bent scaling curve: overlap fraction of the exchange and the step
+    # with the exchange left out, per rank
+    dp = j["data_parallel"]
+    assert 0.0 <= dp["allreduce_overlap_frac"] <= 1.0 and dp["allreduce"]["buckets"] >= 1 and dp["allreduce"]["bytes"] == 4 * 15_725_443
+    assert dp["allreduce"]["comm_ms"] >= dp["allreduce"]["exposed_ms"] >= 0
+    assert 0 < dp["step_ms_no_comm"] <= dp["step_ms_with_comm"] * 1.5
+    assert len(dp["per_rank"]["step_ms_no_comm"]) == 2 and j["allreduce_selftest"]["exact"]["torch"] is True
+
+
+def test_bench_two_ranks_sd_training_reports_the_exchange():
+    j = _run(["--workload", "sd_train", "--batch", "2", "--size", "16"])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["value"] > 0
+    dp = j["data_parallel"]
+    assert 0.0 <= dp["allreduce_overlap_frac"] <= 1.0 and dp["allreduce"]["bytes"] > 3.4e9 and dp["step_ms_no_comm"] > 0
