@@ -26,6 +26,8 @@ struct LinP {
   int qkv_heads, B;                         // > 0: head-major q / k / v output [3][B][heads][rows_per_sample][8] (N = 3 * heads * 8)
   float* stats;                             // optional [B][rows_per_sample / 128][N][2]: per-tile channel (sum, sum of squares) of y
   float* kmax2;                             // optional (qkv_heads > 0, 16-bit) [B][heads]: atomic max of |k row|^2 as stored
+  long long w_sstride;                      // linear_dma_kernel: bytes between the packed weights of consecutive samples (0: one set for all)
+  int bias_sstride;                         // ... floats between their bias vectors
 };
 
 // gelu(g) = g/2 (1 + erf(g / sqrt 2)), F.gelu's default (exact) form.  The bf16 engine takes erf from Abramowitz-Stegun 7.1.26
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
     const int cob = GLU ? ((ct32[c] & 1) ? p.N / 2 : 0) + 32 * (ct32[c] >> 1) : ct32[c] * 32;   // bias stays in module order
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *(const f32x4*)(p.bias + cob + 8 * g + 4 * h);
+      const f32x4 bv = *(const f32x4*)(bias + cob + 8 * g + 4 * h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) init[4 * g + i] = bv[i];
     }
@@ -730,9 +732,10 @@ static int launch_linear(const LinP& p, hipStream_t st) {
 // retired by `s_waitcnt vmcnt(0)` + the chunk's one barrier (inline asm: a compiler-visible global_load_lds would order every
 // later ds_read behind it).  Plain layers only (no GroupNorm prologue, dense output, no statistics): the transformer blocks'
 // q/k/v, to_out, GEGLU and FeedForward projections and their input gradients -- 90 % of the SD UNet's Linear FLOPs.
-template <typename T, int NC, bool GLU, int CK>
+template <typename T, int NC, bool GLU, int CK, bool QKV = false>
 __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma_kernel(const LinP p) {
   static_assert(sizeof(T) == 2, "16-bit element types");
+  static_assert(!(QKV && GLU), "head-major output: plain projection");
   using E = Elem<T>;
   using Frag = typename E::Frag;
   static_assert(CK == 64 || CK == 32, "K chunk");
@@ -778,12 +781,17 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
     xsrc[j] = (const unsigned char*)p.x + ((size_t)m * p.x_stride + srcp * 8) * ES;
   }
   // W fragment f = wave * WP + j of the chunk's 2 NC x KSC: channel tile f / KSC, k-step f % KSC
+  // per-sample weights / bias (QKV: the GroupNorm affine of the projection's input is folded into them, linear_fold_gn_kernel):
+  // a 256-token tile lies inside one sample (rows_per_sample % 256 == 0, checked by pd_linear)
+  const long long smp = p.w_sstride ? m0 / p.rows_per_sample : 0;
+  const unsigned char* wbase = (const unsigned char*)p.w + smp * p.w_sstride;
+  const float* bias = p.bias + smp * p.bias_sstride;
   const unsigned char* wsrc[WP];
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
     const int f = wave * WP + j;
     const int c32 = min(n0 / 32 + f / KSC, last_ct32);              // tiles beyond N_pad do not exist: clamp (never stored)
-    wsrc[j] = (const unsigned char*)p.w + (((size_t)c32 * ksteps + (f % KSC)) * 512 + lane * 8) * ES;
+    wsrc[j] = wbase + (((size_t)c32 * ksteps + (f % KSC)) * 512 + lane * 8) * ES;
   }
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   auto dma = [&](const unsigned char* src, unsigned dst) {
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
     f32x16 init;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *(const f32x4*)(p.bias + cob + 8 * g + 4 * h);
+      const f32x4 bv = *(const f32x4*)(bias + cob + 8 * g + 4 * h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) init[4 * g + i] = bv[i];
     }
@@ -883,6 +891,47 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
   constexpr int PPT = TNO / EPC;                         // pieces per token
   constexpr int TPI = 512 / PPT;                         // tokens per iteration
   constexpr int NIT = TM / TPI;
+  if constexpr (QKV) {
+    // head-major q / k / v output [which][B][heads][token][8] (what pd_attn_d8 reads): consecutive TOKENS on consecutive lanes -- a
+    // (head, token) piece is 16 bytes and a head's tokens are contiguous, so TPI lanes write one run of 16 TPI bytes -- and the
+    // per-(sample, head) max |k|^2 of the key rows as stored (pd_attn_d8's score bound), folded through LDS to one global atomic
+    // per head and tile (non-negative floats order like their bit patterns)
+    unsigned* kmax_s = (unsigned*)(lds + TM * EP_PITCH);
+    if (tid < TN / 8) kmax_s[tid] = 0u;
+    __syncthreads();
+    const int pc = tid / TPI, tr = tid % TPI;
+    const int coq = n0 + pc * EPC;
+    const int Cq = p.qkv_heads * 8, which = coq / Cq, cc = coq - which * Cq;
+    const long long tok0 = m0 - smp * p.rows_per_sample;       // (smp = m0 / rows_per_sample also when the weights are shared)
+    const long long nn = p.w_sstride ? smp : m0 / p.rows_per_sample;
+    const long long tokb = m0 - nn * p.rows_per_sample;
+    (void)tok0;
+    float kmax_run = 0.f;
+    if (coq < p.N) {
+      T* dst = (T*)p.y + ((((size_t)which * p.B + nn) * p.qkv_heads + (cc >> 3)) * p.rows_per_sample + tokb) * 8 + (cc & 7);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int tok = it * TPI + tr;
+        if (m0 + tok >= p.M) continue;
+        const u32x4 v = *(const u32x4*)(lds + tok * EP_PITCH + pc * 16);
+        *(u32x4*)(dst + (size_t)tok * 8) = v;
+        if (p.kmax2 && which == 1) {
+          float n2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { float lo, hi; Pack16<T>::unpack(v[j], lo, hi); n2 = fmaf(lo, lo, fmaf(hi, hi, n2)); }
+          kmax_run = fmaxf(kmax_run, n2);
+        }
+      }
+      if (p.kmax2 && which == 1) atomicMax(&kmax_s[pc], __float_as_uint(kmax_run));
+    }
+    __syncthreads();
+    if (p.kmax2 && tid < TN / 8) {
+      const int c0 = n0 + tid * 8;
+      if (c0 < p.N && c0 / Cq == 1 && kmax_s[tid] != 0u)
+        atomicMax((unsigned*)p.kmax2 + nn * p.qkv_heads + ((c0 - Cq) >> 3), kmax_s[tid]);
+    }
+    return;
+  }
   const int piece = tid % PPT, trow = tid / PPT;
   const int NO = GLU ? p.N / 2 : p.N;
   const int co = (GLU ? ct * TNO : n0) + piece * EPC;
@@ -912,12 +961,12 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
   }
 }
 
-template <typename T, int NC, bool GLU, int CK>
+template <typename T, int NC, bool GLU, int CK, bool QKV = false>
 static int launch_linear_dma(const LinP& p, hipStream_t st) {
   constexpr int BUF = 256 * CK * 2 + 2 * NC * (CK / 16) * 1024, NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
-  constexpr int MAIN = NBUF * BUF, EPI = 256 * (64 * NC * 2 + 16);
+  constexpr int MAIN = NBUF * BUF, EPI = 256 * (64 * NC * 2 + 16) + (QKV ? 64 * NC / 8 * 4 : 0);     // QKV: + the per-head key maxima
   constexpr int LDS = MAIN > EPI ? MAIN : EPI;
-  auto kern = linear_dma_kernel<T, NC, GLU, CK>;
+  auto kern = linear_dma_kernel<T, NC, GLU, CK, QKV>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -930,6 +979,40 @@ static int launch_linear_dma(const LinP& p, hipStream_t st) {
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
+// The GroupNorm affine in front of a projection folded into per-sample weights: (x a_n + s_n) . W^T + b = x . (W diag(a_n))^T + (b + W s_n).
+// One workgroup per (32-channel tile, sample): reads the packed tile (lane (r, h) of k-step ks holds W[32 ct + r][16 ks + 8 h + j]),
+// writes it scaled by a_n in the same packed order, and reduces the bias term over the tile's K (fixed order: deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void linear_fold_gn_kernel(const T* w, const float* bias, const float* scale, const float* shift, int K, int N_pad,
+                                                            T* wn, float* bn) {
+  using E = Elem<T>;
+  __shared__ float red[8][32];
+  const int ct = blockIdx.x, n = blockIdx.y, ksteps = K / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const size_t tile = (size_t)ct * ksteps * 512;
+  T* dstn = wn + (size_t)n * (N_pad / 32) * ksteps * 512;
+  float acc = 0.f;
+  for (int ks = wave; ks < ksteps; ks += 4) {
+    const typename E::Frag f = E::load(w + tile + (size_t)ks * 512 + lane * 8);
+    float v[8];
+    E::unpack(f, v);
+    const float* a8 = scale + (size_t)n * K + ks * 16 + h * 8;
+    const float* s8 = shift + (size_t)n * K + ks * 16 + h * 8;
+    const f32x4 a0 = *(const f32x4*)a8, a1 = *(const f32x4*)(a8 + 4), s0 = *(const f32x4*)s8, s1 = *(const f32x4*)(s8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc = fmaf(v[j], s0[j], acc); acc = fmaf(v[4 + j], s1[j], acc); v[j] *= a0[j]; v[4 + j] *= a1[j]; }
+    E::store(dstn + tile + (size_t)ks * 512 + lane * 8, E::pack(v));
+  }
+  red[wave * 2 + h][r] = acc;
+  __syncthreads();
+  if (tid < 32) {
+    float t = bias[ct * 32 + tid];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][tid];
+    bn[(size_t)n * N_pad + ct * 32 + tid] = t;
+  }
+}
+
 template <typename T>
 static int dispatch_linear_dma(const LinP& p, int variant, bool glu, hipStream_t st) {   // variant: 2 = (NC 2, CK 64), 3 = (NC 2, CK 32), 4 = (NC 4, CK 64)
   if (variant == 4) return glu ? launch_linear_dma<T, 4, true, 64>(p, st) : launch_linear_dma<T, 4, false, 64>(p, st);

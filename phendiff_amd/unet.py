@@ -712,8 +712,9 @@ class UNetPlan:
             out = self._linear(o, e.wo, e.bo, ch, residual=x, stats=True, what="conv1x1")
         else:
             out, _ = self._conv(o, None, e.wo, e.bo, ch, ksize=1, pad=0, residual=x)
-        if self.train:
-            self.tape.append(SimpleNamespace(kind="attn_nhwc", name=name, x=x, qkv=qkv, o=o, out=out, lse=lse, gn=gn, e=e, d=d))
+        # recorded on inference plans too (lse = None), like every other block: diagnostics.assert_finite_activations walks the tape,
+        # and these are the buffers most likely to overflow in fp16
+        self.tape.append(SimpleNamespace(kind="attn_nhwc", name=name, x=x, qkv=qkv, o=o, out=out, lse=lse, gn=gn, e=e, d=d))
         return out
 
     def _build(self):
