@@ -29,7 +29,8 @@ extern "C" {
 
 /* Bumped whenever an args struct grows or an entry point is added (a caller built against an older header passes shorter
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
- * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query). */
+ * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
+ * fold_ws_bytes + pd_linear_fold_workspace). */
 #define PD_ABI_VERSION 4
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
@@ -495,8 +496,14 @@ typedef struct {
                                bias stays in module order [N].  N % 64 == 0, no residual / statistics / head-major output */
   float* kmax2_out;         /* NULL, or (qkv_heads > 0, bf16 / fp16) [B][heads] fp32, ZEROED by the caller before the launch:
                                atomically maxed with |k[b][head][n]|^2 of every stored key row -- pd_attn_d8's kmax2 */
+  void* fold_ws;            /* (ABI 4) NULL, or a device workspace of >= pd_linear_fold_workspace(a) bytes: the q/k/v projection behind a
+                               GroupNorm (scale / shift + qkv_heads) then runs as the DMA-staged GEMM over per-sample weights
+                               W diag(scale_n) and biases b + W shift_n written there by a small fold launch (same stream) */
+  size_t fold_ws_bytes;
 } pd_linear_args;
 int pd_linear(const pd_linear_args* a, void* stream);
+/* bytes of `fold_ws` that make pd_linear take the folded route for these arguments, 0 when the route does not apply */
+size_t pd_linear_fold_workspace(const pd_linear_args* a);
 
 /* pd_attn_wide: softmax(q k^T * scale) v with ONE wide head per D channels, D in {128, 256, 512} -- the mid-block attention of
  * the SD VAE (diffusers AutoencoderKL: Encoder/Decoder.mid_block.attentions[0], a single head over all 512 channels;

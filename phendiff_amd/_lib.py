@@ -159,7 +159,8 @@ class GnApplyArgs(C.Structure):
 class LinearArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_longlong), ("K", C.c_int), ("N", C.c_int), ("N_pad", C.c_int), ("x", vp),
                 ("x_stride", C.c_int), ("w_packed", vp), ("bias", vp), ("residual", vp), ("y", vp), ("scale", vp), ("shift", vp),
-                ("rows_per_sample", C.c_int), ("qkv_heads", C.c_int), ("stats_out", vp), ("glu", C.c_int), ("kmax2_out", vp)]
+                ("rows_per_sample", C.c_int), ("qkv_heads", C.c_int), ("stats_out", vp), ("glu", C.c_int), ("kmax2_out", vp),
+                ("fold_ws", vp), ("fold_ws_bytes", C.c_size_t)]
 
 
 class AttnWideArgs(C.Structure):
@@ -295,6 +296,7 @@ SYMBOLS = {
     "pd_token_wgrad_workspace": (C.c_size_t, [C.POINTER(TokenWgradArgs)]),
     "pd_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
     "pd_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
+    "pd_linear_fold_workspace": (C.c_size_t, [C.POINTER(LinearArgs)]),
     "pd_attn_wide": (C.c_int, [C.POINTER(AttnWideArgs), vp]),
     "pd_attn_wide_bwd": (C.c_int, [C.POINTER(AttnWideBwdArgs), vp]),
     "pd_comm_unique_id": (C.c_int, [C.POINTER(CommId)]),

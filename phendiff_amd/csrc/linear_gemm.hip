@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NC == 2) ? 3 : 2) void line
     const int cob = GLU ? ((ct32[c] & 1) ? p.N / 2 : 0) + 32 * (ct32[c] >> 1) : ct32[c] * 32;   // bias stays in module order
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *(const f32x4*)(bias + cob + 8 * g + 4 * h);
+      const f32x4 bv = *(const f32x4*)(p.bias + cob + 8 * g + 4 * h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) init[4 * g + i] = bv[i];
     }
@@ -902,10 +902,7 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
     const int pc = tid / TPI, tr = tid % TPI;
     const int coq = n0 + pc * EPC;
     const int Cq = p.qkv_heads * 8, which = coq / Cq, cc = coq - which * Cq;
-    const long long tok0 = m0 - smp * p.rows_per_sample;       // (smp = m0 / rows_per_sample also when the weights are shared)
-    const long long nn = p.w_sstride ? smp : m0 / p.rows_per_sample;
-    const long long tokb = m0 - nn * p.rows_per_sample;
-    (void)tok0;
+    const long long nn = m0 / p.rows_per_sample, tokb = m0 - nn * p.rows_per_sample;      // the tile lies inside sample nn
     float kmax_run = 0.f;
     if (coq < p.N) {
       T* dst = (T*)p.y + ((((size_t)which * p.B + nn) * p.qkv_heads + (cc >> 3)) * p.rows_per_sample + tokb) * 8 + (cc & 7);
@@ -1024,6 +1021,16 @@ static int dispatch_linear_dma(const LinP& p, int variant, bool glu, hipStream_t
 
 using namespace pd;
 
+extern "C" size_t pd_linear_fold_workspace(const pd_linear_args* a) {
+  // > 0 iff pd_linear can take the folded route for these arguments: 16-bit engine, GroupNorm prologue + head-major q/k/v output, no
+  // residual / statistics / GEGLU, K a multiple of 64, whole 256-token tiles inside a sample, a 16-byte-aligned row stride
+  if (!a || a->dtype == PD_F32 || !a->scale || !a->shift || a->qkv_heads <= 0 || a->residual || a->stats_out || a->glu) return 0;
+  if (a->rows_per_sample <= 0 || a->rows_per_sample % 256 != 0 || a->M % a->rows_per_sample != 0 || a->K % 64 != 0 || a->x_stride % 8 != 0) return 0;
+  if (a->N_pad % 32 != 0 || a->N != 3 * a->qkv_heads * 8) return 0;
+  const size_t B = (size_t)(a->M / a->rows_per_sample);
+  return B * ((size_t)(a->N_pad / 32) * (a->K / 16) * 512 * 2 + (size_t)a->N_pad * 4);
+}
+
 extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_linear: null args");
   PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16 || a->dtype == PD_F16, PD_ERR_ARG, "pd_linear: bad dtype %d", a->dtype);
@@ -1060,6 +1067,38 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   PD_CHECK(a->kmax2_out == nullptr || (a->qkv_heads > 0 && a->dtype != PD_F32), PD_ERR_SHAPE,
            "pd_linear: kmax2_out needs the head-major q/k/v output and a 16-bit dtype");
   p.kmax2 = a->kmax2_out;
+  // Round 4: the attention's fused q/k/v projection behind a GroupNorm (cond_unet_2d.py:176-178; diffusers Attention.group_norm ->
+  // to_q / to_k / to_v) through the DMA-staged GEMM: the affine is folded into per-sample weights and biases (linear_fold_gn_kernel into
+  // the caller's workspace: B x (packed weights + bias), 12.6 MB at B = 32, C = 256), so the token tiles are staged as they are (no
+  // register staging, no per-element affine) and the head-major + key-bound epilogue is the register-staged kernel's.
+  // PD_LIN_FOLD=0: diagnostic override (same-box A/B); 2 / 4: force the 128- / 256-channel tile.
+  {
+    static const int fold_env = getenv("PD_LIN_FOLD") ? atoi(getenv("PD_LIN_FOLD")) : -1;
+    const size_t need = pd_linear_fold_workspace(a);
+    if (fold_env != 0 && need > 0 && a->fold_ws != nullptr && a->fold_ws_bytes >= need) {
+      hipStream_t st = (hipStream_t)stream;
+      const int B = (int)(a->M / a->rows_per_sample);
+      const size_t wbytes = (size_t)(a->N_pad / 32) * (a->K / 16) * 512 * 2;
+      unsigned char* wn = (unsigned char*)a->fold_ws;
+      float* bn = (float*)(wn + (size_t)B * wbytes);
+      if (a->dtype == PD_F16)
+        hipLaunchKernelGGL(linear_fold_gn_kernel<half_t>, dim3(a->N_pad / 32, B), dim3(256), 0, st, (const half_t*)a->w_packed, a->bias, a->scale,
+                           a->shift, a->K, a->N_pad, (half_t*)wn, bn);
+      else
+        hipLaunchKernelGGL(linear_fold_gn_kernel<bf16_t>, dim3(a->N_pad / 32, B), dim3(256), 0, st, (const bf16_t*)a->w_packed, a->bias, a->scale,
+                           a->shift, a->K, a->N_pad, (bf16_t*)wn, bn);
+      PD_LAUNCH_CHECK();
+      LinP q = p;
+      q.scale = nullptr; q.shift = nullptr;
+      q.w = wn; q.bias = bn; q.w_sstride = (long long)wbytes; q.bias_sstride = a->N_pad;
+      q.t_tiles = (int)((a->M + 255) / 256);
+      const int c4 = (a->N_pad + 255) / 256, c2 = (a->N_pad + 127) / 128;
+      const bool wide = fold_env == 4 || (fold_env != 2 && (long long)c4 * 256 * 10 <= (long long)a->N_pad * 11);
+      q.c_tiles = wide ? c4 : c2;
+      if (a->dtype == PD_F16) return wide ? launch_linear_dma<half_t, 4, false, 64, true>(q, st) : launch_linear_dma<half_t, 2, false, 32, true>(q, st);
+      return wide ? launch_linear_dma<bf16_t, 4, false, 64, true>(q, st) : launch_linear_dma<bf16_t, 2, false, 32, true>(q, st);
+    }
+  }
   // DMA-staged 256-token kernel (round 3) for the plain layers with enough tiles to fill the chip: no GroupNorm prologue, dense
   // output, no statistics, K a multiple of 64, a 16-byte-aligned row stride.  PD_LIN_DMA=0 / 2 / 3 / 4: diagnostic override (off / variant).
   {

@@ -664,6 +664,16 @@ class UNetPlan:
             a = L.LinearArgs(dtype=self.code, M=M, K=ch, N=3 * ch, N_pad=3 * ch, x=x.data_ptr(), x_stride=ch, w_packed=e.wqkv.data_ptr(),
                              bias=e.bqkv.data_ptr(), residual=None, y=qkv.data_ptr(), scale=gn[0].data_ptr(), shift=gn[1].data_ptr(),
                              rows_per_sample=h * w, qkv_heads=e.heads, kmax2_out=kmax2)
+            # 16-bit engines: the GroupNorm affine folded into per-sample weights, the projection through the DMA-staged GEMM
+            # (pd_linear's `fold_ws` route); the attentions of one forward run one after the other and share the workspace
+            need = int(self.lib.pd_linear_fold_workspace(C.byref(a)))
+            if need > 0:
+                ws = getattr(self, "_fold_ws", None)
+                if ws is None or ws.numel() < need:
+                    ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                    self._fold_ws = ws
+                    self.bufs.append(ws)
+                a.fold_ws, a.fold_ws_bytes = ws.data_ptr(), need
             esz_ = 4 if self.code == L.PD_F32 else 2
             self.ops.append(_Op(self.lib.pd_linear, a, "conv1x1", 2.0 * M * ch * 3 * ch, (M * ch * 4 + 3 * ch * ch) * esz_))
         else:

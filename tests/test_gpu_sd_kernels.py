@@ -346,3 +346,51 @@ def test_linear_gemm_groupnorm_prologue_and_head_major_output(env, mode):
     a.kmax2_out = None
     a.rows_per_sample = 200                                                   # not a multiple of 128: refused, not mis-addressed
     assert lib.pd_linear(C.byref(a), stream()) == -2
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(3, 256, 128, 16), (2, 1024, 256, 32), (2, 512, 64, 8)])
+def test_linear_gemm_groupnorm_folded_into_per_sample_weights(env, mode, shape):
+    """Round 4: the pixel-UNet attention's fused q/k/v projection (cond_unet_2d.py:176-178; diffusers Attention.group_norm -> to_q / to_k /
+    to_v) through the DMA-staged GEMM: with a `fold_ws` workspace pd_linear folds the GroupNorm affine into per-sample weights
+    W diag(scale_n) and biases b + W shift_n (one small launch) and multiplies the tokens as they are.  Same head-major output and
+    key bound as the register-staged route; the arithmetic differs in where the 16-bit rounding sits (weights instead of the
+    normalised activations), so both are compared with the un-rounded fp32 result."""
+    from phendiff_amd.packing import pack_conv_weight
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, Ntok, Cc, heads = shape
+    g = torch.Generator().manual_seed(64)
+    x = bf16_round(torch.randn(B, Ntok, Cc, generator=g) * 1.5 + 0.3, mode)
+    scale, shift = torch.rand(B, Cc, generator=g) + 0.5, torch.randn(B, Cc, generator=g)
+    w = bf16_round(torch.randn(3 * Cc, Cc, generator=g) / Cc ** 0.5, mode)
+    bias = torch.randn(3 * Cc, generator=g)
+    ref = torch.nn.functional.linear(x * scale[:, None, :] + shift[:, None, :], w, bias)
+    ref = ref.reshape(B, Ntok, 3, heads, 8).permute(2, 0, 3, 1, 4).contiguous()
+    wp = pack_conv_weight(w[:, :, None, None], tdt).to(dev)
+    X, sc, sh, bv = x.to(tdt).to(dev), scale.to(dev), shift.to(dev), bias.to(dev)
+    a = L.LinearArgs(dtype=code, M=B * Ntok, K=Cc, N=3 * Cc, N_pad=3 * Cc, x=X.data_ptr(), x_stride=Cc, w_packed=wp.data_ptr(),
+                     bias=bv.data_ptr(), residual=None, y=None, scale=sc.data_ptr(), shift=sh.data_ptr(),
+                     rows_per_sample=Ntok, qkv_heads=heads)
+    need = int(lib.pd_linear_fold_workspace(C.byref(a)))
+    assert need == B * (3 * Cc * Cc * 2 + 3 * Cc * 4)
+    outs = {}
+    for route in ("staged", "folded"):
+        y = torch.full((3, B, heads, Ntok, 8), float("nan"), dtype=tdt, device=dev)
+        kmax2 = torch.zeros(B, heads, device=dev)
+        ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
+        a.y, a.kmax2_out = y.data_ptr(), kmax2.data_ptr()
+        a.fold_ws, a.fold_ws_bytes = (ws.data_ptr(), need) if route == "folded" else (None, 0)
+        L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+        torch.cuda.synchronize()
+        assert rel(y.float(), ref) < 6e-3 if mode == "bf16" else rel(y.float(), ref) < 8e-4, route
+        want = (y[1].float() ** 2).sum(-1).amax(-1)                           # the bound is over the key rows AS STORED
+        assert torch.allclose(kmax2, want, rtol=1e-5, atol=0), route
+        outs[route] = y.float()
+    assert rel(outs["folded"], outs["staged"]) < (8e-3 if mode == "bf16" else 1.2e-3)
+    # a workspace that is too small is not used (the staged route answers), a tile that would straddle samples has no folded route
+    a.fold_ws_bytes = need - 1
+    L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+    a.rows_per_sample = 128
+    a.M = B * Ntok
+    assert int(lib.pd_linear_fold_workspace(C.byref(a))) == 0
