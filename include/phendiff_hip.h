@@ -30,7 +30,8 @@ extern "C" {
 /* Bumped whenever an args struct grows or an entry point is added (a caller built against an older header passes shorter
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
  * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
- * fold_ws_bytes + pd_linear_fold_workspace). */
+ * fold_ws_bytes + pd_linear_fold_workspace,
+ * pd_conv_args.phase). */
 #define PD_ABI_VERSION 4
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
@@ -158,6 +159,14 @@ typedef struct {
   int im2col3;              /* 0, or n <= 3: x0 is an NCHW fp32 tensor with n channels (the UNet input sample) and the op is
                                the 3x3 pad-1 conv_in run as a 1x1 conv over 32 virtual channels k = ci*9 + ky*3 + kx
                                (ksize must be 1, C0 = 32, weights packed accordingly) */
+  int phase;                /* (ABI 4) 0: ordinary convolution.  1 + 2 a + b (a, b in {0, 1}): one PHASE of the sub-pixel form of Upsample2D
+                               (F.interpolate(x, 2.0, "nearest") then conv 3x3 pad 1, diffusers resnet.py; cond_unet_2d.py:200-228): output
+                               pixel (2 oy + a, 2 ox + b) of the y tensor [B][2 Hout][2 Wout][Cout] = sum over dy, dx in {0, 1} of
+                               W_ab[dy][dx] . x[oy - (1 - a) + dy][ox - (1 - b) + dx] (zero outside the image), W_ab = the 3x3 taps that
+                               fall on the same source pixel summed (4 of the 9 tap positions per output pixel: 4 / 9 of the FLOPs).
+                               Requires ksize = 2, stride 1, no upsample / GroupNorm / tail / residual, NHWC output, Hout = Hin,
+                               Wout = Win; `pad` is ignored.  stats_out is then [B][4 T][Cout][2], T = pd_conv_stat_tiles(Hout, Wout, 2, 1):
+                               phase p's tiles fill slots (p - 1) T .. p T - 1 */
 } pd_conv_args;
 int pd_conv(const pd_conv_args* a, void* stream);
 /* number of statistic tiles per sample pd_conv writes for this shape (depends on the kernel's tile choice) */

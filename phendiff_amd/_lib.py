@@ -68,7 +68,7 @@ class ConvArgs(C.Structure):
                 ("stride", C.c_int), ("pad", C.c_int), ("upsample", C.c_int), ("silu", C.c_int), ("out_mode", C.c_int),
                 ("heads", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("w_packed", vp), ("bias", vp),
                 ("temb", vp), ("temb_stride", C.c_int), ("residual", vp), ("y", vp), ("stats_out", vp), ("tail_x0", vp), ("tail_x1", vp), ("tail_C0", C.c_int),
-                ("tail_C1", C.c_int), ("im2col3", C.c_int)]
+                ("tail_C1", C.c_int), ("im2col3", C.c_int), ("phase", C.c_int)]
 
 
 class GnFinalizeArgs(C.Structure):

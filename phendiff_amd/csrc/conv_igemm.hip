@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   //   B: lane (i, g) reads pixel i of its 16-pixel run, channels 8 g .. 8 g + 7 (one ds_read_b128); pixel pitch 160 B (10 slots):
   //      the 144-byte pitch is 2-way conflicted for this access, 160 is conflict-free (brute force over the ds_read_b128 lane groups);
   //   D: acq[c][f][2 ti + tj]: lane (i, g) owns pixel 16 tj + i of fragment f and channels 16 ti + 4 g .. + 3 of tile c.
-  constexpr bool M16 = PD_CONV_M16 && (PLAIN || (PD_CONV_M16_GN && (NCO == 1 || PD_CONV_M16_GN >= 2)) || (PRO && PD_CONV_PRO_M16 >= (NCO == 2 ? 1 : 2))) && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DB && TW >= 16;
+  constexpr bool M16 = PD_CONV_M16 && (PLAIN || (PD_CONV_M16_GN && (NCO == 1 || PD_CONV_M16_GN >= 2)) || (PRO && PD_CONV_PRO_M16 >= (NCO == 2 ? 1 : 2))) && sizeof(T) == 2 && (KS == 3 || KS == 2) && STRIDE == 1 && DB && TW >= 16;
   constexpr int CHB = 32 * E::BYTES;                 // bytes of one 32-channel chunk of a pixel
   constexpr int PITCH = DB ? 2 * CHB + (M16 ? 32 : 16) : CHB + 16;
   constexpr int NIT = (NPIX * 4 + 255) / 256;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   // (Downsample2D(padding=0)'s (0,1,0,1)-padded forward)
   const int ups = p.upsample ? 1 : 0;                     // source coordinate = conv coordinate >> ups
   const int ph_mask = p.upsample >= 2 ? 1 : 0, ph_want = p.upsample == 3 ? 1 : 0;   // zero-stuffing: both coordinates' low bit must equal ph_want
-  const int iy_base = y0 * STRIDE - p.pad, ix_base = x0 * STRIDE - p.pad, n_base = n * p.Hin;
+  const int iy_base = y0 * STRIDE - p.pad, ix_base = x0 * STRIDE - p.pad_x, n_base = n * p.Hin;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int pix = (tid + 256 * i) >> 2;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
         piece = due;
       }
     }
-    if constexpr (ACTIVE && M16) {       // TAPS is odd: the operands prefetched for the next chunk's tap 0 sit in entry 1
+    if constexpr (ACTIVE && M16 && TAPS % 2 == 1) {       // TAPS odd: the operands prefetched for the next chunk's tap 0 sit in entry 1
 #pragma unroll
       for (int c = 0; c < NCO; ++c) { aq[0][c][0] = aq[1][c][0]; aq[0][c][1] = aq[1][c][1]; }
     }
@@ -794,15 +794,17 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   // through a buffer resource (invalid pixel / no residual tensor -> out-of-range offset -> zeros, no traffic); stores go
   // through a buffer resource too (out-of-range -> dropped), so the loop has no divergent branch.
   const int py0 = prow / TW, px0 = prow % TW;
-  const unsigned out_bytes = (unsigned)p.B * p.Hout * p.Wout * p.Cout * E::BYTES;     // < 2 GiB (checked by pd_conv)
+  // (sub-pixel phase of an upsampling convolution: this launch writes every out_step-th pixel of a tensor out_step^2 times as large)
+  const int os = p.out_step, HF = p.Hout * os, WF = p.Wout * os;
+  const unsigned out_bytes = (unsigned)p.B * HF * WF * p.Cout * E::BYTES;     // < 2 GiB (checked by pd_conv)
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.out_mode == PD_OUT_NHWC ? out_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.y), 0, p.residual ? out_bytes : 0u, 0x00020000);
-  const unsigned row_bytes = (unsigned)p.Wout * p.Cout * E::BYTES, px_bytes = (unsigned)p.Cout * E::BYTES;
+  const unsigned px_bytes = (unsigned)p.Cout * E::BYTES * os, row_bytes = (unsigned)WF * p.Cout * E::BYTES * os;   // steps of one tile pixel / row
   auto piece_off = [&](int it, int co) -> unsigned {       // byte offset of piece `it` (or OOB_OFF) for the 64-channel tile at `co`
     const int dpy = (it * PXI) / TW, dpx = (it * PXI) % TW;
     const int oy = y0 + py0 + dpy, ox = x0 + px0 + dpx;
-    const unsigned off = (unsigned)((n * p.Hout + y0 + py0) * p.Wout + x0 + px0) * px_bytes + (unsigned)co * E::BYTES
-                         + (unsigned)dpy * row_bytes + (unsigned)dpx * px_bytes;
+    const unsigned off = (unsigned)((n * HF + (y0 + py0) * os + p.out_oy) * WF + (x0 + px0) * os + p.out_ox) * (unsigned)(p.Cout * E::BYTES)
+                         + (unsigned)co * E::BYTES + (unsigned)dpy * row_bytes + (unsigned)dpx * px_bytes;
     return (oy < p.Hout && ox < p.Wout && co < p.Cout) ? off : OOB_OFF;
   };
   if (!DB) __syncthreads();                 // DB: the chunk loop already ended on a barrier
@@ -909,8 +911,8 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
 #pragma unroll 8
       for (int pr = 0; pr < PXI; ++pr) tot += red[(pr * PPP + pc) * (2 * EPC) + which * EPC + j];
       if (cog < p.Cout) {
-        const int tile = ty * p.tiles_x + tx;
-        p.stats[(((size_t)n * (p.tiles_x * p.tiles_y) + tile) * p.Cout + cog) * 2 + which] = tot;
+        const int tile = p.stat_tile_base + ty * p.tiles_x + tx;
+        p.stats[(((size_t)n * p.stat_tiles + tile) * p.Cout + cog) * 2 + which] = tot;
       }
     }
   }
@@ -926,7 +928,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   // double-buffer when two tiles fit comfortably -- and leave room for a second workgroup: the stride-2 halo tile (9 x 65 pixels)
   // double-buffered is 84 KB = ONE workgroup (4 waves) per CU; single-buffered 47 KB admits two, which overlap each other
   constexpr bool DB = 2 * LDS_TILE <= 100 * 1024 && !(STRIDE == 2 && PD_S2_SINGLE);
-  constexpr bool M16 = PD_CONV_M16 && (PLAIN || (PD_CONV_M16_GN && (NCO == 1 || PD_CONV_M16_GN >= 2)) || (PRO && PD_CONV_PRO_M16 >= (NCO == 2 ? 1 : 2))) && sizeof(T) == 2 && KS == 3 && STRIDE == 1 && TW >= 16;        // (conv_kernel: 160-byte pixels)
+  constexpr bool M16 = PD_CONV_M16 && (PLAIN || (PD_CONV_M16_GN && (NCO == 1 || PD_CONV_M16_GN >= 2)) || (PRO && PD_CONV_PRO_M16 >= (NCO == 2 ? 1 : 2))) && sizeof(T) == 2 && (KS == 3 || KS == 2) && STRIDE == 1 && TW >= 16;        // (conv_kernel: 160-byte pixels)
   constexpr int LDS_DB = ((IN_TH * IN_TW * (2 * 32 * Elem<T>::BYTES + (M16 ? 32 : 16)) + 15) / 16) * 16;   // interleaved buffers, one shared pad
   constexpr int EPI_BYTES = TH * TW * (64 * Elem<T>::BYTES + 16) + 256 * 64;   // output tile + stats scratch [256][2*EPC] fp32
   constexpr int LDS_MAIN = (DB ? LDS_DB : LDS_TILE) + (PRO ? 16 : 0);          // PRO: + the dump slot behind the tile
@@ -948,6 +950,8 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   q.tiles_x_shift = -1;
   for (int sft = 0; sft < 16; ++sft) if ((1 << sft) == q.tiles_x) q.tiles_x_shift = sft;
   q.n_co_tiles = (p.Cout_pad + 63) / 64;
+  if (q.stat_tiles == 0) q.stat_tiles = q.tiles_x * q.tiles_y;                 // ordinary launch: the statistic tiles are this launch's tiles
+  else { q.stat_tiles *= q.tiles_x * q.tiles_y; q.stat_tile_base *= q.tiles_x * q.tiles_y; }      // phase launch: (phases, phase index) so far
   hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.n_co_tiles / NCO, p.B), dim3(256), LDS_BYTES, st, q);
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -1030,6 +1034,11 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
     if (w >= 16) return launch_conv<T, 3, 2, 8, 16>(p, st);
     return launch_conv<T, 3, 2, 16, 8>(p, st);
   }
+  if (ksize == 2 && stride == 1) {     // a phase of the sub-pixel upsampling convolution: always without a prologue (PLAIN: 16x16x32 MFMAs in the 16-bit engines)
+    if (w >= 32) return launch_conv<T, 2, 1, 8, 32, false, 1, true>(p, st);
+    set_error("pd_conv: the 2x2 phase form needs Wout >= 32");
+    return PD_ERR_UNSUPPORTED;
+  }
   if (ksize == 1 && stride == 1) {
     if (w >= 32) return launch_conv<T, 1, 1, 8, 32>(p, st);
     if (w >= 16) return launch_conv<T, 1, 1, 16, 16>(p, st);
@@ -1053,10 +1062,18 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   PD_CHECK(a->x0 && a->w_packed && a->bias && a->y, PD_ERR_ARG, "pd_conv: null pointer");
   PD_CHECK((a->C1 == 0) == (a->x1 == nullptr), PD_ERR_ARG, "pd_conv: x1/C1 mismatch");
   PD_CHECK((a->scale == nullptr) == (a->shift == nullptr), PD_ERR_ARG, "pd_conv: scale/shift mismatch");
-  PD_CHECK(a->ksize == 1 || a->ksize == 3, PD_ERR_UNSUPPORTED, "pd_conv: ksize %d", a->ksize);
+  PD_CHECK(a->phase >= 0 && a->phase <= 4, PD_ERR_ARG, "pd_conv: phase %d", a->phase);
+  if (a->phase) {
+    PD_CHECK(a->ksize == 2 && a->stride == 1 && !a->upsample && !a->scale && !a->silu && !a->tail_x0 && !a->im2col3 && !a->residual &&
+             a->out_mode == PD_OUT_NHWC && a->Hout == a->Hin && a->Wout == a->Win && a->C1 == 0, PD_ERR_UNSUPPORTED,
+             "pd_conv: a sub-pixel phase is a plain 2x2 convolution over one source with Hout = Hin, Wout = Win and NHWC output");
+    PD_CHECK((size_t)a->B * a->Hout * a->Wout * 4 * a->Cout * (a->dtype == PD_F32 ? 4 : 2) < 0x80000000ull, PD_ERR_SHAPE,
+             "pd_conv: the upsampled NHWC output exceeds 2 GiB (32-bit buffer offsets); split the batch");
+  }
+  PD_CHECK(a->ksize == 1 || a->ksize == 3 || (a->ksize == 2 && a->phase), PD_ERR_UNSUPPORTED, "pd_conv: ksize %d", a->ksize);
   PD_CHECK(a->stride == 1 || (a->stride == 2 && a->ksize == 3), PD_ERR_UNSUPPORTED, "pd_conv: stride %d", a->stride);
   PD_CHECK(!(a->upsample && a->stride != 1) && a->upsample >= 0 && a->upsample <= 3, PD_ERR_UNSUPPORTED, "pd_conv: upsample %d with stride %d", a->upsample, a->stride);
-  {
+  if (!a->phase) {
     const int hc = a->upsample ? 2 * a->Hin : a->Hin, wc = a->upsample ? 2 * a->Win : a->Win;
     const int extra = (a->ksize == 3 && a->pad == 0) ? 1 : 0;   // asymmetric (0,1,0,1) zero pad of Downsample2D(padding=0)
     const int ho = (hc + 2 * a->pad + extra - a->ksize) / a->stride + 1;
@@ -1101,6 +1118,12 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.w = a->w_packed; p.bias = a->bias;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.residual = a->residual; p.y = a->y;
   p.stats = a->stats_out; p.im2col3 = a->im2col3 ? 1 : 0; p.C0r = a->im2col3;
+  p.pad_x = a->pad; p.out_step = 1;
+  if (a->phase) {          // phase 1 + 2 a + b: rows start at oy - (1 - a), columns at ox - (1 - b)
+    const int pa = (a->phase - 1) >> 1, pb = (a->phase - 1) & 1;
+    p.pad = 1 - pa; p.pad_x = 1 - pb; p.out_step = 2; p.out_oy = pa; p.out_ox = pb;
+    p.stat_tiles = 4; p.stat_tile_base = a->phase - 1;        // (launch_conv scales both by the tiles per phase)
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PD_F32) return dispatch_conv<float>(p, a->ksize, a->stride, st);
   if (a->dtype == PD_F16) return dispatch_conv<half_t>(p, a->ksize, a->stride, st);

@@ -25,6 +25,9 @@ struct ConvP {
   const void* t0; const void* t1;
   int im2col3;         // source is NCHW fp32 with C0r <= 3..4 real channels: 3x3 taps gathered into 32 virtual channels
   int C0r;
+  // sub-pixel phase of an upsampling convolution (pd_conv_args.phase): column padding separate from the row padding, output pixel
+  // (out_step oy + out_oy, out_step ox + out_ox) of a tensor out_step times as large, statistic tiles at stat_tile_base of stat_tiles
+  int pad_x, out_step, out_oy, out_ox, stat_tile_base, stat_tiles;
 };
 
 }  // namespace pd

@@ -30,3 +30,25 @@ def dgrad_weight(w: torch.Tensor) -> torch.Tensor:
     """Weight of the input-gradient convolution: for y = conv(x, W) (stride 1, "same" padding),
     dx = conv(dy, W') with W'[ci, co, ky, kx] = W[co, ci, K-1-ky, K-1-kx]  (transpose + spatial flip)."""
     return w.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+
+
+def upsample_phase_weights(w: torch.Tensor):
+    """The sub-pixel form of ``F.interpolate(x, scale_factor=2, mode="nearest")`` followed by a 3x3 pad-1 convolution (diffusers
+    ``Upsample2D``): output pixel (2y + a, 2x + b) only sees the 2x2 block of LOW-resolution pixels rows y - (1 - a) .. +1,
+    columns x - (1 - b) .. +1, each through the sum of the 3x3 taps that land on it.  Returns the four 2x2 kernels
+    ``[W_00, W_01, W_10, W_11]`` (``W_ab``: OI22, fp32) for ``pd_conv(phase = 1 + 2 a + b)`` -- 4 / 9 of the multiply-adds of the
+    convolution over the upsampled tensor, the same function of the weights (sums formed in fp32 before the 16-bit rounding)."""
+    assert w.ndim == 4 and w.shape[2:] == (3, 3)
+    w = w.detach().float()
+    taps = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # phase -> (3x3 taps on source offset 0, on source offset 1)
+    out = []
+    for a in (0, 1):
+        for b in (0, 1):
+            k = torch.zeros(w.shape[0], w.shape[1], 2, 2, dtype=torch.float32, device=w.device)
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    for ky in taps[a][dy]:
+                        for kx in taps[b][dx]:
+                            k[:, :, dy, dx] += w[:, :, ky, kx]
+            out.append(k)
+    return out

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .packing import pack_conv_weight
+from .packing import pack_conv_weight, upsample_phase_weights
 from .training import mark_requires_grad_calls
 from .unet import UNet2DOutput, UNetPlan, _Block, _DT, _Op, _Resnet, _Sampler, _TimestepEmbedding
 
@@ -333,6 +333,8 @@ class _SDPackedWeights:
                 self.transformers[name] = e
             elif isinstance(r, _Sampler):
                 self.samplers[name] = SimpleNamespace(w=pk(r.conv.weight), b=f32(r.conv.bias), padding=r.padding)
+                if ".upsamplers." in name:      # Upsample2D as four 2x2 phase convolutions (UNetPlan._upconv_subpixel; inference plans)
+                    self.samplers[name].w4 = [pk(k) for k in upsample_phase_weights(r.conv.weight)]
         self.proj_dim = off
         self.wpT = f32(torch.cat(proj_w, 0).t())
         self.bp = f32(torch.cat(proj_b, 0))
@@ -460,7 +462,10 @@ class SDUNetPlan(UNetPlan):
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h)
             if blk.upsamplers is not None:
                 s = w.samplers[f"up_blocks.{i}.upsamplers.0"]
-                hu, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+                if self._subpixel_up_ok(h):
+                    hu = self._upconv_subpixel(h, s)
+                else:
+                    hu, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
                 self.tape.append(SimpleNamespace(kind="up", name=f"up_blocks.{i}.upsamplers.0", x=h, out=hu, e=s))
                 h = hu
         g, be, eps = w.gn_out

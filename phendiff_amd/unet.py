@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .packing import pack_conv_weight
+from .packing import pack_conv_weight, upsample_phase_weights
 from .training import mark_requires_grad_calls
 
 # compute_dtype -> (pd_dtype, storage dtype).  "fp16": the reference's `--mixed_precision fp16` (args_parser.py:381-390; img2img_comparison.py:57):
@@ -410,6 +410,10 @@ class _PackedWeights:
         for name, s in self._iter(m, _Sampler):
             e = SimpleNamespace()
             e.w, e.b, e.padding = self._pack(s.conv.weight), f32(s.conv.bias), s.padding
+            if ".upsamplers." in name:
+                # Upsample2D as four 2x2 convolutions over the low-resolution tensor (pd_conv phase 1..4): 4 / 9 of the FLOPs of the 3x3
+                # convolution over the nearest-upsampled tensor (inference plans; the training plans keep the 3x3 form their backward reads)
+                e.w4 = [self._pack(k) for k in upsample_phase_weights(s.conv.weight)]
             self.samplers[name] = e
         self.gn_out = (f32(m.conv_norm_out.weight), f32(m.conv_norm_out.bias), m.conv_norm_out.eps)
         co = m.conv_out.weight.shape[0]
@@ -561,6 +565,34 @@ class UNetPlan:
             nbytes += B * hout * wout * cout * (4 - esz)
         self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}", flops, nbytes))
         return y, a
+
+    SUBPIXEL_UP = __import__("os").environ.get("PD_SUBPIXEL_UP", "1") != "0"      # diagnostic: same-box A/B against the 3x3-over-upsampled form
+
+    def _subpixel_up_ok(self, x):
+        B, h, w, ch = x.shape
+        esz = 4 if self.code == L.PD_F32 else 2
+        return (self.SUBPIXEL_UP and not getattr(self, "train", False) and w >= 32 and ch % 32 == 0
+                and B * 4 * h * w * ch * esz < (1 << 31))
+
+    def _upconv_subpixel(self, x, s):
+        """Upsample2D (nearest x2 + conv 3x3 pad 1; diffusers resnet.py, reached from cond_unet_2d.py:200-228) as four 2x2 convolutions
+        over the low-resolution tensor, one per output phase (``pd_conv_args.phase``): each launch writes every other pixel of every other
+        row of the upsampled output and its share of the output's GroupNorm statistic tiles."""
+        B, h, w, ch = x.shape
+        y = self._act(2 * h, 2 * w, ch)
+        T = self.lib.pd_conv_stat_tiles(h, w, 2, 1)
+        st = self._f32(B, 4 * T, ch, 2)
+        self.stats[id(y)] = (st, 4 * T)
+        esz = 4 if self.code == L.PD_F32 else 2
+        for ph in range(4):
+            a = L.ConvArgs(dtype=self.code, B=B, Hin=h, Win=w, Hout=h, Wout=w, C0=ch, C1=0, Cout=ch, Cout_pad=ch, ksize=2, stride=1, pad=0,
+                           upsample=0, silu=0, out_mode=L.PD_OUT_NHWC, heads=0, x0=x.data_ptr(), x1=None, scale=None, shift=None,
+                           w_packed=s.w4[ph].data_ptr(), bias=s.b.data_ptr(), temb=None, temb_stride=self.w.proj_dim, residual=None,
+                           y=y.data_ptr(), stats_out=st.data_ptr(), im2col3=0, tail_x0=None, tail_x1=None, tail_C0=0, tail_C1=0, phase=1 + ph)
+            # FLOPs / bytes of the LOGICAL layer (3x3 over the upsampled tensor: what the roofline accounting quotes) shared by the four launches
+            self.ops.append(_Op(self.lib.pd_conv, a, "conv3x3", 2.0 * B * 4 * h * w * ch * ch * 9 / 4.0,
+                                (B * h * w * ch + B * 4 * h * w * ch) * esz / 4.0 + ch * ch * 4 * esz))
+        return y
 
     # pd_conv applies GroupNorm + SiLU while staging, once per 64-channel output tile; from this many output channels on
     # the input is normalised ONCE by pd_gn_apply instead and the convolution (and its weight gradient) runs without a prologue
@@ -788,7 +820,10 @@ class UNetPlan:
                     h = self._attn(f"up_blocks.{i}.attentions.{j}", h)
             if blk.upsamplers is not None:
                 s = w.samplers[f"up_blocks.{i}.upsamplers.0"]
-                hu, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+                if self._subpixel_up_ok(h):
+                    hu = self._upconv_subpixel(h, s)
+                else:
+                    hu, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
                 self.tape.append(SimpleNamespace(kind="up", name=f"up_blocks.{i}.upsamplers.0", x=h, out=hu, e=s))
                 h = hu
         g, be, eps = w.gn_out

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .packing import pack_conv_weight
+from .packing import pack_conv_weight, upsample_phase_weights
 from .training import mark_requires_grad_calls
 from .unet import UNetPlan, _Attention, _Block, _DT, _Op, _Sampler
 
@@ -331,6 +331,8 @@ class _VaeWeights:
                 self.attns[name] = e
             elif isinstance(r, _Sampler):
                 self.samplers[name] = SimpleNamespace(w=pk(r.conv.weight), b=f32(r.conv.bias), padding=r.padding)
+                if ".upsamplers." in name:      # Upsample2D as four 2x2 phase convolutions (UNetPlan._upconv_subpixel; inference plans)
+                    self.samplers[name].w4 = [pk(k) for k in upsample_phase_weights(r.conv.weight)]
 
 
 class _VaePlan(UNetPlan):
@@ -410,7 +412,10 @@ class VaeDecodePlan(_VaePlan):
                 h = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", h)
             if blk.upsamplers is not None:
                 s = w.samplers[f"decoder.up_blocks.{i}.upsamplers.0"]
-                h, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
+                if self._subpixel_up_ok(h):
+                    h = self._upconv_subpixel(h, s)
+                else:
+                    h, _ = self._conv(h, None, s.w, s.b, h.shape[3], upsample=1)
         g, be, eps = w.dec_gn
         gn = self._gn(h, None, g, be, eps)
         _, self._out_args = self._conv(h, None, w.dec_out_w, w.dec_out_b, c.out_channels, silu=1, gn=gn,

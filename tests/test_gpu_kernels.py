@@ -593,3 +593,48 @@ def test_conv3x3_with_fused_1x1_tail(env, mode, shape, plain):
     xcat = torch.cat([bf16_round(xa, mode)] + ([bf16_round(xb, mode)] if xb is not None else []), 1)
     ref = F.conv2d(hin, bf16_round(w2, mode), b2, padding=1) + F.conv2d(xcat, bf16_round(ws, mode), bs)
     assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 128, 96, 40, 72), (2, 32, 64, 9, 33)])
+def test_upsample_conv_as_four_subpixel_phases(env, mode, shape):
+    """Round 4: Upsample2D (F.interpolate(nearest x2) -> conv 3x3 pad 1; diffusers resnet.py, cond_unet_2d.py:200-228) as four 2x2
+    convolutions over the LOW-resolution tensor (pd_conv phase 1..4 with packing.upsample_phase_weights): every output pixel equals
+    the 3x3 convolution over the upsampled tensor (4 / 9 of its multiply-adds), the image border included (odd sizes, partial tiles),
+    and the four launches together leave the output's GroupNorm statistic tiles."""
+    from phendiff_amd.packing import upsample_phase_weights
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    B, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, cin, h, w_, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(F.interpolate(bf16_round(x, mode), scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    X = nhwc(x.to(dev), tdt)
+    y = torch.full((B, 2 * h, 2 * w_, cout), float("nan"), dtype=tdt, device=dev)
+    T = lib.pd_conv_stat_tiles(h, w_, 2, 1)
+    st = torch.full((B, 4 * T, cout, 2), float("nan"), device=dev)
+    bias = b.to(dev)
+    keep = []
+    for ph, k in enumerate(upsample_phase_weights(w)):
+        wp = pack(k, tdt).to(dev)
+        keep.append(wp)
+        a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=h, Wout=w_, C0=cin, C1=0, Cout=cout, Cout_pad=cout, ksize=2, stride=1, pad=0,
+                       upsample=0, silu=0, out_mode=0, heads=0, x0=X.data_ptr(), x1=None, scale=None, shift=None, w_packed=wp.data_ptr(),
+                       bias=bias.data_ptr(), temb=None, temb_stride=0, residual=None, y=y.data_ptr(), stats_out=st.data_ptr(), im2col3=0,
+                       phase=1 + ph)
+        L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+    torch.cuda.synchronize()
+    got = y.float().permute(0, 3, 1, 2)
+    assert bool(torch.isfinite(got).all())                      # every pixel of the upsampled tensor was written by exactly one phase
+    # (the phase weights are sums of up to four 16-bit-rounded taps: one rounding more than the 3x3 form)
+    assert rel(got, ref) < {"f32": 5e-6, "bf16": 8e-3, "fp16": 1e-3}[mode]
+    yc = got.cpu().double()
+    assert bool(torch.isfinite(st).all())
+    assert rel(st[..., 0].sum(1).cpu(), yc.sum((2, 3))) < 1e-4 and rel(st[..., 1].sum(1).cpu(), (yc * yc).sum((2, 3))) < 1e-4
+    # refused: a phase with a GroupNorm prologue / another kernel size / Hout != Hin
+    a.ksize = 3
+    assert lib.pd_conv(C.byref(a), stream()) != 0
+    a.ksize, a.Hout = 2, h + 1
+    assert lib.pd_conv(C.byref(a), stream()) != 0
