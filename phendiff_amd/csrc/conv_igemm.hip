@@ -1133,12 +1133,15 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
 #ifdef PD_STAMPS
 extern "C" int pd_debug_conv_occupancy(int lds_bytes) {
   int nb = -1;
-  auto kern = pd::conv_kernel<pd::bf16_t, 3, 1, 8, 32, true, false>;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, (size_t)lds_bytes);
-  hipFuncAttributes fa;
-  hipFuncGetAttributes(&fa, (const void*)kern);
-  printf("occupancy API: %d blocks/CU at %d B dyn LDS (err %d); numRegs %d sharedStatic %zu maxDyn %d\n", nb, lds_bytes, (int)e,
-         fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+  const void* kerns[2] = {(const void*)pd::conv_kernel<pd::bf16_t, 3, 1, 8, 32, true, false>,
+                          (const void*)pd::conv_kernel<pd::bf16_t, 3, 1, 8, 32, true, false, 1, true>};      // GroupNorm-prologue form; PLAIN (16x16x32, 160-byte pixels: 54 400 B)
+  for (int k = 0; k < 2; ++k) {
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kerns[k], 256, (size_t)lds_bytes);
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, kerns[k]);
+    printf("occupancy API (%s): %d blocks/CU at %d B dyn LDS (err %d); numRegs %d sharedStatic %zu maxDyn %d\n", k ? "PLAIN" : "GN", nb, lds_bytes, (int)e,
+           fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+  }
   hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
   printf("device: sharedMemPerBlock %zu sharedMemPerMultiprocessor %zu regsPerBlock %d CUs %d maxThreadsPerMP %d\n", pr.sharedMemPerBlock,
          pr.sharedMemPerMultiprocessor, pr.regsPerBlock, pr.multiProcessorCount, pr.maxThreadsPerMultiProcessor);
