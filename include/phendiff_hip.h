@@ -159,9 +159,9 @@ typedef struct {
   int im2col3;              /* 0, or n <= 3: x0 is an NCHW fp32 tensor with n channels (the UNet input sample) and the op is
                                the 3x3 pad-1 conv_in run as a 1x1 conv over 32 virtual channels k = ci*9 + ky*3 + kx
                                (ksize must be 1, C0 = 32, weights packed accordingly) */
-  int phase;                /* (ABI 4) 0: ordinary convolution.  1 + 2 a + b (a, b in {0, 1}): one PHASE of the sub-pixel form of Upsample2D
+  int phase;                /* (ABI 4) 0: ordinary convolution.  1 + 2 a + b (a, b = 0 or 1): one PHASE of the sub-pixel form of Upsample2D
                                (F.interpolate(x, 2.0, "nearest") then conv 3x3 pad 1, diffusers resnet.py; cond_unet_2d.py:200-228): output
-                               pixel (2 oy + a, 2 ox + b) of the y tensor [B][2 Hout][2 Wout][Cout] = sum over dy, dx in {0, 1} of
+                               pixel (2 oy + a, 2 ox + b) of the y tensor [B][2 Hout][2 Wout][Cout] = sum over dy, dx = 0, 1 of
                                W_ab[dy][dx] . x[oy - (1 - a) + dy][ox - (1 - b) + dx] (zero outside the image), W_ab = the 3x3 taps that
                                fall on the same source pixel summed (4 of the 9 tap positions per output pixel: 4 / 9 of the FLOPs).
                                Requires ksize = 2, stride 1, no upsample / GroupNorm / tail / residual, NHWC output, Hout = Hin,
