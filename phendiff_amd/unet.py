@@ -773,9 +773,8 @@ class UNetPlan:
         self._in_field = "x0"
         centered = None
         if c.center_input_sample:      # cond_unet_2d.py:272-273: sample = 2 * sample - 1.0 (before conv_in's zero padding)
-            if self.train:
-                raise NotImplementedError("the backward plan does not implement center_input_sample")
             centered = self._f32(B, c.in_channels, H, W)
+            self._centered = centered      # (training: conv_in's weight gradient reads THIS tensor; the input gradient is doubled)
             self._center_const = (torch.ones_like(centered), torch.full((B,), 2.0, device=self.device), torch.full((B,), -1.0, device=self.device))
             ones, two, neg = self._center_const
             ca = L.AddNoiseArgs(numel=centered.numel(), per_sample=centered[0].numel(), velocity=0, x=None, noise=ones.data_ptr(),

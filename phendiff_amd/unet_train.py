@@ -129,10 +129,10 @@ class UNetTrainPlan(UNetPlan):
         # the time-embedding chain (d proj -> time_emb_proj -> time_embedding MLP -> class table) runs iff one of its parameters trains
         self._temb_trains = self.param_grads and any(
             n not in self.frozen for n in (grads or {}) if ".time_emb_proj." in n or n.startswith("time_embedding.") or n == "class_embedding.weight")
-        if self.param_grads and getattr(w, "class_mode", None) is not None:
-            # class_embed_type "timestep" / "identity" (cond_unet_2d.py:146-153): inference plans only -- the class MLP / identity rows
-            # have no gradient launches (no shipped config sets them; every shipped config uses the nn.Embedding table or none)
-            raise NotImplementedError(f"the backward plan implements the nn.Embedding class table only (class_embed_type={w.class_mode!r})")
+        if self.param_grads and getattr(w, "class_mode", None) == "timestep":
+            # class_embed_type "timestep" (cond_unet_2d.py:146-153): inference plans only -- the class MLP has no gradient launches (no
+            # shipped config sets it).  "identity" trains: the rows are an INPUT (nn.Identity has no parameter, nothing to differentiate)
+            raise NotImplementedError(f"the backward plan implements the nn.Embedding class table and identity rows only (class_embed_type={w.class_mode!r})")
         self.dsample = self._f32(B, m.config.in_channels, H, W) if input_grad else None
         if self.param_grads:
             self._check_layout()
@@ -174,6 +174,12 @@ class UNetTrainPlan(UNetPlan):
         """One training forward: fp32 NCHW ``sample`` -> fp32 NCHW ``out``; keeps what ``backward`` needs."""
         a = self.temb_args
         a.rows = self.B
+        if getattr(self.w, "class_mode", None) == "identity":      # the "labels" ARE the embedding rows (temb_rows does the same)
+            if class_emb is None and labels is not None:
+                class_emb = labels.to(dtype=torch.float32).contiguous()
+            labels = None
+            if class_emb is not None and class_emb.numel() != self.B * self.m.time_embed_dim:
+                raise ValueError(f"class_embed_type='identity': {class_emb.numel()} elements for {self.B} rows of {self.m.time_embed_dim}")
         a.timesteps, a.labels, a.class_emb = timesteps.data_ptr(), L.ptr(labels), L.ptr(class_emb)
         a.emb, a.proj = self.t_emb.data_ptr(), self.temb_table.data_ptr()
         a.feat, a.z1 = self.t_feat.data_ptr(), self.t_z1.data_ptr()
@@ -181,8 +187,9 @@ class UNetTrainPlan(UNetPlan):
         a.feat, a.z1 = None, None
         self.run(sample.data_ptr(), self.temb_table.data_ptr(), out.data_ptr(), stream)
         self._labels = labels
+        src = getattr(self, "_centered", None)        # center_input_sample: what conv_in multiplied is 2 x - 1
         for args in self._sample_ptr_args:
-            args.x = sample.data_ptr()
+            args.x = src.data_ptr() if src is not None else sample.data_ptr()
         self.keepalive = (sample, timesteps, labels, class_emb, out)
 
     # ---- backward emitters -----------------------------------------------------------------------
@@ -458,6 +465,13 @@ class UNetTrainPlan(UNetPlan):
                 finally:
                     self.ops = ops
                 self.bwd_ops[-1].what = "dgrad3x3"
+                if getattr(self, "_centered", None) is not None:      # d (2 x - 1) / d x = 2 (cond_unet_2d.py:272-273)
+                    ones, two, _ = self._center_const
+                    zero = torch.zeros_like(two)
+                    self.bufs.append(zero)
+                    sa = L.AddNoiseArgs(numel=self.dsample.numel(), per_sample=self.dsample[0].numel(), velocity=0, x=self.dsample.data_ptr(),
+                                        noise=ones.data_ptr(), sa=two.data_ptr(), sb=zero.data_ptr(), out=self.dsample.data_ptr())
+                    self._b(self.lib.pd_add_noise, sa, "center_bwd", 0.0, 2.0 * self.dsample.numel() * 4)
             if not self.param_grads:
                 return
             self._bias_grad(dout, G("conv_in.bias"))
@@ -572,7 +586,7 @@ class UNetTrainPlan(UNetPlan):
                 db=G(first + ".time_emb_proj.bias", [r + ".time_emb_proj.bias" for r in res[1:]]).data_ptr()), "linear_wgrad")
         self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=pd, dy=self.dproj.data_ptr(),
                 w=P[first + ".time_emb_proj.weight"].data_ptr(), pre=self.t_emb.data_ptr(), dx=demb.data_ptr()), "linear_dgrad")
-        if getattr(m, "class_embedding", None) is not None and "class_embedding.weight" not in self.frozen:
+        if getattr(getattr(m, "class_embedding", None), "weight", None) is not None and "class_embedding.weight" not in self.frozen:
             self._emb_grad_args = L.EmbeddingGradArgs(rows=B, dim=tdim, num_classes=m.class_embedding.weight.shape[0], labels=None,
                                                       d=demb.data_ptr(), dtable=G("class_embedding.weight").data_ptr())
             self._emb_grad_at = len(self.bwd_ops)
@@ -834,6 +848,8 @@ class UNetTrainer:
         st = torch.cuda.current_stream(self.device).cuda_stream
         x = noisy.contiguous().float()
         ts = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
+        if getattr(plan.w, "class_mode", None) == "identity" and class_emb is None and class_labels is not None:
+            class_emb, class_labels = class_labels, None          # class_embed_type = "identity": the "labels" are the embedding rows
         labels = class_labels.to(device=self.device, dtype=torch.int64).contiguous() if class_labels is not None else None
         cemb = class_emb.to(device=self.device, dtype=torch.float32).contiguous() if class_emb is not None else None
         self._cond = labels is not None        # the class table has a gradient only when the labels went through it

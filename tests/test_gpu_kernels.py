@@ -629,7 +629,7 @@ def test_upsample_conv_as_four_subpixel_phases(env, mode, shape):
     got = y.float().permute(0, 3, 1, 2)
     assert bool(torch.isfinite(got).all())                      # every pixel of the upsampled tensor was written by exactly one phase
     # (the phase weights are sums of up to four 16-bit-rounded taps: one rounding more than the 3x3 form)
-    assert rel(got, ref) < {"f32": 5e-6, "bf16": 8e-3, "fp16": 1e-3}[mode]
+    assert rel(got, ref) < {"f32": 2e-6, "bf16": 5e-3, "fp16": 6e-4}[mode]      # measured 5.2e-7 / 2.1e-3 / 2.6e-4 (profiles/r4_parity_errors.json)
     yc = got.cpu().double()
     assert bool(torch.isfinite(st).all())
     assert rel(st[..., 0].sum(1).cpu(), yc.sum((2, 3))) < 1e-4 and rel(st[..., 1].sum(1).cpu(), (yc * yc).sum((2, 3))) < 1e-4

@@ -383,11 +383,11 @@ def test_linear_gemm_groupnorm_folded_into_per_sample_weights(env, mode, shape):
         a.fold_ws, a.fold_ws_bytes = (ws.data_ptr(), need) if route == "folded" else (None, 0)
         L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
         torch.cuda.synchronize()
-        assert rel(y.float(), ref) < 6e-3 if mode == "bf16" else rel(y.float(), ref) < 8e-4, route
+        assert rel(y.float(), ref) < (5e-3 if mode == "bf16" else 6e-4), route      # measured 2.2e-3 / 2.8e-4
         want = (y[1].float() ** 2).sum(-1).amax(-1)                           # the bound is over the key rows AS STORED
         assert torch.allclose(kmax2, want, rtol=1e-5, atol=0), route
         outs[route] = y.float()
-    assert rel(outs["folded"], outs["staged"]) < (8e-3 if mode == "bf16" else 1.2e-3)
+    assert rel(outs["folded"], outs["staged"]) < (6e-3 if mode == "bf16" else 8e-4)      # measured 2.8e-3 / 3.5e-4
     # a workspace that is too small is not used (the staged route answers), a tile that would straddle samples has no folded route
     a.fold_ws_bytes = need - 1
     L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")

@@ -229,7 +229,7 @@ def test_sd_ddib_graph_replays_the_eager_transfer_bit_for_bit(mode):
 
 
 # ---- gradient-guided transfer, latent-diffusion branch (utils_Img2Img.py:651-760 with a CustomStableDiffusionImg2ImgPipeline) ----------
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2)])      # measured 2.4e-6 / 1.2e-2
 def test_sd_guidance_gradient_through_unet_matches_autograd(mode, tol):
     """d Lp(x0_pred, target) / d latents through the SD UNet (input-gradient-only backward plan) and the scheduler's x0 formula, one
     step: what ``torch.autograd.grad(losses_seq, images)`` returns with ``pipe.unet(images, t, target_class_embeds)`` (:718-745)."""
@@ -274,7 +274,7 @@ def test_sd_guidance_gradient_through_unet_matches_autograd(mode, tol):
     assert rel(d_dir + plan.dsample, want) < tol
 
 
-@pytest.mark.parametrize("mode,tol_lat,tol_img", [("f32", 2e-3, 2e-3), ("bf16", 8e-2, 1e-1)])
+@pytest.mark.parametrize("mode,tol_lat,tol_img", [("f32", 5e-5, 2e-4), ("bf16", 8e-2, 1e-1)])
 def test_sd_gradient_guided_transfer_matches_golden(mode, tol_lat, tol_img):
     """_linear_interp_custom_guidance_inverted_start with the latent-diffusion pipeline, end to end, against the committed oracle
     vectors (tests/golden/make_golden.py --sd-guided: tiny stack, 32x32 images = 16x16 latents, S = 3, p = 2, loss scale 0.5 -- raised

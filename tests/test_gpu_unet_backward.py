@@ -66,6 +66,48 @@ def test_unet_backward_matches_autograd(mode, per_tol, glob_tol, size):
 
 
 @pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 2e-4, 2e-5), ("bf16", 8e-2, 2e-2)])
+def test_centered_input_and_identity_class_rows_train(mode, per_tol, glob_tol):
+    """Two config switches no shipped JSON sets but `CustomCondUNet2DModel` accepts (cond_unet_2d.py:146-153,272-273), in the training
+    plan: center_input_sample (conv_in multiplies 2 x - 1: its weight gradient reads the centred tensor, the input gradient is doubled)
+    and class_embed_type = "identity" (the "labels" are embedding rows: an input, no class parameter).  Parameter gradients and
+    d loss / d sample against torch.autograd over the oracle."""
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef
+    from phendiff_amd.unet_train import UNetTrainer
+    torch.manual_seed(0)
+    cfg = dict(P.UNET_CONFIGS["super_small"], sample_size=32, center_input_sample=True, class_embed_type="identity", num_class_embeds=None)
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    r = CondUNet2DRef(**{k: v for k, v in cfg.items() if k in keys}).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype=mode, **cfg)
+    m.load_state_dict(r.state_dict())
+    m = m.to("cuda:0")
+    sched, clean, noise, ts, _, noisy, target = batch(3, 32)
+    rows = torch.randn(3, m.time_embed_dim, generator=torch.Generator().manual_seed(9))
+    x = noisy.clone().requires_grad_(True)
+    for p in r.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    out = r(x, ts, class_labels=rows).sample
+    loss_ref = torch.nn.functional.mse_loss(out, target)
+    loss_ref.backward()
+    ref = {n: p.grad.clone() for n, p in r.named_parameters()}
+    tr = UNetTrainer(m, sched, lr=1e-4, use_ema=False)
+    loss, _ = tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=rows.cuda())
+    torch.cuda.synchronize()
+    assert set(ref) == set(tr.grads) and abs(float(loss) - float(loss_ref.detach())) < (1e-5 if mode == "f32" else 5e-3) * float(loss_ref.detach())
+    compare(ref, tr.grads, per_tol, glob_tol)
+    # the input gradient (what the gradient-guided transfer differentiates): d loss / d sample = 2 x d loss / d (2 x - 1)
+    plan = m.input_grad_plan(3, 32, 32, torch.device("cuda:0"))
+    st = torch.cuda.current_stream().cuda_stream
+    o = torch.empty(3, 3, 32, 32, device="cuda:0")
+    plan.forward(noisy.cuda().contiguous(), ts.cuda().float(), None, rows.cuda().contiguous(), o, st)
+    dout = (2.0 / o.numel()) * (o - target.cuda())
+    plan.backward(dout.contiguous(), st)
+    torch.cuda.synchronize()
+    assert rel(plan.dsample, x.grad) < (2e-5 if mode == "f32" else 4e-2)
+
+
+@pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 2e-4, 2e-5), ("bf16", 8e-2, 2e-2)])
 def test_orig_google_ddpm_backward_matches_autograd(mode, per_tol, glob_tol):
     """models_configs/denoiser/orig_google_ddpm_model_denoiser.json trains too (VERDICT r2 missing 3: the reference trains whatever
     config it loads, utils_models.py:158-182, train.py:180-182): gradients of all its parameters at 64x64 against torch.autograd --
@@ -259,7 +301,7 @@ def _pipes(mode, size=32):
     return (ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**cfg)), P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**cfg)))
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 4e-2)])      # measured 4.2e-6 / 1.7e-2 (profiles/r4_parity_errors.json)
 @pytest.mark.parametrize("p", [2, 1.5])
 def test_guidance_gradient_through_unet_matches_autograd(mode, tol, p):
     """d Lp(x0_pred, target) / d image through the UNet and the scheduler's x0 formula (clipped), one step
