@@ -739,6 +739,7 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
   using E = Elem<T>;
   using Frag = typename E::Frag;
   static_assert(CK == 64 || CK == 32, "K chunk");
+  static_assert(NC != 5 || (!GLU && !QKV && CK == 64), "the 320-channel tile: plain projections, 64-channel K chunks");
   constexpr int ES = 2, TM = 256, TN = 64 * NC;
   constexpr int KSC = CK / 16;                           // k-steps per chunk
   constexpr int RPP = 1024 / (CK * ES);                  // token rows per 1-KiB DMA piece (8 / 16)
@@ -861,6 +862,58 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
   __syncthreads();                                       // every wave is done with the last buffer: the epilogue reuses the LDS
 
   // ---- epilogue: [token][TN channels] through LDS, then coalesced 16-byte residual loads / stores
+  if constexpr (NC == 5) {
+    // 320-channel tile (round 4: the SD UNet's narrowest level, N = 320 -- the 128- / 256-channel tiles computed 384 / 512 of them and
+    // re-staged the token tile per column tile): the [256][320] output tile is 164 KB, more than the LDS holds, so the two token halves
+    // go through the staging area one after the other; pieces are dealt to the 512 threads by their flat index (40 pieces per token)
+    constexpr int PPT5 = TN / 8, NIT5 = (TM / 2) * PPT5 / 512;
+    static_assert((TM / 2) * PPT5 % 512 == 0, "piece map");
+    const unsigned ybytes5 = (unsigned)min((unsigned long long)p.M * p.N * ES, 0xffffffffull);
+    const __amdgpu_buffer_rsrc_t ry5 = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes5, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr5 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.y), 0, p.residual ? ybytes5 : 0u, 0x00020000);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if ((wt >> 1) == pass) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const int tok = (wt & 1) * 64 + f * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              store4((T*)(lds + tok * EP_PITCH) + (wc * NC + c) * 32 + 8 * g + 4 * h, acc[c][f][4 * g], acc[c][f][4 * g + 1], acc[c][f][4 * g + 2],
+                     acc[c][f][4 * g + 3]);
+          }
+      }
+      __syncthreads();
+      u32x4 res5[NIT5];
+      unsigned off5[NIT5];
+#pragma unroll
+      for (int it = 0; it < NIT5; ++it) {
+        const int q = it * 512 + tid, tok = q / PPT5, piece = q - tok * PPT5;
+        const long long m = m0 + pass * (TM / 2) + tok;
+        const int co = n0 + piece * 8;
+        off5[it] = (m < p.M && co < p.N) ? (unsigned)(((size_t)m * p.N + co) * ES) : OOB_OFF;
+        res5[it] = __builtin_amdgcn_raw_buffer_load_b128(rr5, off5[it], 0, 0);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT5; ++it) {
+        const int q = it * 512 + tid, tok = q / PPT5, piece = q - tok * PPT5;
+        u32x4 v = *(const u32x4*)(lds + tok * EP_PITCH + piece * 16);
+        if (p.residual) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float lo, hi, rl, rh;
+            Pack16<T>::unpack(v[j], lo, hi); Pack16<T>::unpack(res5[it][j], rl, rh);
+            v[j] = Pack16<T>::pack(lo + rl, hi + rh);
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, ry5, off5[it], 0, 0);
+      }
+      if (pass == 0) __syncthreads();                    // the second half overwrites the staging area
+    }
+    return;
+  }
   if constexpr (GLU) {
 #pragma unroll
     for (int u = 0; u < NC / 2; ++u)
@@ -961,7 +1014,7 @@ __global__ __launch_bounds__(512, (CK == 32 && NC == 2) ? 4 : 2) void linear_dma
 template <typename T, int NC, bool GLU, int CK, bool QKV = false>
 static int launch_linear_dma(const LinP& p, hipStream_t st) {
   constexpr int BUF = 256 * CK * 2 + 2 * NC * (CK / 16) * 1024, NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
-  constexpr int MAIN = NBUF * BUF, EPI = 256 * (64 * NC * 2 + 16) + (QKV ? 64 * NC / 8 * 4 : 0);     // QKV: + the per-head key maxima
+  constexpr int MAIN = NBUF * BUF, EPI = (NC == 5 ? 128 : 256) * (64 * NC * 2 + 16) + (QKV ? 64 * NC / 8 * 4 : 0);     // QKV: + the per-head key maxima; NC = 5: two token halves in turn
   constexpr int LDS = MAIN > EPI ? MAIN : EPI;
   auto kern = linear_dma_kernel<T, NC, GLU, CK, QKV>;
   static bool attr_set = false;
@@ -1012,6 +1065,7 @@ __global__ __launch_bounds__(256) void linear_fold_gn_kernel(const T* w, const f
 
 template <typename T>
 static int dispatch_linear_dma(const LinP& p, int variant, bool glu, hipStream_t st) {   // variant: 2 = (NC 2, CK 64), 3 = (NC 2, CK 32), 4 = (NC 4, CK 64)
+  if (variant == 5) return launch_linear_dma<T, 5, false, 64>(p, st);      // (never with the fused GEGLU: chosen for plain N_pad = 320 k only)
   if (variant == 4) return glu ? launch_linear_dma<T, 4, true, 64>(p, st) : launch_linear_dma<T, 4, false, 64>(p, st);
   if (variant == 3) return glu ? launch_linear_dma<T, 2, true, 32>(p, st) : launch_linear_dma<T, 2, false, 32>(p, st);
   return glu ? launch_linear_dma<T, 2, true, 64>(p, st) : launch_linear_dma<T, 2, false, 64>(p, st);
@@ -1115,11 +1169,18 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
       //   32^2 qkv 640->1920 .111/.129/.100/.109  out .045/.045/.039/.048            ff1+glu .261/.306/.255/.269            ff2 2560->640 .145/.144/.132/.151
       //   16^2 qkv 1280->3840 .100/.114/.100/.093 out .042/.051/.043/.044            ff1+glu .241/.263/.232/.223            ff2 5120->1280 .143/.173/.148/.142
       // -> 256-channel tiles for wide outputs (N >= 960; behind the fused GEGLU only at K >= 1280), else the two-workgroups-per-CU form
+      // round 4, 320-channel tiles (NC = 5; every SD-2.1 width is a multiple of 320): same box, B = 32, ms (variant 3 / 4 / 5):
+      //   64^2 qkv .153/.140/.130  out .047/.064/.045  ff2 1280->320 .157/.182/.121 (888 TF/s)     32^2 qkv .102/.103/.099  out .039/.049/.036  ff2 2560->640 .124/.144/.107
+      //   16^2 qkv .094/.095/.104  out .044/.044/.051  ff2 .149/.142/.159 -> from 32 768 tokens up, with at least one workgroup per CU (not behind the fused GEGLU:
+      //   its (value, gate) tiles pair up inside a wave).  PD_LIN_NC5=0: diagnostic override (same-box A/B)
+      static const bool nc5_off = getenv("PD_LIN_NC5") && atoi(getenv("PD_LIN_NC5")) == 0;
+      const bool can5 = !glu && a->N_pad % 320 == 0 && a->N == a->N_pad;
       if (dma_env >= 2 && dma_env <= 4) nc = dma_env;
+      else if (dma_env == 5 ? can5 : (can5 && !nc5_off && t256 >= 128 && (long long)t256 * (a->N_pad / 320) >= 256)) nc = 5;
       else if ((long long)t256 * c4 >= 256 && waste4_ok && a->N_pad >= 960 && (!glu || a->K >= 1280)) nc = 4;
       else if ((long long)t256 * c2 >= 256) nc = 3;
       if (nc) {
-        p.t_tiles = t256; p.c_tiles = nc == 4 ? c4 : c2;
+        p.t_tiles = t256; p.c_tiles = nc == 5 ? a->N_pad / 320 : (nc == 4 ? c4 : c2);
         p.xbytes = (unsigned)xbytes; p.x = a->x; p.w = a->w_packed; p.bias = a->bias; p.residual = a->residual; p.y = a->y;
         hipStream_t st = (hipStream_t)stream;
         return a->dtype == PD_F16 ? dispatch_linear_dma<half_t>(p, nc, glu, st) : dispatch_linear_dma<bf16_t>(p, nc, glu, st);

@@ -206,7 +206,10 @@ def test_geglu_backward(env, mode):
                                  (4096, 96, 320, 1, 32), (130, 32, 8, 0, 0), (65536 + 70, 128, 512, 1, 0),
                                  # round 3: shapes the 16-bit engines run on the DMA-staged 256-token kernel (linear_dma_kernel) -- NC = 2
                                  # with a ragged 128-channel tile and ragged tokens, one K chunk, a strided input, NC = 4 at K = 1280
-                                 (32768 + 5, 320, 320, 1, 0), (70000, 64, 1280, 0, 0), (33000, 192, 384, 1, 64), (65536, 1280, 1280, 1, 0)])
+                                 (32768 + 5, 320, 320, 1, 0), (70000, 64, 1280, 0, 0), (33000, 192, 384, 1, 64), (65536, 1280, 1280, 1, 0),
+                                 # round 4: N = 320 with >= 256 token tiles -> the 320-channel tile (NC = 5, two-pass epilogue): ragged tokens + residual,
+                                 # one-chunk-deep K with a strided input, no residual
+                                 (65536 + 37, 1280, 320, 1, 0), (70000, 320, 320, 1, 64), (65536, 64, 320, 0, 0)])
 def test_linear_gemm(env, mode, cfg):
     """pd_linear against F.linear: full / ragged token tiles, K with a trailing half chunk (96, 32), N not a multiple of the
     128-channel tile, residual, strided input rows (a slice of a fused projection's output).  The (2048, 1280, 10240) and the
