@@ -31,8 +31,8 @@ extern "C" {
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
  * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
  * fold_ws_bytes + pd_linear_fold_workspace,
- * pd_conv_args.phase). */
-#define PD_ABI_VERSION 4
+ * pd_conv_args.phase); 5 = pd_conv_args.phase_in. */
+#define PD_ABI_VERSION 5
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
@@ -167,6 +167,12 @@ typedef struct {
                                Requires ksize = 2, stride 1, no upsample / GroupNorm / tail / residual, NHWC output, Hout = Hin,
                                Wout = Win; `pad` is ignored.  stats_out is then [B][4 T][Cout][2], T = pd_conv_stat_tiles(Hout, Wout, 2, 1):
                                phase p's tiles fill slots (p - 1) T .. p T - 1 */
+  int phase_in;             /* (ABI 5) with phase = 1 + 2 a + b: the phase selects INPUT pixels instead of output pixels -- the input
+                               gradient of a sub-pixel phase: x0 is [B][2 Hin][2 Win][C0] (the gradient of the upsampled output), the
+                               launch reads its pixels (2 iy + a, 2 ix + b) and writes the dense y [B][Hout][Wout][Cout], Hout = Hin,
+                               Wout = Win: y[oy][ox] (+= residual) = sum over dy, dx = 0, 1 of W[dy][dx] . x0[2 (oy - a + dy) + a][2 (ox - b + dx) + b]
+                               (W = the phase's 2x2 weights packed as input-gradient weights: transposed, taps flipped).  residual is
+                               allowed (the four phases accumulate into one gradient tensor); no stats_out */
 } pd_conv_args;
 int pd_conv(const pd_conv_args* a, void* stream);
 /* number of statistic tiles per sample pd_conv writes for this shape (depends on the kernel's tile choice) */

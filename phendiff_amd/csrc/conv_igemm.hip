@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   // (Downsample2D(padding=0)'s (0,1,0,1)-padded forward)
   const int ups = p.upsample ? 1 : 0;                     // source coordinate = conv coordinate >> ups
   const int ph_mask = p.upsample >= 2 ? 1 : 0, ph_want = p.upsample == 3 ? 1 : 0;   // zero-stuffing: both coordinates' low bit must equal ph_want
-  const int iy_base = y0 * STRIDE - p.pad, ix_base = x0 * STRIDE - p.pad_x, n_base = n * p.Hin;
+  // (input-side phase, pd_conv_args.phase_in: the source is in_step times as large and the launch reads its pixels
+  // (in_step iy + in_oy, in_step ix + in_ox); in_step = 1, offsets 0 otherwise)
+  const int istep = p.in_step, Ws = p.Win * istep;
+  const int iy_base = y0 * STRIDE - p.pad, ix_base = x0 * STRIDE - p.pad_x, n_base = n * p.Hin * istep + p.in_oy;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int pix = (tid + 256 * i) >> 2;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
     const int iy = iy_base + u, ix = ix_base + vv;
     const bool ok = (pix < NPIX) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc)
                     & (((iy & ph_mask) == (ph_want & ph_mask)) & ((ix & ph_mask) == (ph_want & ph_mask)));
-    int v = (n_base + (iy >> ups)) * p.Win + (ix >> ups);
+    int v = (n_base + (iy >> ups) * istep) * Ws + (ix >> ups) * istep + p.in_ox;
     // fused 1x1 tail: its chunks multiply the CENTRE tap only, so they need the tile's own pixels, not the halo ring around them
     // (a third more pixels: 10 x 34 against 8 x 32) -- bit 30 marks the pixels a tail chunk loads (an index is < 2^26: the tensors
     // are < 2 GiB at >= 64 bytes per pixel)
@@ -1065,12 +1068,13 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   PD_CHECK((a->C1 == 0) == (a->x1 == nullptr), PD_ERR_ARG, "pd_conv: x1/C1 mismatch");
   PD_CHECK((a->scale == nullptr) == (a->shift == nullptr), PD_ERR_ARG, "pd_conv: scale/shift mismatch");
   PD_CHECK(a->phase >= 0 && a->phase <= 4, PD_ERR_ARG, "pd_conv: phase %d", a->phase);
+  PD_CHECK(a->phase_in == 0 || (a->phase_in == 1 && a->phase), PD_ERR_ARG, "pd_conv: phase_in %d without a phase", a->phase_in);
   if (a->phase) {
-    PD_CHECK(a->ksize == 2 && a->stride == 1 && !a->upsample && !a->scale && !a->silu && !a->tail_x0 && !a->im2col3 && !a->residual &&
-             a->out_mode == PD_OUT_NHWC && a->Hout == a->Hin && a->Wout == a->Win && a->C1 == 0, PD_ERR_UNSUPPORTED,
-             "pd_conv: a sub-pixel phase is a plain 2x2 convolution over one source with Hout = Hin, Wout = Win and NHWC output");
-    PD_CHECK((size_t)a->B * a->Hout * a->Wout * 4 * a->Cout * (a->dtype == PD_F32 ? 4 : 2) < 0x80000000ull, PD_ERR_SHAPE,
-             "pd_conv: the upsampled NHWC output exceeds 2 GiB (32-bit buffer offsets); split the batch");
+    PD_CHECK(a->ksize == 2 && a->stride == 1 && !a->upsample && !a->scale && !a->silu && !a->tail_x0 && !a->im2col3 && (!a->residual || a->phase_in) &&
+             a->out_mode == PD_OUT_NHWC && a->Hout == a->Hin && a->Wout == a->Win && a->C1 == 0 && !(a->phase_in && a->stats_out), PD_ERR_UNSUPPORTED,
+             "pd_conv: a sub-pixel phase is a plain 2x2 convolution over one source with Hout = Hin, Wout = Win and NHWC output (residual only with phase_in, statistics only without)");
+    PD_CHECK((size_t)a->B * a->Hout * a->Wout * 4 * (a->phase_in ? a->C0 : a->Cout) * (a->dtype == PD_F32 ? 4 : 2) < 0x80000000ull, PD_ERR_SHAPE,
+             "pd_conv: the upsampled NHWC tensor exceeds 2 GiB (32-bit buffer offsets); split the batch");
   }
   PD_CHECK(a->ksize == 1 || a->ksize == 3 || (a->ksize == 2 && a->phase), PD_ERR_UNSUPPORTED, "pd_conv: ksize %d", a->ksize);
   PD_CHECK(a->stride == 1 || (a->stride == 2 && a->ksize == 3), PD_ERR_UNSUPPORTED, "pd_conv: stride %d", a->stride);
@@ -1101,7 +1105,7 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
     PD_CHECK(a->tail_C0 == 0 && a->tail_C1 == 0 && a->tail_x1 == nullptr, PD_ERR_ARG, "pd_conv: tail_C without tail_x0");
   }
   const size_t esz = a->dtype == PD_F32 ? 4 : 2;
-  const size_t bytes0 = (size_t)a->B * a->Hin * a->Win * a->C0 * esz, bytes1 = (size_t)a->B * a->Hin * a->Win * a->C1 * esz;
+  const size_t bytes0 = (size_t)a->B * a->Hin * a->Win * a->C0 * esz * (a->phase_in ? 4 : 1), bytes1 = (size_t)a->B * a->Hin * a->Win * a->C1 * esz;
   PD_CHECK(bytes0 < 0x80000000ull && bytes1 < 0x80000000ull, PD_ERR_SHAPE,
            "pd_conv: source tensor exceeds 2 GiB (32-bit buffer offsets); split the batch");
   PD_CHECK(a->out_mode != PD_OUT_NHWC || (size_t)a->B * a->Hout * a->Wout * a->Cout * esz < 0x80000000ull, PD_ERR_SHAPE,
@@ -1120,11 +1124,15 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.w = a->w_packed; p.bias = a->bias;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.residual = a->residual; p.y = a->y;
   p.stats = a->stats_out; p.im2col3 = a->im2col3 ? 1 : 0; p.C0r = a->im2col3;
-  p.pad_x = a->pad; p.out_step = 1;
+  p.pad_x = a->pad; p.out_step = 1; p.in_step = 1;
   if (a->phase) {          // phase 1 + 2 a + b: rows start at oy - (1 - a), columns at ox - (1 - b)
     const int pa = (a->phase - 1) >> 1, pb = (a->phase - 1) & 1;
-    p.pad = 1 - pa; p.pad_x = 1 - pb; p.out_step = 2; p.out_oy = pa; p.out_ox = pb;
-    p.stat_tiles = 4; p.stat_tile_base = a->phase - 1;        // (launch_conv scales both by the tiles per phase)
+    if (a->phase_in) {     // input gradient of that phase: dense output, rows start at oy - a in the phase's sub-image of the source
+      p.pad = pa; p.pad_x = pb; p.in_step = 2; p.in_oy = pa; p.in_ox = pb;
+    } else {
+      p.pad = 1 - pa; p.pad_x = 1 - pb; p.out_step = 2; p.out_oy = pa; p.out_ox = pb;
+      p.stat_tiles = 4; p.stat_tile_base = a->phase - 1;        // (launch_conv scales both by the tiles per phase)
+    }
   }
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == PD_F32) return dispatch_conv<float>(p, a->ksize, a->stride, st);

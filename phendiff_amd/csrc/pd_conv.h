@@ -28,6 +28,8 @@ struct ConvP {
   // sub-pixel phase of an upsampling convolution (pd_conv_args.phase): column padding separate from the row padding, output pixel
   // (out_step oy + out_oy, out_step ox + out_ox) of a tensor out_step times as large, statistic tiles at stat_tile_base of stat_tiles
   int pad_x, out_step, out_oy, out_ox, stat_tile_base, stat_tiles;
+  // input-side phase (pd_conv_args.phase_in): source pixel (in_step iy + in_oy, in_step ix + in_ox) of a tensor in_step times as large
+  int in_step, in_oy, in_ox;
 };
 
 }  // namespace pd

@@ -32,23 +32,23 @@ def dgrad_weight(w: torch.Tensor) -> torch.Tensor:
     return w.permute(1, 0, 2, 3).flip(2, 3).contiguous()
 
 
+def upsample_phase_weights_stacked(w: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``[4][Cout][Cin][2][2]`` fp32: the four phase kernels of :func:`upsample_phase_weights` stacked (phase 2 a + b), formed by ONE
+    contraction on the weight's device -- R_a w R_b^T with R_0 = [[1,0,0],[0,1,1]] (taps {0 | 1+2}), R_1 = [[1,1,0],[0,0,1]] ({0+1 | 2}) --
+    so that the training re-pack can refresh them every step (``out``: a persistent buffer the pack jobs read)."""
+    assert w.ndim == 4 and w.shape[2:] == (3, 3)
+    R = torch.tensor([[[1., 0., 0.], [0., 1., 1.]], [[1., 1., 0.], [0., 0., 1.]]], dtype=torch.float32, device=w.device)
+    k = torch.einsum("auy,oiyx,bvx->aboiuv", R, w.detach().float(), R).reshape(4, w.shape[0], w.shape[1], 2, 2)
+    if out is not None:
+        out.copy_(k)
+        return out
+    return k.contiguous()
+
+
 def upsample_phase_weights(w: torch.Tensor):
     """The sub-pixel form of ``F.interpolate(x, scale_factor=2, mode="nearest")`` followed by a 3x3 pad-1 convolution (diffusers
     ``Upsample2D``): output pixel (2y + a, 2x + b) only sees the 2x2 block of LOW-resolution pixels rows y - (1 - a) .. +1,
     columns x - (1 - b) .. +1, each through the sum of the 3x3 taps that land on it.  Returns the four 2x2 kernels
     ``[W_00, W_01, W_10, W_11]`` (``W_ab``: OI22, fp32) for ``pd_conv(phase = 1 + 2 a + b)`` -- 4 / 9 of the multiply-adds of the
     convolution over the upsampled tensor, the same function of the weights (sums formed in fp32 before the 16-bit rounding)."""
-    assert w.ndim == 4 and w.shape[2:] == (3, 3)
-    w = w.detach().float()
-    taps = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # phase -> (3x3 taps on source offset 0, on source offset 1)
-    out = []
-    for a in (0, 1):
-        for b in (0, 1):
-            k = torch.zeros(w.shape[0], w.shape[1], 2, 2, dtype=torch.float32, device=w.device)
-            for dy in (0, 1):
-                for dx in (0, 1):
-                    for ky in taps[a][dy]:
-                        for kx in taps[b][dx]:
-                            k[:, :, dy, dx] += w[:, :, ky, kx]
-            out.append(k)
-    return out
+    return list(upsample_phase_weights_stacked(w))

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .packing import pack_conv_weight, upsample_phase_weights
+from .packing import pack_conv_weight, upsample_phase_weights_stacked
 from .training import mark_requires_grad_calls
 from .unet import UNet2DOutput, UNetPlan, _Block, _DT, _Op, _Resnet, _Sampler, _TimestepEmbedding
 
@@ -334,7 +334,9 @@ class _SDPackedWeights:
             elif isinstance(r, _Sampler):
                 self.samplers[name] = SimpleNamespace(w=pk(r.conv.weight), b=f32(r.conv.bias), padding=r.padding)
                 if ".upsamplers." in name:      # Upsample2D as four 2x2 phase convolutions (UNetPlan._upconv_subpixel; inference plans)
-                    self.samplers[name].w4 = [pk(k) for k in upsample_phase_weights(r.conv.weight)]
+                    # (w4_src: the four fp32 phase kernels stacked on the device; the fine-tuning re-pack refreshes them every step)
+                    self.samplers[name].w4_src = upsample_phase_weights_stacked(r.conv.weight.detach().to(device=dev, dtype=torch.float32))
+                    self.samplers[name].w4 = tuple(pk(self.samplers[name].w4_src[p]) for p in range(4))
         self.proj_dim = off
         self.wpT = f32(torch.cat(proj_w, 0).t())
         self.bp = f32(torch.cat(proj_b, 0))

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib as L
-from .packing import dgrad_weight, pack_conv_weight
+from .packing import dgrad_weight, pack_conv_weight, upsample_phase_weights_stacked
 from .sd_unet import (CustomEmbedding, SDUNet2DConditionModel, SDUNetPlan, _SDPackedWeights, _Transformer2D,
                       class_emb_to_encoder_hidden_states)
 from .unet import _Resnet, _Sampler, _copy_into
@@ -272,7 +272,7 @@ class _SDRepacker:
 
     def __init__(self, m: SDUNet2DConditionModel, w: _SDPackedWeights, tw: SDTrainWeights):
         self.lib = L.lib()
-        self.jobs, self.small = [], []
+        self.jobs, self.small, self.pre = [], [], []
         self.jobs_device = m.conv_in.weight.device
         code = w.code
 
@@ -329,6 +329,11 @@ class _SDRepacker:
             elif isinstance(mod, _Sampler):
                 ch = mod.conv.weight.shape[0]
                 both(w.samplers[name].w, tw.samplers[name].wd, mod.conv.weight, ch, ch, 3)
+                if getattr(w.samplers[name], "w4_src", None) is not None:      # the inference plans' sub-pixel phase kernels follow the weights too
+                    src4, wt = w.samplers[name].w4_src, mod.conv.weight
+                    self.pre.append(lambda src4=src4, wt=wt: upsample_phase_weights_stacked(wt.data, out=src4))
+                    for p in range(4):
+                        job(w.samplers[name].w4[p], src4[p], ch, ch, 2)
         co, cc = m.conv_out.weight.shape[0], m.conv_out.weight.shape[1]
         job(w.conv_out_w, m.conv_out.weight, co, cc, 3, cout_pad=w.conv_out_pad)
         job(tw.conv_out_d, m.conv_out.weight, cc, co, 3, dgrad=1, cin_pad=w.conv_out_pad)
@@ -351,6 +356,9 @@ class _SDRepacker:
                                    "after the parameters were moved into the flat training buffer)")
 
     def run(self, stream):
+        with torch.no_grad():
+            for f in self.pre:
+                f()
         run_pack_jobs(self.lib, self.jobs, stream, self.__dict__.setdefault("_batch", {}), self.jobs_device)
         with torch.no_grad():
             for f in self.small:

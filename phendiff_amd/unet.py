@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .packing import pack_conv_weight, upsample_phase_weights
+from .packing import pack_conv_weight, upsample_phase_weights, upsample_phase_weights_stacked
 from .training import mark_requires_grad_calls
 
 # compute_dtype -> (pd_dtype, storage dtype).  "fp16": the reference's `--mixed_precision fp16` (args_parser.py:381-390; img2img_comparison.py:57):
@@ -412,8 +412,10 @@ class _PackedWeights:
             e.w, e.b, e.padding = self._pack(s.conv.weight), f32(s.conv.bias), s.padding
             if ".upsamplers." in name:
                 # Upsample2D as four 2x2 convolutions over the low-resolution tensor (pd_conv phase 1..4): 4 / 9 of the FLOPs of the 3x3
-                # convolution over the nearest-upsampled tensor (inference plans; the training plans keep the 3x3 form their backward reads)
-                e.w4 = [self._pack(k) for k in upsample_phase_weights(s.conv.weight)]
+                # convolution over the nearest-upsampled tensor (round 4: the training plans too -- their input gradient runs the four phases backwards, pd_conv phase_in; the weight gradient stays on the 3x3 form)
+                # (w4_src: the four fp32 phase kernels stacked, on the device -- the training re-pack refreshes it and re-packs w4 every step)
+                e.w4_src = upsample_phase_weights_stacked(s.conv.weight.detach().to(device=device, dtype=torch.float32))
+                e.w4 = tuple(self._pack(e.w4_src[p]) for p in range(4))      # (a tuple: _copy_into refreshes tuples of tensors in place)
             self.samplers[name] = e
         self.gn_out = (f32(m.conv_norm_out.weight), f32(m.conv_norm_out.bias), m.conv_norm_out.eps)
         co = m.conv_out.weight.shape[0]
@@ -571,7 +573,7 @@ class UNetPlan:
     def _subpixel_up_ok(self, x):
         B, h, w, ch = x.shape
         esz = 4 if self.code == L.PD_F32 else 2
-        return (self.SUBPIXEL_UP and not getattr(self, "train", False) and w >= 32 and ch % 32 == 0
+        return (self.SUBPIXEL_UP and (not getattr(self, "train", False) or getattr(self, "subpixel_in_training", False)) and w >= 32 and ch % 32 == 0
                 and B * 4 * h * w * ch * esz < (1 << 31))
 
     def _upconv_subpixel(self, x, s):

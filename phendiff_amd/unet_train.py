@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib as L
-from .packing import dgrad_weight, pack_conv_weight
+from .packing import dgrad_weight, pack_conv_weight, upsample_phase_weights_stacked
 from .unet import CustomCondUNet2DModel, UNetPlan, _Attention, _Op, _PackedWeights, _Resnet, _Sampler, _copy_into
 
 
@@ -94,6 +94,9 @@ class TrainWeights:
                 self.attns[name] = SimpleNamespace(wqkvd=pk(lin(wqkv)), wod=pk(lin(mod.to_out[0].weight)))
             elif isinstance(mod, _Sampler):
                 self.samplers[name] = SimpleNamespace(wd=pk(mod.conv.weight))
+                if ".upsamplers." in name:      # input-gradient weights of the four sub-pixel phases (pd_conv phase_in): transposed, taps flipped
+                    k4 = upsample_phase_weights_stacked(mod.conv.weight.detach().to(device=device, dtype=torch.float32))
+                    self.samplers[name].wd4 = tuple(pk(k4[p]) for p in range(4))
         co = m.conv_out.weight.shape[0]
         wo = torch.zeros((((co + 31) // 32) * 32,) + tuple(m.conv_out.weight.shape[1:]), dtype=torch.float32, device=device)
         wo[:co] = m.conv_out.weight.detach().to(device=device, dtype=torch.float32)
@@ -110,6 +113,11 @@ class UNetTrainPlan(UNetPlan):
 
     ``params`` / ``grads``: state_dict-name -> fp32 device tensor (master parameter / its gradient), laid out as
     :func:`training_param_order` prescribes.  ``backward`` ACCUMULATES into ``grads`` (zero them between steps)."""
+
+    # Upsample2D runs as four sub-pixel 2x2 phases in the training forward as well (round 4): its input gradient is the four phases run
+    # backwards (pd_conv phase_in: 4 / 9 of the FLOPs of the 3x3 input gradient over the upsampled tensor, and no 2x2 pooling pass);
+    # the weight gradient differentiates the 3x3 weights over the nearest-upsampled input as before
+    subpixel_in_training = True
 
     def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, tw: TrainWeights, B, H, W, device,
                  params: Optional[Dict[str, torch.Tensor]] = None, grads: Optional[Dict[str, torch.Tensor]] = None,
@@ -447,14 +455,29 @@ class UNetTrainPlan(UNetPlan):
             dout = self._g(rec.out)[0]
             self._bias_grad(dout, G(rec.name + ".conv.bias"))
             self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), upsample=1)
-            du = self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], tag="du")
             gx = self._g(rec.x)
             _, h, ww, ch = rec.x.shape
-            a = L.Pool2x2Args(dtype=self.code, B=B, H=h, W=ww, C=ch, du=du.data_ptr(), dx=gx[0].data_ptr(),
-                              accumulate=int(gx[1]))
-            gx[1] = True
-            self._drop_fused_sums(gx[0])
-            self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
+            wd4 = getattr(tw.samplers[rec.name], "wd4", None)
+            if wd4 is not None and self._subpixel_up_ok(rec.x):
+                # d x = sum over the four phases of a 2x2 convolution over that phase's pixels of d out (transposed, flipped phase kernels):
+                # each launch accumulates into the gradient of the low-resolution tensor through `residual`
+                for ph in range(4):
+                    a = L.ConvArgs(dtype=self.code, B=B, Hin=h, Win=ww, Hout=h, Wout=ww, C0=ch, C1=0, Cout=ch, Cout_pad=ch, ksize=2, stride=1, pad=0,
+                                   upsample=0, silu=0, out_mode=L.PD_OUT_NHWC, heads=0, x0=dout.data_ptr(), x1=None, scale=None, shift=None,
+                                   w_packed=wd4[ph].data_ptr(), bias=self._zero_bias.data_ptr(), temb=None, temb_stride=self.w.proj_dim,
+                                   residual=(gx[0].data_ptr() if (gx[1] or ph > 0) else None), y=gx[0].data_ptr(), stats_out=None, im2col3=0,
+                                   tail_x0=None, tail_x1=None, tail_C0=0, tail_C1=0, phase=1 + ph, phase_in=1)
+                    self._b(self.lib.pd_conv, a, "dgrad3x3", 2.0 * B * 4 * h * ww * ch * ch * 9 / 4.0,
+                            (B * 4 * h * ww * ch / 4.0 + 2.0 * B * h * ww * ch) * self._esz() + ch * ch * 4 * self._esz())
+                gx[1] = True
+                self._drop_fused_sums(gx[0])
+            else:
+                du = self._dgrad(dout, tw.samplers[rec.name].wd, rec.x.shape[3], tag="du")
+                a = L.Pool2x2Args(dtype=self.code, B=B, H=h, W=ww, C=ch, du=du.data_ptr(), dx=gx[0].data_ptr(),
+                                  accumulate=int(gx[1]))
+                gx[1] = True
+                self._drop_fused_sums(gx[0])
+                self._b(self.lib.pd_pool2x2_sum, a, "pool2x2", 0.0, du.numel() * self._esz() * 1.25)
         elif k == "conv_in":
             dout = self._g(rec.out)[0]
             if self.input_grad:
@@ -679,7 +702,7 @@ class _Repacker:
 
     def __init__(self, m: CustomCondUNet2DModel, w: _PackedWeights, tw: TrainWeights):
         self.lib = L.lib()
-        self.jobs, self.small = [], []
+        self.jobs, self.small, self.pre = [], [], []      # pre: torch-side preparations the pack jobs read (run first)
         self.jobs_device = m.conv_in.weight.device
         code = w.code
 
@@ -726,6 +749,12 @@ class _Repacker:
                 ch = mod.conv.weight.shape[0]
                 job(w.samplers[name].w, mod.conv.weight, ch, ch, 3)
                 job(tw.samplers[name].wd, mod.conv.weight, ch, ch, 3, dgrad=1)
+                if ".upsamplers." in name:      # the sub-pixel phase kernels: pre-summed taps first (one contraction), then packed like any weight
+                    src4, wt = w.samplers[name].w4_src, mod.conv.weight
+                    self.pre.append(lambda src4=src4, wt=wt: upsample_phase_weights_stacked(wt.data, out=src4))
+                    for p in range(4):
+                        job(w.samplers[name].w4[p], src4[p], ch, ch, 2)
+                        job(tw.samplers[name].wd4[p], src4[p], ch, ch, 2, dgrad=1)
         co, c0 = m.conv_out.weight.shape[0], m.conv_out.weight.shape[1]
         job(w.conv_out_w, m.conv_out.weight, co, c0, 3, cout_pad=w.conv_out_pad)
         job(tw.conv_out_d, m.conv_out.weight, c0, co, 3, dgrad=1, cin_pad=w.conv_out_pad)
@@ -751,6 +780,9 @@ class _Repacker:
                                    "after the parameters were moved into the flat training buffer)")
 
     def run(self, stream):
+        with torch.no_grad():
+            for f in self.pre:
+                f()
         run_pack_jobs(self.lib, self.jobs, stream, self.__dict__.setdefault("_batch", {}), self.jobs_device)
         with torch.no_grad():
             for f in self.small:

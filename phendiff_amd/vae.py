@@ -332,7 +332,7 @@ class _VaeWeights:
             elif isinstance(r, _Sampler):
                 self.samplers[name] = SimpleNamespace(w=pk(r.conv.weight), b=f32(r.conv.bias), padding=r.padding)
                 if ".upsamplers." in name:      # Upsample2D as four 2x2 phase convolutions (UNetPlan._upconv_subpixel; inference plans)
-                    self.samplers[name].w4 = [pk(k) for k in upsample_phase_weights(r.conv.weight)]
+                    self.samplers[name].w4 = tuple(pk(k) for k in upsample_phase_weights(r.conv.weight))
 
 
 class _VaePlan(UNetPlan):

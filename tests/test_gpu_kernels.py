@@ -638,3 +638,44 @@ def test_upsample_conv_as_four_subpixel_phases(env, mode, shape):
     assert lib.pd_conv(C.byref(a), stream()) != 0
     a.ksize, a.Hout = 2, h + 1
     assert lib.pd_conv(C.byref(a), stream()) != 0
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 96, 128, 40, 72), (2, 64, 32, 9, 33)])
+def test_upsample_conv_input_gradient_as_four_subpixel_phases(env, mode, shape):
+    """The input gradient of Upsample2D's convolution through the sub-pixel form (pd_conv phase = 1 + 2 a + b with phase_in = 1): phase
+    (a, b) reads the pixels (2 y + a, 2 x + b) of d out and adds a 2x2 convolution of them -- transposed phase kernel, taps flipped,
+    rows starting at y - a -- into the gradient of the LOW-resolution tensor; the four launches together equal torch.autograd through
+    conv2d(interpolate(x, nearest x2), w, padding=1), on top of what the buffer already held (`residual`)."""
+    from phendiff_amd.packing import dgrad_weight, upsample_phase_weights
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    B, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, cin, h, w_, generator=g).requires_grad_(True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    dy = bf16_round(torch.randn(B, cout, 2 * h, 2 * w_, generator=g), mode)
+    prev = bf16_round(torch.randn(B, cin, h, w_, generator=g), mode)          # what the gradient buffer already holds
+    F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, padding=1).backward(dy)
+    DY = nhwc(dy.to(dev), tdt)
+    dx = nhwc(prev.to(dev), tdt).contiguous()
+    zero = torch.zeros(cin, device=dev)
+    keep = []
+    for ph, k in enumerate(upsample_phase_weights(w)):
+        wp = pack(dgrad_weight(k), tdt).to(dev)
+        keep.append(wp)
+        a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=h, Wout=w_, C0=cout, C1=0, Cout=cin, Cout_pad=cin, ksize=2, stride=1, pad=0,
+                       upsample=0, silu=0, out_mode=0, heads=0, x0=DY.data_ptr(), x1=None, scale=None, shift=None, w_packed=wp.data_ptr(),
+                       bias=zero.data_ptr(), temb=None, temb_stride=0, residual=dx.data_ptr(), y=dx.data_ptr(), stats_out=None, im2col3=0,
+                       phase=1 + ph, phase_in=1)
+        L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+    torch.cuda.synchronize()
+    got = dx.float().permute(0, 3, 1, 2).cpu()
+    # (16-bit engines: the accumulation through `residual` rounds the running sum after every phase)
+    assert rel(got, prev + x.grad) < {"f32": 2e-6, "bf16": 8e-3, "fp16": 1e-3}[mode]
+    # refused: statistics with an input-side phase, phase_in without a phase
+    st = torch.empty(B, 4 * lib.pd_conv_stat_tiles(h, w_, 2, 1), cin, 2, device=dev)
+    a.stats_out = st.data_ptr()
+    assert lib.pd_conv(C.byref(a), stream()) != 0
+    a.stats_out, a.phase = None, 0
+    assert lib.pd_conv(C.byref(a), stream()) != 0

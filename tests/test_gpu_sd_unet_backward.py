@@ -123,6 +123,28 @@ def test_sd_training_steps_follow_torch_adamw_f32():
     assert rel(got, ref_out) < 1e-4
 
 
+def test_sd_inference_after_training_steps_sees_the_updated_upsampler_phase_kernels():
+    """As above at 64 x 64 latents, where the inference plan runs Upsample2D (32 -> 64) as four sub-pixel phases with PRE-SUMMED copies of
+    the 3x3 weights: the fine-tuning re-pack refreshes those copies as well."""
+    import phendiff_amd as P
+    from oracle import class_emb_to_encoder_hidden_states as ehs_ref
+    r, emb, m, e2 = make_pair(TINY, "f32")
+    sched, clean, noise, ts, labels, noisy, target = batch(2, 64)
+    tr = P.SDUNetTrainer(m, e2, sched, lr=2e-3, use_ema=False)
+    up = [n for n, _ in m.named_parameters() if ".upsamplers." in n and n.endswith("conv.weight")]
+    before = {n: p.detach().clone() for n, p in m.named_parameters() if n in up}
+    for _ in range(2):
+        tr.step(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    assert up and all(float((p.detach() - before[n]).abs().max()) > 1e-4 for n, p in m.named_parameters() if n in before)
+    r.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    emb.inner_module.weight.data.copy_(e2.inner_module.weight.detach().cpu())
+    with torch.no_grad():
+        ref_out = r(noisy, ts, ehs_ref(emb(labels))).sample
+    got = m(noisy.cuda(), ts.cuda(), P.class_emb_to_encoder_hidden_states(e2(labels.cuda()))).sample
+    assert rel(got, ref_out) < 1e-4
+
+
 def test_sd_training_step_bf16_reduces_loss_and_overlapped_path():
     import phendiff_amd as P
     _, _, m, e2 = make_pair(TINY, "bf16")
