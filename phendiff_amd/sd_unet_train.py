@@ -85,6 +85,9 @@ class SDTrainWeights:
                     wff1_d=pk(lin(blk.ff.net[0].proj.weight)), wff2_d=pk(lin(blk.ff.net[2].weight)))
             elif isinstance(mod, _Sampler):
                 self.samplers[name] = SimpleNamespace(wd=pk(mod.conv.weight))
+                if ".upsamplers." in name:      # input-gradient weights of the four sub-pixel phases (UNetTrainPlan's "up" backward, pd_conv phase_in)
+                    k4 = upsample_phase_weights_stacked(mod.conv.weight.detach().to(device=device, dtype=torch.float32))
+                    self.samplers[name].wd4 = tuple(pk(k4[p]) for p in range(4))
         co = m.conv_out.weight.shape[0]
         wo = torch.zeros((((co + 31) // 32) * 32,) + tuple(m.conv_out.weight.shape[1:]), dtype=torch.float32, device=device)
         wo[:co] = m.conv_out.weight.detach().to(device=device, dtype=torch.float32)
@@ -334,6 +337,7 @@ class _SDRepacker:
                     self.pre.append(lambda src4=src4, wt=wt: upsample_phase_weights_stacked(wt.data, out=src4))
                     for p in range(4):
                         job(w.samplers[name].w4[p], src4[p], ch, ch, 2)
+                        job(tw.samplers[name].wd4[p], src4[p], ch, ch, 2, dgrad=1)
         co, cc = m.conv_out.weight.shape[0], m.conv_out.weight.shape[1]
         job(w.conv_out_w, m.conv_out.weight, co, cc, 3, cout_pad=w.conv_out_pad)
         job(tw.conv_out_d, m.conv_out.weight, cc, co, 3, dgrad=1, cin_pad=w.conv_out_pad)

@@ -39,7 +39,7 @@ def oracle_grads(r, emb, noisy, ts, target, labels, unconditional=False):
 
 
 @pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 3e-4, 3e-5), ("bf16", 1e-1, 2.5e-2)])
-@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32), (WIDE, 16)])
+@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32), (WIDE, 16), (TINY, 64)])      # (TINY, 64): Upsample2D 32 -> 64 as sub-pixel phases, forward and input gradient
 def test_sd_unet_backward_matches_autograd(mode, per_tol, glob_tol, cfg, size):
     import phendiff_amd as P
     r, emb, m, e2 = make_pair(cfg, mode)
