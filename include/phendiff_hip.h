@@ -31,7 +31,7 @@ extern "C" {
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
  * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
  * fold_ws_bytes + pd_linear_fold_workspace,
- * pd_conv_args.phase); 5 = pd_conv_args.phase_in. */
+ * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase. */
 #define PD_ABI_VERSION 5
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
@@ -362,6 +362,11 @@ typedef struct {
   const void* dy;
   float* slab; size_t slab_bytes;
   float* dw; int Cout_valid, Cin_valid; int accumulate;
+  int phase;                /* (ABI 5) 0: ordinary.  1 + 2 a + b: the weight gradient THROUGH sub-pixel phase (a, b) of an upsampler's 3x3 convolution
+                               (pd_conv_args.phase): ksize = 2, x0 = the LOW-resolution input [B][Hin][Win][C0], dy = the gradient of the upsampled
+                               output [B][2 Hout][2 Wout][Cout] (Hout = Hin, Wout = Win) read at its pixels (2 oy + a, 2 ox + b), dw = the 3x3
+                               gradient [Cout][C0][3][3]: the phase kernel's tap gradients are added to the 3x3 taps they are sums of (phase 1
+                               honours `accumulate`, phases 2-4 always add: run the four in order).  4 / 9 of the FLOPs of upsample = 1. */
 } pd_wgrad_args;
 size_t pd_conv_wgrad_workspace(const pd_wgrad_args* a);
 int pd_conv_wgrad(const pd_wgrad_args* a, void* stream);

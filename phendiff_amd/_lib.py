@@ -119,7 +119,7 @@ class WgradArgs(C.Structure):
                 ("C0", C.c_int), ("C1", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
                 ("upsample", C.c_int), ("silu", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("dy", vp),
                 ("slab", vp), ("slab_bytes", C.c_size_t), ("dw", vp), ("Cout_valid", C.c_int), ("Cin_valid", C.c_int),
-                ("accumulate", C.c_int)]
+                ("accumulate", C.c_int), ("phase", C.c_int)]
 
 
 class PackWeightArgs(C.Structure):

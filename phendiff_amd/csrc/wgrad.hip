@@ -20,6 +20,7 @@ namespace pd {
 
 struct WgradP {
   int B, Hin, Win, Hout, Wout, C0, C1, Cout, pad, upsample, silu;
+  int pad_x, dy_step, dy_oy, dy_ox;      // sub-pixel phase (pd_wgrad_args.phase): column padding, dy read at (dy_step oy + dy_oy, dy_step ox + dy_ox) of a tensor dy_step times as large
   int tiles_x, tiles_y, ntiles, tiles_per_split, n_ci_t, n_co_t, splits, nwork;
   int COP, CIP;                    // slab dims (multiples of 64)
   unsigned bytes0, bytes1, bytesdy;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
       const int q = tid + 256 * i, pix = q >> 3, sub = q & 7;
       const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
       const bool ok = pix < Cf::TP && oy < p.Hout && ox < p.Wout && (co0 + sub * 8) < p.Cout;
-      const unsigned off = ok ? (unsigned)((((n * p.Hout + oy) * p.Wout + ox) * p.Cout + co0 + sub * 8) * E::BYTES) : OOB_OFF;
+      const unsigned off = ok ? (unsigned)((((n * p.Hout * p.dy_step + oy * p.dy_step + p.dy_oy) * (p.Wout * p.dy_step) + ox * p.dy_step + p.dy_ox) * p.Cout + co0 + sub * 8) * E::BYTES) : OOB_OFF;
       sdy[i] = Stage<T>::load(rsd, off);
     }
     zvalid = 0;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
         unsigned off = OOB_OFF;
         if (pix < NPIX && psrc[pl] < 2) {
           const int u = pix / HWD, v = pix - u * HWD;
-          const int iy = oy0 * STRIDE - p.pad + u, ix = ox0 * STRIDE - p.pad + v;
+          const int iy = oy0 * STRIDE - p.pad + u, ix = ox0 * STRIDE - p.pad_x + v;
           if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) {
             const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
             off = (unsigned)((((n * p.Hin + sy) * p.Win + sx) * pcs[pl] + pch[pl] + sub4 * 8) * E::BYTES);
@@ -226,9 +227,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
 // dw[co][ci][tap] (+)= sum over splits of slab[split][tap][co][ci], splits added in a fixed order (bitwise reproducible).
 // Workgroup = one co x 64 consecutive ci x all taps: the slab rows are read coalesced (ci fastest), transposed through LDS
 // and written as one contiguous run of 64*taps floats of dw (for a 3x3 conv the taps are the fastest dw index).
+// Sub-pixel phase (a, b) of an upsampler's convolution (pd_wgrad_args.phase = 1 + 2 a + b): the slab holds the gradient of the phase's 2x2
+// kernel, whose tap (u, v) is the SUM of the 3x3 taps {rows R_a(u)} x {columns R_b(v)}, R_0 = {0 | 1, 2}, R_1 = {0, 1 | 2}
+// (packing.upsample_phase_weights) -- so its gradient is ADDED to each of those 3x3 taps.  Within one phase the four (u, v) cover the nine
+// taps exactly once (no two threads touch the same element); the four phases are four launches on one stream.
+__device__ __forceinline__ void phase_scatter(float* out9, int phase, int k, float v, bool add) {
+  const int a = (phase - 1) >> 1, b = (phase - 1) & 1, u = k >> 1, w = k & 1;
+  const int y0 = a == 0 ? (u == 0 ? 0 : 1) : (u == 0 ? 0 : 2), y1 = a == 0 ? (u == 0 ? 0 : 2) : (u == 0 ? 1 : 2);
+  const int x0 = b == 0 ? (w == 0 ? 0 : 1) : (w == 0 ? 0 : 2), x1 = b == 0 ? (w == 0 ? 0 : 2) : (w == 0 ? 1 : 2);
+  for (int ky = y0; ky <= y1; ++ky)
+    for (int kx = x0; kx <= x1; ++kx) out9[ky * 3 + kx] = add ? out9[ky * 3 + kx] + v : v;
+}
+
 template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
-                                                            int COP, int CIP, int cout_valid, int cin_valid, int accumulate) {
+                                                            int COP, int CIP, int cout_valid, int cin_valid, int accumulate, int phase = 0) {
   __shared__ float tile[64 * TAPS];
   const int tid = threadIdx.x;
   const int ci_blocks = CIP / 64;
@@ -246,13 +259,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   __syncthreads();
   const int nci = min(64, cin_valid - ci0);            // may be <= 0 for padded input channels
+  if (TAPS == 4 && phase) {
+    float* out3 = dw + ((size_t)co * cin_valid + ci0) * 9;
+    for (int e = tid; e < nci * TAPS; e += 256) phase_scatter(out3 + (e >> 2) * 9, phase, e & 3, tile[e], accumulate || phase > 1);
+    return;
+  }
   float* out = dw + ((size_t)co * cin_valid + ci0) * TAPS;
   for (int e = tid; e < nci * TAPS; e += 256) out[e] = accumulate ? out[e] + tile[e] : tile[e];
 }
 
 // Many splits (small weights, many pixels): block = 64 consecutive slab elements x 4 split groups, combined in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_split_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int taps,
-                                                                  int COP, int CIP, int cout_valid, int cin_valid, int accumulate) {
+                                                                  int COP, int CIP, int cout_valid, int cin_valid, int accumulate, int phase = 0) {
   __shared__ float red[256];
   const int tid = threadIdx.x, sg = tid >> 6;
   const size_t per = (size_t)taps * COP * CIP;
@@ -266,8 +284,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_split_kernel(const float* __
     const int ci = (int)(e % CIP);
     const int co = (int)((e / CIP) % COP), k = (int)(e / ((size_t)CIP * COP));
     if (co < cout_valid && ci < cin_valid) {
-      float* o = dw + ((size_t)co * cin_valid + ci) * taps + k;
-      *o = accumulate ? *o + s : s;
+      if (phase) phase_scatter(dw + ((size_t)co * cin_valid + ci) * 9, phase, k, s, accumulate || phase > 1);
+      else {
+        float* o = dw + ((size_t)co * cin_valid + ci) * taps + k;
+        *o = accumulate ? *o + s : s;
+      }
     }
   }
 }
@@ -377,6 +398,11 @@ static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
   WgradP p;
   p.B = a->B; p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout; p.C0 = a->C0; p.C1 = a->C1; p.Cout = a->Cout;
   p.pad = a->pad; p.upsample = a->upsample; p.silu = a->silu;
+  p.pad_x = a->pad; p.dy_step = 1; p.dy_oy = 0; p.dy_ox = 0;
+  if (a->phase) {      // rows start at oy - (1 - a), columns at ox - (1 - b); dy = the phase's pixels of the upsampled output's gradient
+    const int pa = (a->phase - 1) >> 1, pb = (a->phase - 1) & 1;
+    p.pad = 1 - pa; p.pad_x = 1 - pb; p.dy_step = 2; p.dy_oy = pa; p.dy_ox = pb;
+  }
   p.tiles_x = (a->Wout + Cf::TW - 1) / Cf::TW; p.tiles_y = (a->Hout + TH - 1) / TH;
   p.ntiles = a->B * p.tiles_x * p.tiles_y;
   const int cin = a->C0 + a->C1;
@@ -393,7 +419,7 @@ static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
   const size_t es = sizeof(T);
   p.bytes0 = (unsigned)((size_t)a->B * a->Hin * a->Win * a->C0 * es);
   p.bytes1 = (unsigned)((size_t)a->B * a->Hin * a->Win * a->C1 * es);
-  p.bytesdy = (unsigned)((size_t)a->B * a->Hout * a->Wout * a->Cout * es);
+  p.bytesdy = (unsigned)((size_t)a->B * a->Hout * a->Wout * a->Cout * es * (a->phase ? 4 : 1));
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.dy = a->dy; p.slab = a->slab;
   auto kern = wgrad_kernel<T, KS, STRIDE, TH>;
   static bool attr_done = false;
@@ -410,10 +436,10 @@ static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
   const int cout_v = a->Cout_valid > 0 ? a->Cout_valid : a->Cout, cin_v = a->Cin_valid > 0 ? a->Cin_valid : cin;
   if (splits > 8)     // small weights spread over many pixel splits: parallelise over the splits
     hipLaunchKernelGGL(wgrad_reduce_split_kernel, dim3((unsigned)((size_t)Cf::TAPS * p.COP * p.CIP / 64)), dim3(256), 0, st,
-                       (const float*)a->slab, a->dw, splits, Cf::TAPS, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
+                       (const float*)a->slab, a->dw, splits, Cf::TAPS, p.COP, p.CIP, cout_v, cin_v, a->accumulate, a->phase);
   else                // large weights (few splits): coalesced transposing copy
     hipLaunchKernelGGL(wgrad_reduce_kernel<Cf::TAPS>, dim3((unsigned)((size_t)p.COP * (p.CIP / 64))), dim3(256), 0, st, (const float*)a->slab,
-                       a->dw, splits, p.COP, p.CIP, cout_v, cin_v, a->accumulate);
+                       a->dw, splits, p.COP, p.CIP, cout_v, cin_v, a->accumulate, a->phase);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
@@ -436,6 +462,16 @@ extern "C" int pd_conv_wgrad(const pd_wgrad_args* a, void* stream) {
   PD_CHECK(a->B > 0 && a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0, PD_ERR_SHAPE, "pd_conv_wgrad: bad shape");
   PD_CHECK(a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: C0=%d C1=%d must be multiples of 32", a->C0, a->C1);
   PD_CHECK(a->Cout > 0 && a->Cout % 8 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: Cout=%d (channel stride of dy) must be a multiple of 8", a->Cout);
+  PD_CHECK(a->phase >= 0 && a->phase <= 4, PD_ERR_ARG, "pd_conv_wgrad: phase %d", a->phase);
+  if (a->phase) {
+    PD_CHECK(a->ksize == 2 && a->stride == 1 && !a->upsample && !a->scale && a->C1 == 0 && a->Hout == a->Hin && a->Wout == a->Win && !a->Cout_valid && !a->Cin_valid,
+             PD_ERR_UNSUPPORTED, "pd_conv_wgrad: a sub-pixel phase is a plain 2x2 weight gradient over one source with Hout = Hin, Wout = Win");
+    PD_CHECK(a->x0 && a->dy && a->slab && a->dw, PD_ERR_ARG, "pd_conv_wgrad: null pointer");
+    PD_CHECK((size_t)a->B * a->Hout * a->Wout * 4 * a->Cout * (a->dtype == PD_F32 ? 4 : 2) < ((size_t)1 << 31) && (size_t)a->B * a->Hin * a->Win * a->C0 * (a->dtype == PD_F32 ? 4 : 2) < ((size_t)1 << 31),
+             PD_ERR_SHAPE, "pd_conv_wgrad: tensors must be < 2 GiB (32-bit buffer offsets)");
+    hipStream_t stp = (hipStream_t)stream;
+    return a->dtype == PD_BF16 ? launch_wgrad<bf16_t, 2, 1, 8>(a, stp) : launch_wgrad<float, 2, 1, 4>(a, stp);
+  }
   PD_CHECK((a->ksize == 3 && (a->stride == 1 || a->stride == 2)) || (a->ksize == 1 && a->stride == 1 && a->pad == 0), PD_ERR_SHAPE,
            "pd_conv_wgrad: unsupported ksize=%d stride=%d", a->ksize, a->stride);
   PD_CHECK(!(a->upsample && a->stride != 1) && (a->upsample == 0 || a->upsample == 1), PD_ERR_SHAPE, "pd_conv_wgrad: bad upsample");

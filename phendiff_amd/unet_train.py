@@ -284,7 +284,7 @@ class UNetTrainPlan(UNetPlan):
                              workspace=ws.data_ptr(), splits=splits)
         self._b(self.lib.pd_channel_sum, a, "channel_sum", 0.0, dy.numel() * self._esz())
 
-    def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0):
+    def _wgrad(self, x0, x1, gn, silu, dy, dw, *, ksize=3, stride=1, pad=1, upsample=0, cout_valid=0, cin_valid=0, phase=0):
         """Weight gradient of a convolution (``pd_conv_wgrad``); plain Linear layers (1x1, one dense source, no fused GroupNorm)
         go through the token-reduction GEMM ``pd_token_wgrad``."""
         if not self.param_grads or dw is None:          # (dw None: a frozen weight)
@@ -320,10 +320,12 @@ class UNetTrainPlan(UNetPlan):
         B, hin, win, c0 = x0.shape
         c1 = x1.shape[3] if x1 is not None else 0
         _, hout, wout, cout = dy.shape
+        if phase:          # sub-pixel phase of an upsampler (pd_wgrad_args.phase): dy is the gradient of the UPSAMPLED output, the grid is the low-resolution one
+            hout, wout, ksize, pad = hin, win, 2, 0
         a = L.WgradArgs(dtype=self.code, B=B, Hin=hin, Win=win, Hout=hout, Wout=wout, C0=c0, C1=c1, Cout=cout, ksize=ksize,
                         stride=stride, pad=pad, upsample=upsample, silu=silu, x0=x0.data_ptr(), x1=L.ptr(x1),
                         scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None, dy=dy.data_ptr(),
-                        dw=dw.data_ptr(), Cout_valid=cout_valid, Cin_valid=cin_valid, accumulate=1)
+                        dw=dw.data_ptr(), Cout_valid=cout_valid, Cin_valid=cin_valid, accumulate=1, phase=phase)
         self._wgrad_args.append(a)
         flops = 2.0 * B * hout * wout * cout * (c0 + c1) * ksize * ksize
         nbytes = (x0.numel() + (x1.numel() if x1 is not None else 0) + dy.numel()) * self._esz() + dw.numel() * 4
@@ -454,11 +456,19 @@ class UNetTrainPlan(UNetPlan):
         elif k == "up":
             dout = self._g(rec.out)[0]
             self._bias_grad(dout, G(rec.name + ".conv.bias"))
-            self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), upsample=1)
             gx = self._g(rec.x)
             _, h, ww, ch = rec.x.shape
             wd4 = getattr(tw.samplers[rec.name], "wd4", None)
-            if wd4 is not None and self._subpixel_up_ok(rec.x):
+            sub = wd4 is not None and self._subpixel_up_ok(rec.x)
+            if sub:        # the weight gradient through the four phases as well: each adds its 2x2 tap gradients to the 3x3 taps they sum (4 / 9 of the FLOPs)
+                gw = G(rec.name + ".conv.weight")
+                for ph in range(4):
+                    self._wgrad(rec.x, None, None, 0, dout, gw, phase=1 + ph)
+                if gw is not None:      # the gradient is final after the LAST of the four launches (G() recorded the first: the overlapped all-reduce hands its bucket over there)
+                    self.grad_ready[rec.name + ".conv.weight"] = len(self.bwd_ops) - 1
+            else:
+                self._wgrad(rec.x, None, None, 0, dout, G(rec.name + ".conv.weight"), upsample=1)
+            if sub:
                 # d x = sum over the four phases of a 2x2 convolution over that phase's pixels of d out (transposed, flipped phase kernels):
                 # each launch accumulates into the gradient of the low-resolution tensor through `residual`
                 for ph in range(4):

@@ -269,6 +269,49 @@ def test_conv_weight_gradient_upsample_and_1x1_and_padded_channels(env, mode):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("shape,splits", [((2, 64, 64, 8, 12), None), ((1, 96, 128, 33, 40), None), ((3, 64, 32, 32, 32), 1), ((2, 32, 64, 40, 70), 20)])
+def test_upsampler_weight_gradient_through_four_subpixel_phases(env, mode, shape, splits):
+    """pd_conv_wgrad(phase = 1 + 2 a + b): the gradient of Upsample2D's 3x3 weights through the sub-pixel form -- phase (a, b) multiplies the
+    LOW-resolution input with the pixels (2 y + a, 2 x + b) of d out (a 2x2 weight gradient, 4 / 9 of the FLOPs of the upsample = 1 form) and
+    adds each tap gradient to the 3x3 taps that tap is the sum of; the four launches in order (few- and many-split reductions, on top of a
+    previous gradient) equal torch.autograd through conv2d(interpolate(x, nearest x2), w, padding=1)."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    B, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(29)
+    x = bf16_round(torch.randn(B, cin, h, w_, generator=g), mode)
+    dy = bf16_round(torch.randn(B, cout, 2 * h, 2 * w_, generator=g), mode)
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, padding=1), w, dy)
+    prev = torch.randn(cout, cin, 3, 3, generator=g)
+    X, DY = nhwc(x.to(dev), tdt), nhwc(dy.to(dev), tdt)
+    dw = prev.clone().to(dev)
+    for ph in range(4):
+        a = L.WgradArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=h, Wout=w_, C0=cin, C1=0, Cout=cout, ksize=2, stride=1, pad=0, upsample=0, silu=0,
+                        x0=X.data_ptr(), x1=None, scale=None, shift=None, dy=DY.data_ptr(), dw=dw.data_ptr(), Cout_valid=0, Cin_valid=0,
+                        accumulate=1, phase=1 + ph)
+        want = lib.pd_conv_wgrad_workspace(C.byref(a))
+        assert want > 0
+        nbytes = want if splits is None else splits * 4 * ((cout + 63) // 64 * 64) * ((cin + 63) // 64 * 64) * 4
+        slab = torch.empty(nbytes // 4, device=dev)
+        a.slab, a.slab_bytes = slab.data_ptr(), nbytes
+        L.check(lib.pd_conv_wgrad(C.byref(a), stream()), "pd_conv_wgrad")
+    torch.cuda.synchronize()
+    assert rel(dw.cpu() - prev, ref) < (2e-5 if mode == "f32" else 1e-4)
+    # phase 1 without `accumulate` SETS the taps it touches; refused: a phase with the fused upsample / another kernel size
+    a.phase, a.accumulate = 1, 0
+    dw2 = torch.full_like(dw, float("nan"))
+    a.dw = dw2.data_ptr()
+    L.check(lib.pd_conv_wgrad(C.byref(a), stream()), "pd_conv_wgrad")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dw2).all())
+    a.upsample = 1
+    assert lib.pd_conv_wgrad(C.byref(a), stream()) != 0
+    a.upsample, a.ksize = 0, 3
+    assert lib.pd_conv_wgrad(C.byref(a), stream()) != 0
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("cfg", [(2, 4, 64), (1, 8, 1024), (2, 8, 200), (1, 2, 16), (1, 3, 300)])
 def test_attention_backward(env, mode, cfg):
     L, lib, _, dev = env
