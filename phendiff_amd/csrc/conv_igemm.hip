@@ -1041,7 +1041,8 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
   }
   if (ksize == 2 && stride == 1) {     // a phase of the sub-pixel upsampling convolution: always without a prologue (PLAIN: 16x16x32 MFMAs in the 16-bit engines)
     if (w >= 32) return launch_conv<T, 2, 1, 8, 32, false, 1, true>(p, st);
-    set_error("pd_conv: the 2x2 phase form needs Wout >= 32");
+    if (w >= 16) return launch_conv<T, 2, 1, 16, 16, false, 1, true>(p, st);      // (the SD UNet's 16 -> 32 upsampler: 1 280 channels)
+    set_error("pd_conv: the 2x2 phase form needs Wout >= 16");
     return PD_ERR_UNSUPPORTED;
   }
   if (ksize == 1 && stride == 1) {

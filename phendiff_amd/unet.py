@@ -573,7 +573,7 @@ class UNetPlan:
     def _subpixel_up_ok(self, x):
         B, h, w, ch = x.shape
         esz = 4 if self.code == L.PD_F32 else 2
-        return (self.SUBPIXEL_UP and (not getattr(self, "train", False) or getattr(self, "subpixel_in_training", False)) and w >= 32 and ch % 32 == 0
+        return (self.SUBPIXEL_UP and (not getattr(self, "train", False) or getattr(self, "subpixel_in_training", False)) and w >= 16 and ch % 32 == 0
                 and B * 4 * h * w * ch * esz < (1 << 31))
 
     def _upconv_subpixel(self, x, s):

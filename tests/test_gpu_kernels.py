@@ -596,7 +596,7 @@ def test_conv3x3_with_fused_1x1_tail(env, mode, shape, plain):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 128, 96, 40, 72), (2, 32, 64, 9, 33)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 128, 96, 40, 72), (2, 32, 64, 9, 33), (2, 64, 64, 16, 16), (1, 32, 64, 20, 17)])      # the last two: 16 x 16 tiles
 def test_upsample_conv_as_four_subpixel_phases(env, mode, shape):
     """Round 4: Upsample2D (F.interpolate(nearest x2) -> conv 3x3 pad 1; diffusers resnet.py, cond_unet_2d.py:200-228) as four 2x2
     convolutions over the LOW-resolution tensor (pd_conv phase 1..4 with packing.upsample_phase_weights): every output pixel equals
@@ -641,7 +641,7 @@ def test_upsample_conv_as_four_subpixel_phases(env, mode, shape):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 96, 128, 40, 72), (2, 64, 32, 9, 33)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 96, 128, 40, 72), (2, 64, 32, 9, 33), (2, 64, 64, 16, 16), (1, 64, 32, 20, 17)])
 def test_upsample_conv_input_gradient_as_four_subpixel_phases(env, mode, shape):
     """The input gradient of Upsample2D's convolution through the sub-pixel form (pd_conv phase = 1 + 2 a + b with phase_in = 1): phase
     (a, b) reads the pixels (2 y + a, 2 x + b) of d out and adds a 2x2 convolution of them -- transposed phase kernel, taps flipped,
