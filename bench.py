@@ -344,17 +344,53 @@ def reduce_elapsed(dist, elapsed, dev, units_per_rank):
                         **({"allreduce_selftest": st} if st else {})}
 
 
-def comm_selftest(dist, dev, nbytes=64 << 20, native_timeout_s=90.0):
-    """world > 1, before anything is timed: one 64 MB fp32 bucket all-reduced three ways --
-    ``torch.distributed.all_reduce`` (RCCL through PyTorch), ``pd_allreduce_bucket`` algo 0 (ncclAllReduce through the C ABI) and
-    algo 1 (reduce-scatter + all-gather) -- each checked bit for bit against the analytic sum and timed; the bus bandwidth
-    2 (W - 1) / W x bytes / t of each goes on the JSON line, with the size of the communicator as RCCL itself reports it
-    (``pd_comm_query``: ncclCommCount).  The first execution of this code with more than one RCCL rank is the driver's 8-GPU run: if
-    the curve bends, this says what the exchange can do on that node.  The native communicator is built in a worker thread with a
-    time limit: a failure or a stall there is recorded on the line and costs the run nothing else (the trainers' default exchange
-    is ``torch.distributed``)."""
+class _StubComm:
+    """Test double of phendiff_amd.comm.NativeComm for the self-test's control flow (tests/test_distributed_gloo.py,
+    tests/test_gpu_bench_two_ranks.py): PD_BENCH_SELFTEST_STUB="<rank>:<seconds>" makes pd_comm_init's stand-in sleep that long on that
+    rank ("-1:0": nobody sleeps); its all-reduce is never reached when a rank timed out, and sums through the torch group otherwise."""
+    spec = (-1, 0.0)
+
+    def __init__(self, rank, world, comm_id, device=None):
+        assert len(comm_id) == 128
+        self.rank, self.world = rank, world
+        if rank == self.spec[0]:
+            time.sleep(self.spec[1])
+
+    @staticmethod
+    def unique_id():
+        return bytes(range(128))
+
+    def query(self):
+        return self.rank, self.world
+
+    def allreduce_(self, flat, mean=True, algo=1, stream=None):
+        import torch.distributed as dist
+        dist.all_reduce(flat)
+        return flat
+
+    def close(self):
+        pass
+
+
+def comm_selftest(dist, dev, nbytes=64 << 20, native_timeout_s=90.0, native=None, comm_cls=None):
+    """world > 1, before anything is timed: one 64 MB fp32 bucket all-reduced through ``torch.distributed.all_reduce`` (RCCL through
+    PyTorch), checked bit for bit against the analytic sum and timed; its bus bandwidth 2 (W - 1) / W x bytes / t goes on the JSON line.
+    If the scaling curve bends, this says what the exchange can do on that node.
+
+    The two legs through the C ABI -- ``pd_allreduce_bucket`` algo 0 (ncclAllReduce) and algo 1 (reduce-scatter + all-gather), with the
+    size of the communicator as RCCL itself reports it (``pd_comm_query``: ncclCommCount) -- are OPT-IN (``PD_BENCH_NATIVE_SELFTEST=1`` or
+    ``native=True``): the driver's default command runs the torch leg only, because the native communicator has never been formed
+    with more than one rank anywhere and the self-test must not be able to cost the run it explains.  When they
+    run, every torch collective is issued by the MAIN thread and every rank issues the same sequence of them whatever fails where:
+      * rank 0 draws the 128-byte id (failure -> a sentinel) and ONE ``dist.broadcast`` of 129 bytes carries it: every rank learns
+        together whether there is an id (ADVICE r4: no rank is left alone inside a broadcast);
+      * only ``pd_comm_init`` (ncclCommInitRank, which can stall) runs in a worker thread, with a time limit; a thread that does not
+        come back is LEFT (daemon; it touches neither torch nor the process group) and its communicator is abandoned, not destroyed;
+      * one ``all_reduce(MIN)`` of a status code makes the ranks agree on ok / error / timeout; each native leg then runs inside
+        try / except with one more agreed status, so an error on one rank ends the native part on all of them."""
     import threading
     world, rank = dist.get_world_size(), dist.get_rank()
+    cuda = dev.type == "cuda"
     n = nbytes // 4
     n -= n % (world * 256)
     base = (torch.arange(n, device=dev, dtype=torch.float32) % 1024) / 1024          # exact dyadic fractions
@@ -362,59 +398,113 @@ def comm_selftest(dist, dev, nbytes=64 << 20, native_timeout_s=90.0):
     out = {"bytes": n * 4, "world": world, "busbw_GBs": {}, "exact": {}}
     rehearsal = bool(os.environ.get("PD_BENCH_REHEARSAL"))
 
+    def sync():
+        if cuda:
+            torch.cuda.synchronize(dev)
+
+    def agree(code):
+        """MIN over the ranks of a small status code: one torch collective, main thread, every rank."""
+        flag = torch.tensor([code], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item())
+
     def timed(fn, reps=3):
-        buf = base * float(rank + 1)
-        fn(buf)                                                                     # warm-up (and the checked result)
-        torch.cuda.synchronize(dev)
-        ok = bool(torch.equal(buf, want))
+        """(exact, busbw GB/s) of one way of all-reducing the bucket, or (error string, None) -- agreed by all ranks."""
+        err, ok, ms = None, False, 0.0
+        try:
+            buf = base * float(rank + 1)
+            fn(buf)                                                                 # warm-up (and the checked result)
+            sync()
+            ok = bool(torch.equal(buf, want))
+        except Exception as e:                                                      # noqa: BLE001 -- recorded, agreed below
+            err = repr(e)
+        if not agree(0 if err else 1):
+            return err or "failed on another rank", None
         dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        bufs = [base * float(rank + 1) for _ in range(reps)]
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for b in bufs:
-            fn(b)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / reps
+        try:
+            bufs = [base * float(rank + 1) for _ in range(reps)]
+            sync()
+            t0 = time.perf_counter()
+            for b in bufs:
+                fn(b)
+            sync()
+            ms = 1e3 * (time.perf_counter() - t0) / reps
+        except Exception as e:                                                      # noqa: BLE001
+            err = repr(e)
+        if not agree(0 if err else 1):
+            return err or "failed on another rank", None
         return ok, round(2.0 * (world - 1) / world * n * 4 / (ms * 1e-3) / 1e9, 2)
 
     out["exact"]["torch"], out["busbw_GBs"]["torch"] = timed(lambda b: dist.all_reduce(b, op=dist.ReduceOp.SUM))
     out["rccl_world_size"], out["rccl_world_size_source"] = world, "torch.distributed.get_world_size()"
-    if rehearsal:
+    stub = os.environ.get("PD_BENCH_SELFTEST_STUB")
+    if comm_cls is None and stub:
+        r_, s_ = stub.split(":")
+        _StubComm.spec = (int(r_), float(s_))
+        comm_cls, native = _StubComm, True
+    if native is None:
+        native = os.environ.get("PD_BENCH_NATIVE_SELFTEST") == "1"
+    if not native:
+        out["native"] = "not run: the C-ABI legs are opt-in (PD_BENCH_NATIVE_SELFTEST=1)"
+        return out
+    if rehearsal and comm_cls is None:
         out["native"] = "skipped: rehearsal over gloo on one device (RCCL refuses two ranks per device)"
         return out
+    if comm_cls is None:
+        from phendiff_amd.comm import NativeComm as comm_cls
+    # the id: drawn on rank 0, shipped by the main thread; byte 0 says whether there is one
+    msg = torch.zeros(129, dtype=torch.uint8, device=dev)
+    id_err = None
+    if rank == 0:
+        try:
+            cid = comm_cls.unique_id()
+            msg[0] = 1
+            msg[1:] = torch.frombuffer(bytearray(cid), dtype=torch.uint8).to(dev)
+        except Exception as e:                                                      # noqa: BLE001 -- the sentinel goes out instead
+            id_err = repr(e)
+    dist.broadcast(msg, src=0)
+    host = msg.cpu()
+    if int(host[0]) == 0:
+        out["native"] = "no communicator id: pd_comm_unique_id failed on rank 0" + (f" ({id_err})" if id_err else "")
+        return out
+    cid = bytes(host[1:].tolist())
     box = {}
 
-    def build():
+    def init():                                                                     # pd_comm_init only: no torch collective in here
         try:
-            from phendiff_amd.comm import NativeComm
-            box["comm"] = NativeComm.from_process_group(None, dev)
-        except Exception as e:                                                     # noqa: BLE001 -- recorded, never fatal
+            box["comm"] = comm_cls(rank, world, cid, dev if cuda else None)
+        except Exception as e:                                                      # noqa: BLE001 -- recorded, never fatal
             box["error"] = repr(e)
 
-    th = threading.Thread(target=build, daemon=True)
+    native_timeout_s = float(os.environ.get("PD_BENCH_NATIVE_TIMEOUT_S", native_timeout_s))
+    th = threading.Thread(target=init, daemon=True)
     th.start()
     th.join(native_timeout_s)
-    flag = torch.tensor([1 if "comm" in box else 0], device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                                     # every rank agrees on whether the native part runs
-    if not int(flag.item()):
-        out["native"] = box.get("error", f"pd_comm_init did not return within {native_timeout_s:.0f} s on some rank")
+    status = agree(2 if "comm" in box else (1 if "error" in box else 0))            # 2 ok / 1 error / 0 still inside pd_comm_init
+    if status < 2:
+        out["native"] = "timeout" if status == 0 else "error"
+        out["native_detail"] = (f"pd_comm_init did not return within {native_timeout_s:.0f} s on some rank; the thread is left behind, its "
+                                "communicator abandoned") if status == 0 else box.get("error", "pd_comm_init failed on another rank")
+        comm = box.pop("comm", None)
+        if comm is not None:
+            comm._comm = None            # a communicator whose peers are missing is not destroyed (ncclCommDestroy may wait for them)
         return out
     comm = box["comm"]
     try:
         r_, w_ = comm.query()
         out["rccl_world_size"], out["rccl_world_size_source"] = w_, "pd_comm_query (ncclCommCount)"
         out["rccl_rank_matches"] = bool(r_ == rank)
-        out["exact"]["rccl_allreduce"], out["busbw_GBs"]["rccl_allreduce"] = timed(lambda b: comm.allreduce_(b, mean=False, algo=0))
-        out["exact"]["rs_ag"], out["busbw_GBs"]["rs_ag"] = timed(lambda b: comm.allreduce_(b, mean=False, algo=1))
-    except Exception as e:                                                         # noqa: BLE001
-        out["native"] = repr(e)
-    finally:
-        try:
-            comm.close()
-        except Exception:                                                          # noqa: BLE001
-            pass
+    except Exception as e:                                                          # noqa: BLE001
+        out["native_detail"] = repr(e)
+    for name, algo in (("rccl_allreduce", 0), ("rs_ag", 1)):
+        out["exact"][name], out["busbw_GBs"][name] = timed(lambda b, algo=algo: comm.allreduce_(b, mean=False, algo=algo))
+        if out["busbw_GBs"][name] is None:
+            break                                                                   # an agreed failure ends the native part everywhere
+    out["native"] = "ran"
+    try:
+        comm.close()
+    except Exception:                                                               # noqa: BLE001
+        pass
     return out
 
 
@@ -622,7 +712,7 @@ def main_sd_train(args, P, world, rank, dev, dist):
 # Kernel-selecting diagnostic overrides the library reads from the environment (conv_igemm.hip / linear_gemm.hip / attn_d8.hip /
 # unet.py): a bench line measured under one of them says so, and the default (driver) run is expected to carry none.
 DIAG_ENV = ("PD_LIB", "PD_TW_DMA", "PD_ALLOW_ABI_MISMATCH", "PD_BENCH_REHEARSAL", "PD_LIN_DMA", "PD_CONV_NCO", "PD_CONV_PLAIN", "PD_LIN_NC4", "PD_ATTN_NO_GLDS", "PD_ATTN_LDS_PAD", "PD_PREAPPLY_MIN_COUT", "PD_NO_LINEAR_GRADS", "PD_NO_PREAPPLY_WGRAD",
-            "PD_CONV_PRO", "PD_SUBPIXEL_UP", "PD_LIN_FOLD", "PD_LIN_NC5", "PD_BENCH_NO_SELFTEST", "PD_ATTN_WPB4", "PD_ATTN64_QB1", "EXTRA_HIPCC_FLAGS")
+            "PD_CONV_PRO", "PD_SUBPIXEL_UP", "PD_LIN_FOLD", "PD_LIN_NC5", "PD_BENCH_NO_SELFTEST", "PD_BENCH_NATIVE_SELFTEST", "PD_BENCH_SELFTEST_STUB", "PD_BENCH_NATIVE_TIMEOUT_S", "PD_ATTN_WPB4", "PD_ATTN64_QB1", "EXTRA_HIPCC_FLAGS")
 
 
 def diagnostic_env():

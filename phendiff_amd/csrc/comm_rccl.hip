@@ -4,7 +4,8 @@
 // process that never trains in data parallel never touches it); one communicator per process = per GPU, created on the CURRENT device.
 //   pd_comm_unique_id   rank 0 draws the 128-byte id; the host program ships it to the other ranks (torch.distributed's store, a file, MPI)
 //   pd_comm_init        ncclCommInitRank
-//   pd_allreduce_bucket in-place fp32 sum (or mean) of one contiguous gradient bucket on the given stream; algo 0 = ncclAllReduce (RCCL picks
+//   pd_allreduce_bucket in-place fp32 sum (or mean: ncclAvg inside the collective when the library has it -- no extra pass over the bucket, 7 GB of
+//                       traffic per step on the 3.46 GB SD gradient -- else sum + a scaling kernel) of one contiguous gradient bucket on the given stream; algo 0 = ncclAllReduce (RCCL picks
 //                       ring / tree), algo 1 = reduce-scatter + all-gather over equal shards (the direct form SURVEY 5.8 asks for on the
 //                       7 point-to-point xGMI links: each rank reduces 1 / world of the bucket and broadcasts it; needs count % world == 0)
 //   pd_comm_query       rank / size of the communicator as RCCL reports them
@@ -30,6 +31,8 @@ struct Rccl {
   int (*CommCount)(const nccl_comm, int*) = nullptr;
   int (*CommUserRank)(const nccl_comm, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  bool has_avg = false;          // ncclAvg (NCCL >= 2.10): the mean comes out of the collective itself, no pass over the bucket afterwards
 };
 // Loaded once (thread-safe: function-local static initialiser); when the library or one of its symbols is missing the reason is kept
 // for the error message and the handle is closed again.
@@ -54,6 +57,9 @@ struct RcclLoad {
     r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
     r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.h, "ncclCommUserRank");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
+    int ver = 0;
+    r.has_avg = r.GetVersion != nullptr && r.GetVersion(&ver) == 0 && ver >= 21000;
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.ReduceScatter || !r.AllGather || !r.CommDestroy || !r.CommCount || !r.CommUserRank) {
       snprintf(why, sizeof(why), "librccl.so lacks one of the nccl* entry points this library binds");
       dlclose(r.h);
@@ -65,7 +71,7 @@ static RcclLoad& rccl_load() { static RcclLoad l; return l; }
 static Rccl* rccl() { RcclLoad& l = rccl_load(); return l.r.h ? &l.r : nullptr; }
 static const char* rccl_why() { return rccl_load().why; }
 struct Comm { nccl_comm c; int rank, world; };
-constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;
+constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0, NCCL_AVG = 4;
 
 __global__ __launch_bounds__(256) void scale_kernel(float* p, size_t n, float s) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] *= s;
@@ -117,14 +123,16 @@ extern "C" int pd_allreduce_bucket(void* comm, float* buf, size_t count, int mea
   hipStream_t st = (hipStream_t)stream;
   // (no `world > 1` guard: RCCL runs both collectives at one rank too, so a one-rank communicator exercises this branch and its in-place
   // pointer arithmetic -- ADVICE r3)
+  const bool avg_in_collective = mean && cm->world > 1 && R->has_avg;
+  const int op = avg_in_collective ? NCCL_AVG : NCCL_SUM;
   if (algo == 1 && count % (size_t)cm->world == 0) {
     const size_t shard = count / cm->world;
-    PD_RCCL(R->ReduceScatter(buf, buf + (size_t)cm->rank * shard, shard, NCCL_FLOAT32, NCCL_SUM, cm->c, st), "pd_allreduce_bucket (reduce-scatter)");
+    PD_RCCL(R->ReduceScatter(buf, buf + (size_t)cm->rank * shard, shard, NCCL_FLOAT32, op, cm->c, st), "pd_allreduce_bucket (reduce-scatter)");
     PD_RCCL(R->AllGather(buf + (size_t)cm->rank * shard, buf, shard, NCCL_FLOAT32, cm->c, st), "pd_allreduce_bucket (all-gather)");
   } else {
-    PD_RCCL(R->AllReduce(buf, buf, count, NCCL_FLOAT32, NCCL_SUM, cm->c, st), "pd_allreduce_bucket");
+    PD_RCCL(R->AllReduce(buf, buf, count, NCCL_FLOAT32, op, cm->c, st), "pd_allreduce_bucket");
   }
-  if (mean && cm->world > 1) {
+  if (mean && cm->world > 1 && !avg_in_collective) {
     const unsigned blocks = (unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
     hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, st, buf, count, 1.0f / (float)cm->world);
     PD_LAUNCH_CHECK();

@@ -982,7 +982,7 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
     // (same-box: 256 -> 256 @64^2 0.219 -> 0.185 ms, 128 -> 128 @128^2 0.234 -> 0.197, 512 -> 256 0.403 -> 0.343; no prologue
     // 0.184 -> 0.194; 64 -> 128 @128^2 0.110 -> 0.116: K too small).  PD_CONV_NCO=1 / 2: diagnostic override (same-box A/B).
     if constexpr (sizeof(T) == 2) {
-      static const int nco_env = getenv("PD_CONV_NCO") ? atoi(getenv("PD_CONV_NCO")) : 0;
+      const int nco_env = diag_env("PD_CONV_NCO", 0);
       static int cus_of[16] = {0};      // per device (a process that drives several GPUs: each its own count; benign race: same value)
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -1000,11 +1000,11 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
         nco2 = nco_env ? nco_env == 2 : eff(wgs2, 2ll * cus) * speed2 > eff(wgs1, 3ll * cus);
       }
       // no GroupNorm / SiLU prologue (input gradients, the SD UNet's convolutions, upsamplers): the PLAIN instantiations = 16x16x32 MFMAs
-      static const bool plain_off = getenv("PD_CONV_PLAIN") && atoi(getenv("PD_CONV_PLAIN")) == 0;      // diagnostic: same-box A/B
+      const bool plain_off = diag_env("PD_CONV_PLAIN", 1) == 0;      // diagnostic: same-box A/B
       const bool plain = !plain_off && p.scale == nullptr && !p.silu && !p.im2col3 && w >= 16;
       // (the two-tile form keeps the 32x32x16 MFMAs: its 16x16x32 form needs 32 registers of A operands and spills at 256)
       // GroupNorm + SiLU prologue known at compile time (PRO): branch-free staging interleaved with the MFMAs.  PD_CONV_PRO=0 / 1 / 2: diagnostic override (none / the two-tile form / the one-tile form too)
-      static const int pro_lvl = getenv("PD_CONV_PRO") ? atoi(getenv("PD_CONV_PRO")) : PD_CONV_PRO;
+      const int pro_lvl = diag_env("PD_CONV_PRO", PD_CONV_PRO);
       const bool gs = p.scale != nullptr && p.silu != 0 && !p.im2col3 && w >= 32 && p.Cout_pad % 64 == 0 && p.out_mode != PD_OUT_NCHW_F32;
       if (nco2 && gs && pro_lvl >= 1)
         return p.n_tail > 0 ? launch_conv<T, 3, 1, 8, 32, true, 2, false, 1>(p, st) : launch_conv<T, 3, 1, 8, 32, false, 2, false, 1>(p, st);

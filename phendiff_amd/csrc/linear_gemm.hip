@@ -1127,7 +1127,7 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   // register staging, no per-element affine) and the head-major + key-bound epilogue is the register-staged kernel's.
   // PD_LIN_FOLD=0: diagnostic override (same-box A/B); 2 / 4: force the 128- / 256-channel tile.
   {
-    static const int fold_env = getenv("PD_LIN_FOLD") ? atoi(getenv("PD_LIN_FOLD")) : -1;
+    const int fold_env = diag_env("PD_LIN_FOLD", -1);
     const size_t need = pd_linear_fold_workspace(a);
     if (fold_env != 0 && need > 0 && a->fold_ws != nullptr && a->fold_ws_bytes >= need) {
       hipStream_t st = (hipStream_t)stream;
@@ -1156,7 +1156,7 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   // DMA-staged 256-token kernel (round 3) for the plain layers with enough tiles to fill the chip: no GroupNorm prologue, dense
   // output, no statistics, K a multiple of 64, a 16-byte-aligned row stride.  PD_LIN_DMA=0 / 2 / 3 / 4: diagnostic override (off / variant).
   {
-    static const int dma_env = getenv("PD_LIN_DMA") ? atoi(getenv("PD_LIN_DMA")) : -1;
+    const int dma_env = diag_env("PD_LIN_DMA", -1);
     const bool plain = a->dtype != PD_F32 && !a->scale && a->qkv_heads == 0 && !a->stats_out && !a->kmax2_out && a->K % 64 == 0 &&
                        a->x_stride % 8 == 0 && ((size_t)a->M * (glu ? a->N / 2 : a->N) * 2) < 0xC0000000ull;
     if (plain && dma_env != 0) {
@@ -1173,7 +1173,7 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
       //   64^2 qkv .153/.140/.130  out .047/.064/.045  ff2 1280->320 .157/.182/.121 (888 TF/s)     32^2 qkv .102/.103/.099  out .039/.049/.036  ff2 2560->640 .124/.144/.107
       //   16^2 qkv .094/.095/.104  out .044/.044/.051  ff2 .149/.142/.159 -> from 32 768 tokens up, with at least one workgroup per CU (not behind the fused GEGLU:
       //   its (value, gate) tiles pair up inside a wave).  PD_LIN_NC5=0: diagnostic override (same-box A/B)
-      static const bool nc5_off = getenv("PD_LIN_NC5") && atoi(getenv("PD_LIN_NC5")) == 0;
+      const bool nc5_off = diag_env("PD_LIN_NC5", 1) == 0;
       const bool can5 = !glu && a->N_pad % 320 == 0 && a->N == a->N_pad;
       if (dma_env >= 2 && dma_env <= 4) nc = dma_env;
       else if (dma_env == 5 ? can5 : (can5 && !nc5_off && t256 >= 128 && (long long)t256 * (a->N_pad / 320) >= 256)) nc = 5;
@@ -1189,7 +1189,7 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
   }
   // 256-channel tiles (NC = 4): every staged token tile feeds twice the MFMAs (the activation stream is this kernel's larger cost,
   // DESIGN.md 9); two workgroups per CU.  PD_LIN_NC4=0/1: diagnostic override (same-box A/B).
-  static const int nc4_env = getenv("PD_LIN_NC4") ? atoi(getenv("PD_LIN_NC4")) : -1;
+  const int nc4_env = diag_env("PD_LIN_NC4", -1);
   // a ragged last tile (N not a multiple of 256) repeats clamped weight tiles whose results are never stored: allowed up to 10 % waste
   const int c_tiles4 = (a->N_pad + 255) / 256;
   const bool nc4 = !narrow && !a->stats_out && (long long)c_tiles4 * 256 * 10 <= (long long)a->N_pad * 11 &&

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/phendiff_hip.h"
 
 namespace pd {
@@ -14,6 +15,11 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 struct half_t { unsigned short bits; };   // raw IEEE fp16 bits: a distinct type, so templates can tell the two 16-bit formats apart
 
 void set_error(const char* fmt, ...);
+
+// Kernel-selecting diagnostic switch, read from the environment at EVERY dispatch (a linear scan of environ: ~0.1 us): one process can
+// capture the same trajectory under several switch settings and replay them in alternation (scripts/ab_cells.py: the same-box,
+// same-thermal-state A/B the whole-workload decisions are made by).  The driver's run carries none of them (bench.py diagnostic_env).
+static inline int diag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 #define PD_CHECK(cond, code, ...)        \
   do {                                   \

@@ -568,7 +568,10 @@ class UNetPlan:
         self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}", flops, nbytes))
         return y, a
 
-    SUBPIXEL_UP = __import__("os").environ.get("PD_SUBPIXEL_UP", "1") != "0"      # diagnostic: same-box A/B against the 3x3-over-upsampled form
+    @property
+    def SUBPIXEL_UP(self):      # diagnostic (read when a plan is built): same-box A/B against the 3x3-over-upsampled form
+        return __import__("os").environ.get("PD_SUBPIXEL_UP", "1") != "0"
+
 
     def _subpixel_up_ok(self, x):
         B, h, w, ch = x.shape
