@@ -399,6 +399,8 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
         if constexpr (k < 36) {
           constexpr int half = k / 18, kk = k % 18, stg = kk >> 1, j = half * 2 + (kk & 1);
           if constexpr (stg == 0) { const uint32_t wj = Stage<T>::word(stage[i], j); float lo, hi; Pack16<T>::unpack(wj, lo, hi); pw[j].x = lo; pw[j].y = hi; }
+          // (fp16: y stays fp32 here, the non-PRO path -- Stage<half_t>::xform_gs -- rounds y to fp16 before the sigmoid: the two forms of an
+          //  fp16 layer agree to fp16 rounding, NOT bit for bit, and dispatch picks the form from B, W and PD_CONV_PRO; bf16 / fp32 are unaffected)
           else if constexpr (stg == 1) py[j] = pw[j] * (f32x2){sc[2 * j], sc[2 * j + 1]} + (f32x2){sh[2 * j], sh[2 * j + 1]};
           else if constexpr (stg == 2) pw[j] = py[j] * (f32x2)(-1.4426950408889634f);
           else if constexpr (stg == 3) pw[j].x = __builtin_amdgcn_exp2f(pw[j].x);

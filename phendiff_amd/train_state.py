@@ -160,7 +160,9 @@ def save_state(trainer, output_dir: str, rank: int = 0, base_lr: Optional[float]
     for i, mod, _ in mods:
         torch.save({k: v.detach().cpu() for k, v in mod.state_dict().items()}, os.path.join(output_dir, _model_file(i)))
     torch.save(optimizer_state_dict(pnames, fnames, sizes, opt.exp_avg, opt.exp_avg_sq, opt.t, opt.lr, opt.betas, opt.eps, opt.wd,
-                                    {n: opt.t_tail for n in getattr(opt, "tail_names", ())}),
+                                    # a frozen parameter (requires_grad_(False), train.py:189-220) never gets a gradient: torch.optim.AdamW
+                                    # keeps NO state entry for it, and neither does this file
+                                    {**{n: opt.t_tail for n in getattr(opt, "tail_names", ())}, **{n: 0 for n in getattr(trainer, "frozen", ())}}),
                os.path.join(output_dir, "optimizer.bin"))
     torch.save(lr_scheduler_state_dict(base_lr if base_lr is not None else opt.lr, lr_step if lr_step is not None else opt.t,
                                        current_lr if current_lr is not None else opt.lr), os.path.join(output_dir, "scheduler.bin"))

@@ -701,9 +701,13 @@ class UNetPlan:
             a = L.LinearArgs(dtype=self.code, M=M, K=ch, N=3 * ch, N_pad=3 * ch, x=x.data_ptr(), x_stride=ch, w_packed=e.wqkv.data_ptr(),
                              bias=e.bqkv.data_ptr(), residual=None, y=qkv.data_ptr(), scale=gn[0].data_ptr(), shift=gn[1].data_ptr(),
                              rows_per_sample=h * w, qkv_heads=e.heads, kmax2_out=kmax2)
-            # 16-bit engines: the GroupNorm affine folded into per-sample weights, the projection through the DMA-staged GEMM
-            # (pd_linear's `fold_ws` route); the attentions of one forward run one after the other and share the workspace
-            need = int(self.lib.pd_linear_fold_workspace(C.byref(a)))
+            # 16-bit engines, OPT-IN (PD_LIN_FOLD=1): the GroupNorm affine folded into per-sample weights, the projection through the
+            # DMA-staged GEMM (pd_linear's `fold_ws` route); the attentions of one forward run one after the other and share the
+            # workspace.  Round 5's one-process 2x2x2 factorial on the whole headline workload (profiles/r5_ab_factorial.log): the route
+            # is faster per layer (0.106 -> 0.08 ms) and SLOWER per trajectory -- 15.844 images/s with it, 16.043 without (-1.2 %, spread
+            # +-0.1 %; neutral on configs[1]) -- the denser MFMA issue costs the attention next to it more clock than the layer saves.
+            # Decisions are taken on the whole workload: the staged route is the default.
+            need = int(self.lib.pd_linear_fold_workspace(C.byref(a))) if __import__("os").environ.get("PD_LIN_FOLD", "0") != "0" else 0
             if need > 0:
                 ws = getattr(self, "_fold_ws", None)
                 if ws is None or ws.numel() < need:

@@ -867,6 +867,12 @@ class UNetTrainer:
         if m._weights is None:
             m._weights = self._make_packed()
         self._tw = self._make_train_weights()
+        # ONE gradient-layout set per model: the model's input-gradient plans (gradient-guided transfer of a model fine-tuned
+        # in the same process, utils_Img2Img.py:651-760 after train.py) read the trainer's set, which the re-packer refreshes after
+        # every optimizer step; input-gradient plans built on an older set are dropped
+        m._grad_weights = self._tw
+        for k in [k for k in m._plans if isinstance(k, tuple) and k and k[0] == "input_grad"]:
+            del m._plans[k]
         self._repack = None
         self._plans = {}
         self._bucket_key = None

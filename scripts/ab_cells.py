@@ -30,15 +30,19 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-def smi_sample():
+def smi_sample(raw=False):
+    """(sclk MHz, socket power W) of card 0 from one `rocm-smi` child process (key names differ between releases: matched loosely)."""
+    import re
     try:
         r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
-        j = json.loads(r.stdout)
+        if raw:
+            return r.stdout[:1500]
+        j = json.loads(r.stdout[r.stdout.index("{"):])
         card = j[sorted(k for k in j if k.startswith("card"))[0]]
-        sclk = next((v for k, v in card.items() if k.startswith("sclk clock speed")), None)
-        pw = next((v for k, v in card.items() if "Power" in k and "W" in k), None)
-        mhz = float(str(sclk).strip("()MHz ").replace("Mhz", "")) if sclk else None
-        return mhz, (float(pw) if pw else None)
+        sclk = next((v for k, v in card.items() if "sclk" in k.lower()), None)
+        pw = next((v for k, v in card.items() if "power" in k.lower() and "(w)" in k.lower()), None)
+        num = lambda v: float(re.search(r"[-+]?\d+(\.\d+)?", str(v)).group(0))      # noqa: E731
+        return (num(sclk) if sclk else None), (num(pw) if pw else None)
     except Exception:      # noqa: BLE001
         return None, None
 
@@ -100,8 +104,11 @@ def main():
     for cell, o in outputs.items():
         print(f"output of {cell!r} vs the first cell: max |diff| = {float((o - ref).abs().max()):.3e}", flush=True)
 
+    if args.smi:
+        print("rocm-smi sample:", smi_sample(), "raw:", smi_sample(raw=True).replace("\n", " ")[:600], flush=True)
     results = collections.defaultdict(list)
     smi = collections.defaultdict(list)
+    in_situ = {}
     order = list(cells)
     for r in range(args.rounds):
         for cell in (order if r % 2 == 0 else order[::-1]):
@@ -133,6 +140,18 @@ def main():
                 ok = [s for s in samples if s[0]]
                 extra = f"  sclk {statistics.median(s[0] for s in ok):.0f} MHz  power {statistics.median(s[1] for s in ok if s[1]):.0f} W"
             print(f"round {r + 1}  {cell:58s} {v:8.4f} images/s{extra}", flush=True)
+    # the dominant kernel's launch time IN SITU under every cell (bench._in_situ_launch_ms: steady-state eager replay of the cell's plan)
+    for cell in order:
+        runner = cells[cell][0]
+        one_batch(runner)
+        for k in touched:                         # the eager replay dispatches anew: the cell's switches go back into the environment
+            os.environ.pop(k, None)
+        os.environ.update({} if cell == "-" else dict(w.split("=", 1) for w in cell.split(",")))
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ms, _, n = bench._in_situ_launch_ms(runner.plan, "attn_d8", st)
+        torch.cuda.synchronize(dev)
+        in_situ[cell] = ms
+        print(f"in situ  {cell:58s} attn_d8 {ms:.4f} ms per launch ({n} samples)", flush=True)
     base = statistics.median(results[order[0]])
     lines = []
     for cell in order:
@@ -140,12 +159,12 @@ def main():
         m = statistics.median(v)
         s = smi.get(cell) or []
         extra = f"  sclk {statistics.median(a for a, _ in s):.0f} MHz  power {statistics.median(b for _, b in s if b):.0f} W" if s else ""
-        lines.append(f"{cell:58s} median {m:8.4f}  x{m / base:.4f}  min {min(v):.4f} max {max(v):.4f}{extra}  {[round(a, 3) for a in v]}")
+        lines.append(f"{cell:58s} median {m:8.4f}  x{m / base:.4f}  min {min(v):.4f} max {max(v):.4f}  attn in situ {in_situ[cell]:.4f} ms{extra}  {[round(a, 3) for a in v]}")
     print("\n".join(lines), flush=True)
     if args.out:
         with open(args.out, "w") as f:
             json.dump({"cells": {c: results[c] for c in order}, "rounds": args.rounds, "steps": args.steps, "batch": B,
-                       "smi": {c: smi.get(c) for c in order}}, f)
+                       "smi": {c: smi.get(c) for c in order}, "attn_d8_in_situ_ms": in_situ}, f)
 
 
 if __name__ == "__main__":

@@ -5,19 +5,25 @@
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${R:-r3}          # round tag of the files written (profiles/${R}_*)
+R=${R:-r5}          # round tag of the files written (profiles/${R}_*)
 OUT=gpurun_out/profiles_new
 mkdir -p $OUT
-stats() {   # <tag> <log name> -- bench args
-  local tag=$1 log=$2; shift 2
+# Steady state only (round 5): every collection runs BATCHES = warm-up + timed steps of the workload and the summary is computed from
+# the kernel trace with the first DISCARD batches cut off (scripts/steady_stats.py) -- rocprofv3's own --stats file, which averages
+# over the cold first batches too, is kept beside it as *_whole_run.csv.
+stats() {   # <tag> <log name> <batches> <discard> -- bench args (whose --warmup + --steps == batches)
+  local tag=$1 log=$2 batches=$3 discard=$4; shift 4
   local d=/tmp/prof_$tag
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py "$@" > $OUT/$log 2>$OUT/$log.err
-  cp "$(ls $d/*/*_kernel_stats.csv | head -1)" $OUT/${R}_${tag}_kernel_stats.csv
+  cp "$(ls $d/*/*_kernel_stats.csv | head -1)" $OUT/${R}_${tag}_kernel_stats_whole_run.csv
+  python3 scripts/steady_stats.py "$(ls $d/*/*_kernel_trace.csv | head -1)" $batches $discard $OUT/${R}_${tag}_kernel_stats.csv 2> $OUT/${R}_${tag}_kernel_stats.note
+  cat $OUT/${R}_${tag}_kernel_stats.note
   echo "== $tag: $(tail -c 300 $OUT/$log | head -c 300)"
 }
 case "$1" in
 head)
-  stats b32 ${R}_bench_under_rocprof_b32.log --steps 1 --warmup 1 --batch 32 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
+  stats b32 ${R}_bench_under_rocprof_b32.log 6 2 --steps 4 --warmup 2 --batch 32 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
+  for x in kernel_stats.csv kernel_stats_whole_run.csv kernel_stats.note; do mv $OUT/${R}_b32_$x $OUT/${R}_kernel_stats_b32${x#kernel_stats}; done
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads > /dev/null 2>$OUT/pmc_$c.err
   done
@@ -34,7 +40,7 @@ head)
 train)
   python3 bench.py --workload train --steps 10 --warmup 2 > $OUT/${R}_bench_train.json 2>/dev/null
   cut -c1-200 $OUT/${R}_bench_train.json
-  stats train_b112 ${R}_train_bench_under_rocprof_b112.log --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
+  stats train_b112 ${R}_train_bench_under_rocprof_b112.log 40 10 --workload train --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
   mv $OUT/${R}_train_b112_kernel_stats.csv $OUT/${R}_train_kernel_stats_b112.csv
   ;;
 sd)
@@ -42,9 +48,9 @@ sd)
   cut -c1-200 $OUT/${R}_bench_sd_img2img.json
   python3 bench.py --workload sd_train --steps 10 --warmup 2 > $OUT/${R}_bench_sd_train.json 2>/dev/null
   cut -c1-200 $OUT/${R}_bench_sd_train.json
-  stats sd_img2img_b32 ${R}_sd_img2img_bench_under_rocprof_b32.log --workload sd_img2img --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-side-workloads
+  stats sd_img2img_b32 ${R}_sd_img2img_bench_under_rocprof_b32.log 3 1 --workload sd_img2img --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-side-workloads
   mv $OUT/${R}_sd_img2img_b32_kernel_stats.csv $OUT/${R}_sd_img2img_kernel_stats_b32.csv
-  stats sd_train_b32 ${R}_sd_train_bench_under_rocprof_b32.log --workload sd_train --steps 5 --warmup 2 --no-roofline --no-cpu-baseline --no-side-workloads
+  stats sd_train_b32 ${R}_sd_train_bench_under_rocprof_b32.log 12 4 --workload sd_train --steps 8 --warmup 4 --no-roofline --no-cpu-baseline --no-side-workloads
   mv $OUT/${R}_sd_train_b32_kernel_stats.csv $OUT/${R}_sd_train_kernel_stats_b32.csv
   ;;
 esac

@@ -2,6 +2,8 @@
 ``--attention_fine_tuning`` (``unet.requires_grad_(False)`` then ``module.attentions.requires_grad_(True)``), class-embedding-only
 training -- against ``torch.autograd`` + ``clip_grad_norm_`` + ``torch.optim.AdamW`` on the CPU oracle with the same flags (torch
 skips a parameter whose ``.grad`` is None: no decay, no moments, no step, not in the norm)."""
+import os
+
 import pytest
 import torch
 
@@ -89,6 +91,15 @@ def test_attention_fine_tuning_follows_torch():
         ref_out = r(noisy, ts, class_labels=labels).sample
     assert rel(m(noisy.cuda(), ts.cuda(), class_labels=labels.cuda()).sample, ref_out) < 1e-4
     assert float(ref_norm) > 0
+    # optimizer.bin of the checkpoint == torch's AdamW.state_dict(): a state entry for the parameters that got gradients, NONE for the frozen ones
+    # (an unfrozen-later parameter must not resume with a bias-correction step it never took)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        tr.save_state(d)
+        osd = torch.load(os.path.join(d, "optimizer.bin"), map_location="cpu")
+    ref_osd = opt.state_dict()
+    assert set(osd["state"]) == set(ref_osd["state"]) and len(osd["state"]) == 60
+    assert all(float(v["step"]) == 3.0 for v in osd["state"].values())
 
 
 def test_clip_norm_excludes_frozen_gradients():

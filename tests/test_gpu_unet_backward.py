@@ -129,6 +129,35 @@ def test_inference_after_training_steps_sees_the_updated_upsampler_phase_kernels
     assert rel(out, ref) < 2e-5
 
 
+def test_input_gradient_after_training_steps_sees_the_updated_gradient_layout_weights():
+    """ADVICE r4: `input_grad_plan` (the gradient-guided transfer) caches the transposed / flipped input-gradient weights on the model;
+    a trainer's re-pack after every optimizer step has to refresh THAT set too -- d out / d sample of the trained model, through a plan
+    built BEFORE the training steps and through one built after, against autograd over the oracle holding the trained state_dict."""
+    from phendiff_amd.unet_train import UNetTrainer
+    r, m = make_pair("super_small", 32, "f32")
+    sched, clean, noise, ts, labels, noisy, target = batch(2, 32)
+    dev = torch.device("cuda:0")
+    early = m.input_grad_plan(2, 32, 32, dev)            # built on the untrained weights
+    tr = UNetTrainer(m, sched, lr=2e-3, use_ema=False)
+    for _ in range(2):
+        tr.step(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    r.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    x = noisy.clone().requires_grad_(True)
+    out_ref = r(x, ts, class_labels=labels).sample
+    g = torch.Generator().manual_seed(5)
+    dout = torch.randn(out_ref.shape, generator=g)
+    (gx,) = torch.autograd.grad((out_ref * dout).sum(), x)
+    plan = m.input_grad_plan(2, 32, 32, dev)
+    assert plan is not early                              # the stale plan was dropped when the trainer bound its gradient-layout set
+    st = torch.cuda.current_stream().cuda_stream
+    o = torch.empty(2, 3, 32, 32, device=dev)
+    plan.forward(noisy.cuda().contiguous(), ts.cuda().float(), labels.cuda(), None, o, st)
+    plan.backward(dout.cuda().contiguous(), st)
+    torch.cuda.synchronize()
+    assert rel(o, out_ref.detach()) < 2e-5 and rel(plan.dsample, gx) < 2e-5
+
+
 # (bf16 per-parameter bound: the worst parameters are attention to_q / to_k weights of the 4x4 / 2x2 levels whose gradients carry 6e-5 of the
 #  global norm -- measured 0.079 with the 3x3 upsampler form, 0.082 with the sub-pixel form of round 4; global error 5.1e-3 either way)
 @pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 2e-4, 2e-5), ("bf16", 1.2e-1, 2e-2)])
