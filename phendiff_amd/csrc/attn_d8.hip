@@ -935,7 +935,7 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
   const int qbw = 1;
 #endif
   // 8-wave workgroups (256 queries share each staged tile) once there are enough query blocks to fill the chip with them
-  static const bool wpb4_only = getenv("PD_ATTN_WPB4") != nullptr;      // diagnostic: same-box A/B
+  const bool wpb4_only = diag_env("PD_ATTN_WPB4", 0) != 0;      // diagnostic: same-box A/B
   const bool wide = !wpb4_only && qbw == 1 && a->N >= 1024 && (long long)(a->N / 256) * a->heads * a->B >= 1024;
   const int qpb = wide ? 256 : 128 * qbw;
   PD_CHECK((long long)((a->N + qpb - 1) / qpb) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8: grid too large");
@@ -956,7 +956,7 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
     PD_LAUNCH_CHECK();
     return PD_OK;
   }
-  static const bool no_glds = getenv("PD_ATTN_NO_GLDS") != nullptr;      // diagnostic: same-box A/B
+  const bool no_glds = diag_env("PD_ATTN_NO_GLDS", 0) != 0;      // diagnostic: same-box A/B
   if (a->kmax2 && wide && !no_glds && a->dtype != PD_F32) {
     if (a->dtype == PD_BF16) hipLaunchKernelGGL((attn_glds_kernel<bf16_t>), grid, dim3(512), 0, st, *a);
     else if (a->dtype == PD_F16) {

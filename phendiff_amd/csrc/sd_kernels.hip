@@ -314,7 +314,7 @@ extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
   if (a->dtype == PD_BF16) {
     // two query fragments per wave once that still fills the chip (256 CUs x 2 resident workgroups) and the key sequence is
     // long enough for the LDS traffic to matter
-    static const bool qb1_only = getenv("PD_ATTN64_QB1") != nullptr;      // diagnostic: same-box A/B
+    const bool qb1_only = diag_env("PD_ATTN64_QB1", 0) != 0;      // diagnostic: same-box A/B
     const bool wide = !qb1_only && a->Nkv >= 512 && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
     return wide ? launch_attn_d64<bf16_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<bf16_t, 1>(a, (hipStream_t)stream);
   }

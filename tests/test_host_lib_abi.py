@@ -45,7 +45,7 @@ def test_struct_field_order_matches_header():
              "pd_geglu_bwd_args": L.GegluBwdArgs, "pd_linear_args": L.LinearArgs, "pd_gn_apply_args": L.GnApplyArgs, "pd_token_wgrad_args": L.TokenWgradArgs, "pd_layernorm_args": L.LayerNormArgs, "pd_geglu_args": L.GegluArgs,
              "pd_pack_weight_args": L.PackWeightArgs, "pd_pack_weight_batch_args": L.PackWeightBatchArgs, "pd_zero_args": L.ZeroArgs}
     for cname, cls in pairs.items():
-        body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + ";", src, flags=re.S).group(1)
+        body = re.search(r"typedef struct(?:\s+\w+)?\s*\{([^{}]*)\}\s*" + cname + ";", src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
         for decl in body.split(";"):
