@@ -31,9 +31,8 @@ extern "C" {
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
  * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
  * fold_ws_bytes + pd_linear_fold_workspace,
- * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_conv_args.fin / fin_counter (the consumer's
- * GroupNorm finalize as the tail of the producing convolution). */
-#define PD_ABI_VERSION 6
+ * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase. */
+#define PD_ABI_VERSION 5
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
@@ -127,7 +126,6 @@ int pd_gn_stats(const pd_gn_stats_args* a, void* stream);
  * (r = l & 31, h = l >> 5) element j is W[co = 32*ct + r][ci = 32*chunk + 16*s + 8*h + j][tap].
  */
 typedef enum { PD_OUT_NHWC = 0, PD_OUT_NCHW_F32 = 1, PD_OUT_QKV_HEADS = 2 } pd_out_mode;
-struct pd_gn_finalize_args_s;   /* (defined below: pd_gn_finalize_args) */
 typedef struct {
   int dtype;
   int B, Hin, Win;          /* source spatial size (before upsample) */
@@ -175,17 +173,6 @@ typedef struct {
                                Wout = Win: y[oy][ox] (+= residual) = sum over dy, dx = 0, 1 of W[dy][dx] . x0[2 (oy - a + dy) + a][2 (ox - b + dx) + b]
                                (W = the phase's 2x2 weights packed as input-gradient weights: transposed, taps flipped).  residual is
                                allowed (the four phases accumulate into one gradient tensor); no stats_out */
-  /* (ABI 6) The GroupNorm finalize of y's CONSUMER as the tail of this launch (what a separate pd_gn_finalize launch between producer and
-     consumer does: cond_unet_2d.py's ResnetBlock2D.norm1 / norm2 / Attention.group_norm statistics): every workgroup publishes its
-     stats_out rows and bumps fin_counter[n]; the workgroup that arrives last for sample n folds the rows into scale / shift
-     (fixed-order fp64 tree: the result does not depend on which workgroup that is).
-       fin          NULL, or a DEVICE-resident pd_gn_finalize_args whose stats0 (or stats1) is this launch's stats_out; the other
-                    source's statistics, if any, must be complete before this launch starts.  Requires stats_out.
-       fin_counter  [B] uint32, zero before the first launch; the finalizing workgroup resets its slot
-     A tensor several launches write (the four sub-pixel phases of an upsampler) is finalized by the LAST of them in stream order: the
-     earlier launches' rows are complete at its start. */
-  const struct pd_gn_finalize_args_s* fin;
-  unsigned int* fin_counter;
 } pd_conv_args;
 int pd_conv(const pd_conv_args* a, void* stream);
 /* number of statistic tiles per sample pd_conv writes for this shape (depends on the kernel's tile choice) */
@@ -193,7 +180,7 @@ int pd_conv_stat_tiles(int Hout, int Wout, int ksize, int stride);
 
 /* pd_gn_finalize: per-tile channel sums (pd_conv stats_out) of one or two tensors (channel concat [x0 | x1]) ->
  * GroupNorm scale/shift per (sample, channel):  scale = rstd*gamma, shift = beta - mean*rstd*gamma  (fp64 combine). */
-typedef struct pd_gn_finalize_args_s {
+typedef struct {
   int B, HW, groups; float eps;
   int C0, T0; const float* stats0;     /* [B][T0][C0][2] */
   int C1, T1; const float* stats1;     /* [B][T1][C1][2] or NULL (C1 = 0) */

@@ -38,7 +38,7 @@ def library_is_current() -> bool:
 PD_F32, PD_BF16, PD_F16 = 0, 1, 2
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 5
 
 vp = C.c_void_p
 
@@ -68,8 +68,7 @@ class ConvArgs(C.Structure):
                 ("stride", C.c_int), ("pad", C.c_int), ("upsample", C.c_int), ("silu", C.c_int), ("out_mode", C.c_int),
                 ("heads", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("w_packed", vp), ("bias", vp),
                 ("temb", vp), ("temb_stride", C.c_int), ("residual", vp), ("y", vp), ("stats_out", vp), ("tail_x0", vp), ("tail_x1", vp), ("tail_C0", C.c_int),
-                ("tail_C1", C.c_int), ("im2col3", C.c_int), ("phase", C.c_int), ("phase_in", C.c_int),
-                ("fin", vp), ("fin_counter", vp)]
+                ("tail_C1", C.c_int), ("im2col3", C.c_int), ("phase", C.c_int), ("phase_in", C.c_int)]
 
 
 class GnFinalizeArgs(C.Structure):

@@ -20,7 +20,6 @@
 #include "pd_common.h"
 #include "pd_stage.h"
 #include "pd_conv.h"
-#include "pd_gn_fin.h"
 
 #ifndef PD_S2_SINGLE
 #define PD_S2_SINGLE 1
@@ -923,10 +922,6 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
     }
   }
   }   // cth
-  if (p.fin) {   // kernel-uniform: the consumer's GroupNorm finalize, by the last workgroup of this sample (pd_gn_fin.h)
-    __syncthreads();
-    gn_fused_finalize_tail(p.fin, p.fin_counter, gridDim.x * gridDim.y, n, lds, tid);
-  }
   PD_STAMP(6);
 }
 
@@ -1132,8 +1127,6 @@ extern "C" int pd_conv(const pd_conv_args* a, void* stream) {
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.w = a->w_packed; p.bias = a->bias;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.residual = a->residual; p.y = a->y;
   p.stats = a->stats_out; p.im2col3 = a->im2col3 ? 1 : 0; p.C0r = a->im2col3;
-  PD_CHECK(a->fin == nullptr || (a->stats_out != nullptr && a->fin_counter != nullptr), PD_ERR_ARG, "pd_conv: fin needs stats_out and fin_counter");
-  p.fin = (const pd_gn_finalize_args*)a->fin; p.fin_counter = a->fin_counter;
   p.pad_x = a->pad; p.out_step = 1; p.in_step = 1;
   if (a->phase) {          // phase 1 + 2 a + b: rows start at oy - (1 - a), columns at ox - (1 - b)
     const int pa = (a->phase - 1) >> 1, pb = (a->phase - 1) & 1;

@@ -30,9 +30,6 @@ struct ConvP {
   int pad_x, out_step, out_oy, out_ox, stat_tile_base, stat_tiles;
   // input-side phase (pd_conv_args.phase_in): source pixel (in_step iy + in_oy, in_step ix + in_ox) of a tensor in_step times as large
   int in_step, in_oy, in_ox;
-  // the consumer's GroupNorm finalize as this launch's tail (pd_conv_args.fin): device-resident args, per-sample arrival counter
-  const pd_gn_finalize_args* fin;
-  unsigned* fin_counter;
 };
 
 }  // namespace pd

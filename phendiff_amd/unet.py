@@ -482,10 +482,6 @@ class UNetPlan:
         self.ops = []
         self.bufs = []          # keep every device buffer alive
         self.stats = {}         # id(NHWC activation) -> (per-tile channel sums [B][T][C][2], T) written by its producer
-        self._producer = {}     # id(NHWC activation) -> ConvArgs of the (last) pd_conv launch that writes it and its statistic rows
-        # round 5: a GroupNorm's finalize runs as the TAIL of the convolution that produced its input (pd_conv_args.fin) instead of a
-        # launch of its own between producer and consumer.  PD_GN_FUSED=0: diagnostic, same-box A/B against the separate launches
-        self.fused_finalize = __import__("os").environ.get("PD_GN_FUSED", "1") != "0"
         self._kmax_arena, self._kmax_used = None, 0   # max |k|^2 per (sample, head) of every d = 8 attention (zeroed once per forward)
         self.groups = c.norm_num_groups
         self.temb_args = None
@@ -525,19 +521,6 @@ class UNetPlan:
             mean, rstd = self._f32(self.B, self.groups), self._f32(self.B, self.groups)
             a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
             self.gn_saved[id(scale)] = SimpleNamespace(mean=mean, rstd=rstd, gamma=gamma, beta=beta, x0=x0, x1=x1)
-        # The producer of x0 is the launch right before this GroupNorm's consumer (x1, a skip connection, was written long before):
-        # when it is a pd_conv launch that has no finalize attached yet, the finalize becomes its tail.  Not for the "scale_shift"
-        # ResNets (their finalize args change per step: the temb row) -- those, and the tensors other kernels produce (conv_in,
-        # the attention's output projection), keep the launch.
-        pa = self._producer.get(id(x0)) if self.fused_finalize and temb_off is None else None
-        if pa is not None and not pa.fin and pa is self.ops[-1].args:
-            dev_args = torch.frombuffer(bytearray(C.string_at(C.byref(a), C.sizeof(a))), dtype=torch.uint8).to(self.device)
-            counter = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
-            self.bufs += [dev_args, counter]
-            self._fin_host = getattr(self, "_fin_host", []) + [a]       # (the host copy: what the device bytes were made from)
-            pa.fin, pa.fin_counter = dev_args.data_ptr(), counter.data_ptr()
-            self.ops[-1].bytes += self.B * (t0 * c0 + t1 * c1) * 8.0
-            return scale, shift
         self.ops.append(_Op(self.lib.pd_gn_finalize, a, "gn_finalize", 0.0, self.B * (t0 * c0 + t1 * c1) * 8.0))
         return scale, shift
 
@@ -583,8 +566,6 @@ class UNetPlan:
         if out_mode == L.PD_OUT_NCHW_F32:
             nbytes += B * hout * wout * cout * (4 - esz)
         self.ops.append(_Op(self.lib.pd_conv, a, f"conv{ksize}x{ksize}", flops, nbytes))
-        if st is not None:
-            self._producer[id(y)] = a
         return y, a
 
     @property
@@ -616,7 +597,6 @@ class UNetPlan:
             # FLOPs / bytes of the LOGICAL layer (3x3 over the upsampled tensor: what the roofline accounting quotes) shared by the four launches
             self.ops.append(_Op(self.lib.pd_conv, a, "conv3x3", 2.0 * B * 4 * h * w * ch * ch * 9 / 4.0,
                                 (B * h * w * ch + B * 4 * h * w * ch) * esz / 4.0 + ch * ch * 4 * esz))
-        self._producer[id(y)] = a      # the LAST phase launch: the other three phases' statistic rows are complete when it starts
         return y
 
     # pd_conv applies GroupNorm + SiLU while staging, once per 64-channel output tile; from this many output channels on

@@ -679,62 +679,3 @@ def test_upsample_conv_input_gradient_as_four_subpixel_phases(env, mode, shape):
     assert lib.pd_conv(C.byref(a), stream()) != 0
     a.stats_out, a.phase = None, 0
     assert lib.pd_conv(C.byref(a), stream()) != 0
-
-
-# ---- round 5: the consumer's GroupNorm finalize as the tail of the producing convolution (pd_conv_args.fin) ----------------------
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(3, 64, 64, 0, 64, 64), (2, 32, 128, 64, 40, 72), (5, 64, 256, 128, 16, 16), (2, 64, 64, 0, 128, 128),
-                                   (1, 32, 512, 0, 8, 8)])
-def test_conv_with_fused_groupnorm_finalize(env, mode, shape):
-    """pd_conv with `fin`: the workgroup that arrives last for a sample folds the launch's per-tile channel sums (and a second source's,
-    for a channel concatenation whose skip tensor was produced earlier) into the CONSUMER's GroupNorm scale / shift -- against a separate
-    pd_gn_finalize launch over the same rows and against torch's group_norm statistics of the stored output.  Three launches in a
-    row: the finalizing workgroup resets the arrival counter."""
-    L, lib, pack, dev = env
-    code, tdt = DT[mode]
-    B, cin, cout, c1, h, w_ = shape
-    g = torch.Generator().manual_seed(11)
-    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
-    b = torch.randn(cout, generator=g)
-    wp, bias = pack(w, tdt, cout).to(dev), b.to(dev)
-    C_ = cout + c1
-    gamma, beta = (torch.rand(C_, generator=g) + 0.5).to(dev), torch.randn(C_, generator=g).to(dev)
-    T = lib.pd_conv_stat_tiles(h, w_, 3, 1)
-    st0 = torch.zeros(B, T, cout, 2, device=dev)
-    # the skip tensor's rows: any earlier producer's (here: random tile sums of a random tensor, 3 tiles per sample)
-    skip = torch.randn(B, c1, h, w_, generator=g).to(dev) if c1 else None
-    st1 = None
-    if c1:
-        parts = skip.permute(0, 2, 3, 1).reshape(B, h * w_, c1).tensor_split(3, dim=1)
-        st1 = torch.stack([torch.stack([p_.sum(1), (p_ * p_).sum(1)], -1) for p_ in parts], 1).contiguous()      # [B][3][c1][2]
-    y = torch.empty(B, h, w_, cout, dtype=tdt, device=dev)
-    scale, shift = torch.empty(B, C_, device=dev), torch.empty(B, C_, device=dev)
-    mean, rstd = torch.empty(B, 32, device=dev), torch.empty(B, 32, device=dev)
-    fa = L.GnFinalizeArgs(B=B, HW=h * w_, groups=32, eps=1e-5, C0=cout, T0=T, stats0=st0.data_ptr(), C1=c1, T1=3 if c1 else 0, stats1=L.ptr(st1),
-                          gamma=gamma.data_ptr(), beta=beta.data_ptr(), scale=scale.data_ptr(), shift=shift.data_ptr(), mean=mean.data_ptr(),
-                          rstd=rstd.data_ptr())
-    fin = torch.frombuffer(bytearray(C.string_at(C.byref(fa), C.sizeof(fa))), dtype=torch.uint8).to(dev)
-    counter = torch.zeros(B, dtype=torch.int32, device=dev)
-    for rep in range(3):
-        x = torch.randn(B, cin, h, w_, generator=g)
-        X = nhwc(x.to(dev), tdt)
-        a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=w_, Hout=h, Wout=w_, C0=cin, C1=0, Cout=cout, Cout_pad=cout, ksize=3, stride=1, pad=1,
-                       x0=X.data_ptr(), w_packed=wp.data_ptr(), bias=bias.data_ptr(), y=y.data_ptr(), stats_out=st0.data_ptr(),
-                       fin=fin.data_ptr(), fin_counter=counter.data_ptr())
-        scale.fill_(float("nan")); shift.fill_(float("nan"))
-        L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
-        torch.cuda.synchronize()
-        assert int(counter.abs().sum()) == 0                     # every sample's slot was reset by its finalizing workgroup
-        fused = (scale.clone(), shift.clone(), mean.clone(), rstd.clone())
-        L.check(lib.pd_gn_finalize(C.byref(fa), stream()), "pd_gn_finalize")
-        torch.cuda.synchronize()
-        for got, sep in zip(fused, (scale, shift, mean, rstd)):  # the separate launch over the same rows (both fp64 trees)
-            assert torch.isfinite(got).all() and float((got - sep).abs().max()) <= 2e-6 * float(sep.abs().max())
-        full = torch.cat([y.float().permute(0, 3, 1, 2)] + ([skip] if c1 else []), 1)
-        xg = full.reshape(B, 32, -1).double()
-        m_ref, v_ref = xg.mean(2), xg.var(2, unbiased=False)
-        assert float((fused[2].double() - m_ref).abs().max()) < 1e-4 * (1 + float(m_ref.abs().max()))
-        assert rel(fused[3], 1.0 / torch.sqrt(v_ref + 1e-5)) < 1e-4
-    # fin without its counter is refused
-    a.fin_counter = None
-    assert lib.pd_conv(C.byref(a), stream()) == -1 and b"fin" in lib.pd_last_error()

@@ -565,24 +565,3 @@ def test_forward_slices_batches_beyond_the_2gib_tensor_limit(monkeypatch):
     assert sliced.shape == whole.shape and torch.equal(sliced, whole)
     emb = torch.randn(7, m.time_embed_dim, generator=g).cuda()
     assert torch.equal(m(x, 400, class_emb=emb, return_dict=False)[0][4:], m(x[4:], 400, class_emb=emb[4:]).sample)
-
-
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_fused_groupnorm_finalize_gives_the_separate_launches_forward(mode, monkeypatch):
-    """Round 5: every GroupNorm whose input a pd_conv launch produced is finalized by that launch's last workgroup (pd_conv_args.fin)
-    instead of a pd_gn_finalize launch of its own.  Same statistic rows, both fp64 trees: the forward agrees with the plan that keeps
-    the separate launches (PD_GN_FUSED=0) to fp32 round-off of the affine, in both engine modes, with far fewer launches -- and a
-    repeated evaluation (the arrival counters were reset by the finalizing workgroups) gives the same bits."""
-    x, labels = synth_batch(3, 64)
-    outs, launches = {}, {}
-    for fused in ("0", "1"):
-        monkeypatch.setenv("PD_GN_FUSED", fused)
-        _, m = make_pair("super_small", 64, mode)
-        a = m(x.cuda(), 640, class_labels=labels.cuda()).sample.clone()
-        b = m(x.cuda(), 640, class_labels=labels.cuda()).sample.clone()
-        assert torch.equal(a, b)
-        outs[fused] = a
-        plan = next(iter(m._plans.values()))
-        launches[fused] = sum(op.what == "gn_finalize" for op in plan.ops)
-    assert launches["0"] == 41 and launches["1"] <= 8, launches      # conv_in's and the six attention output projections' consumers keep theirs
-    assert rel(outs["1"], outs["0"]) < (2e-6 if mode == "f32" else 2e-3)
