@@ -271,7 +271,7 @@ def main_train(args, P, world, rank, dev, dist):
     assert torch.isfinite(loss).all()
     value = world * B * args.steps / elapsed
     res = {
-        "metric": "DDIM training images/sec (128x128 cond_unet_2d, bf16)", "value": round(value, 3), "unit": "images/s",
+        "metric": f"DDIM training images/sec (128x128 cond_unet_2d, {args.dtype})", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", **ranks,
         "config": {"workload": f"configs[1]: {size}x{size} cond_unet_2d DDIM training, {args.model} UNet (random init, seed 0), "
@@ -849,7 +849,7 @@ def main():
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--model", default="super_small")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"],
-                    help="engine mode; fp16 = the reference's --mixed_precision fp16 (inference workloads only: img2img, sd_img2img)")
+                    help="engine mode; fp16 = the reference's --mixed_precision fp16 (img2img, sd_img2img, and train under a loss scale)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many concurrently replayed "
                     "trajectories (separate HIP streams); measured: no gain (DESIGN.md section 6, scripts/bench_concurrent.py)")
@@ -894,8 +894,8 @@ def main():
             _SELFTEST["result"] = comm_selftest(dist, dev)
         except Exception as e:                                                     # noqa: BLE001 -- the self-test never takes the run down
             _SELFTEST["result"] = {"failed": repr(e)}
-    if args.dtype == "fp16" and args.workload in ("train", "sd_train"):
-        print("bench.py: fp16 is an inference mode of this engine (training runs bf16: fp32 exponent range, no GradScaler)", file=sys.stderr)
+    if args.dtype == "fp16" and args.workload == "sd_train":
+        print("bench.py: the latent-diffusion trainer runs bf16 (fp32 exponent range, no GradScaler); fp16 training is the pixel UNet's (--workload train)", file=sys.stderr)
         sys.exit(2)
     if args.workload == "train":
         return main_train(args, P, world, rank, dev, dist)

@@ -960,7 +960,6 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
   if (a->kmax2 && wide && !no_glds && a->dtype != PD_F32) {
     if (a->dtype == PD_BF16) hipLaunchKernelGGL((attn_glds_kernel<bf16_t>), grid, dim3(512), 0, st, *a);
     else if (a->dtype == PD_F16) {
-      PD_CHECK(a->lse == nullptr, PD_ERR_UNSUPPORTED, "pd_attn_d8: fp16 is an inference mode (no log-sum-exp output for a backward)");
       hipLaunchKernelGGL((attn_glds_kernel<half_t>), grid, dim3(512), 0, st, *a);
     } else { set_error("pd_attn_d8: bad dtype"); return PD_ERR_ARG; }
     PD_LAUNCH_CHECK();
@@ -973,7 +972,6 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
     else if (wide) hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, *a);
     else hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 4>), grid, dim3(256), 0, st, *a);
   } else if (a->dtype == PD_F16) {
-    PD_CHECK(a->lse == nullptr, PD_ERR_UNSUPPORTED, "pd_attn_d8: fp16 is an inference mode (no log-sum-exp output for a backward)");
     if (qbw == 2) hipLaunchKernelGGL((attn_kernel<half_t, 2, 4>), grid, dim3(256), 0, st, *a);
     else if (wide) hipLaunchKernelGGL((attn_kernel<half_t, 1, 8>), grid, dim3(512), 0, st, *a);
     else hipLaunchKernelGGL((attn_kernel<half_t, 1, 4>), grid, dim3(256), 0, st, *a);
@@ -997,6 +995,9 @@ extern "C" int pd_attn_d8_bwd(const pd_attn_bwd_args* a, void* stream) {
   } else if (a->dtype == PD_BF16) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid, dim3(256), 0, st, *a);
+  } else if (a->dtype == PD_F16) {      // fp16 training (round 5): dS = p (dP - delta) carries the loss scale; p <= 1, no overflow risk of its own
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<half_t>, grid, dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<half_t>, grid, dim3(256), 0, st, *a);
   } else { set_error("pd_attn_d8_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

@@ -20,6 +20,7 @@ template <> __device__ __forceinline__ float dsilu_t<bf16_t>(float y) {
   const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
   return s * (1.0f + y * (1.0f - s));
 }
+template <> __device__ __forceinline__ float dsilu_t<half_t>(float y) { return dsilu_t<bf16_t>(y); }   // fp16 training (round 5): the 16-bit form
 
 // Thread -> (8-channel piece, pixel row) of one (sample, pixel split); the per-channel constants of the piece sit in
 // registers for the whole pixel loop.
@@ -426,6 +427,10 @@ extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, agrid, dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + C), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), 0, st, *a);
+  } else if (a->dtype == PD_F16) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<half_t>, agrid, dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + C), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, agrid, dim3(256), 0, st, *a);
   } else { set_error("pd_gn_silu_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -437,6 +442,7 @@ extern "C" int pd_pool2x2_sum(const pd_pool2x2_args* a, void* stream) {
   const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(pool2x2_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(pool2x2_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(pool2x2_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_pool2x2_sum: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -450,6 +456,7 @@ extern "C" int pd_channel_sum(const pd_channel_sum_args* a, void* stream) {
   if (!a->x) { /* per-split sums already in the workspace */ }
   else if (a->dtype == PD_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, (a->C + 2047) / 2048), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nblk, (a->C + 2047) / 2048), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(channel_sum_kernel<half_t>, dim3(nblk, (a->C + 2047) / 2048), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_channel_sum: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   if (a->total) PD_CHECK(a->total_valid > 0 && a->total_valid <= a->C, PD_ERR_ARG, "pd_channel_sum: total_valid=%d", a->total_valid);

@@ -1224,7 +1224,7 @@ extern "C" size_t pd_token_wgrad_workspace(const pd_token_wgrad_args* a) {
 
 extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_token_wgrad: null args");
-  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16, PD_ERR_ARG, "pd_token_wgrad: bad dtype %d", a->dtype);
+  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16 || a->dtype == PD_F16, PD_ERR_ARG, "pd_token_wgrad: bad dtype %d", a->dtype);
   PD_CHECK(a->M > 0 && a->K > 0 && a->K % 8 == 0 && a->N > 0 && a->N % 8 == 0 && a->x_stride >= a->K && a->dy_stride >= a->N &&
                a->x_stride % 8 == 0 && a->dy_stride % 8 == 0, PD_ERR_SHAPE, "pd_token_wgrad: K, N and the row strides must be multiples of 8");
   PD_CHECK(a->x && a->dy && a->dw && a->slab, PD_ERR_ARG, "pd_token_wgrad: null pointer");
@@ -1259,6 +1259,9 @@ extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
   } else if (a->dtype == PD_BF16) {
     constexpr int LDS = 2 * 2 * 4 * 64 * 64;            // 64 KiB
     hipLaunchKernelGGL(token_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), LDS, st, p);
+  } else if (a->dtype == PD_F16) {                     // fp16 training (round 5): the register-staged form on the f16 MFMA
+    constexpr int LDS = 2 * 2 * 4 * 64 * 64;
+    hipLaunchKernelGGL(token_wgrad_kernel<half_t>, dim3(grid), dim3(256), LDS, st, p);
   } else {
     constexpr int LDS = 2 * 2 * 4 * 64 * 128;           // 128 KiB
     static bool attr_set = false;

@@ -450,7 +450,7 @@ using namespace pd;
 
 extern "C" size_t pd_conv_wgrad_workspace(const pd_wgrad_args* a) {
   if (!a || a->ksize < 1 || a->B < 1) return 0;
-  const int th = (a->dtype == PD_BF16 ? 8 : 4) / (a->stride == 2 ? 2 : 1);
+  const int th = (a->dtype != PD_F32 ? 8 : 4) / (a->stride == 2 ? 2 : 1);
   const int ntiles = a->B * ((a->Wout + 15) / 16) * ((a->Hout + th - 1) / th);
   const int nco = (a->Cout + 63) / 64, nci = (a->C0 + a->C1 + 63) / 64;
   return (size_t)pick_splits(ntiles, nco * nci) * a->ksize * a->ksize * nco * 64 * nci * 64 * sizeof(float);
@@ -458,7 +458,7 @@ extern "C" size_t pd_conv_wgrad_workspace(const pd_wgrad_args* a) {
 
 extern "C" int pd_conv_wgrad(const pd_wgrad_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_conv_wgrad: null args");
-  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16, PD_ERR_ARG, "pd_conv_wgrad: bad dtype");
+  PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16 || a->dtype == PD_F16, PD_ERR_ARG, "pd_conv_wgrad: bad dtype");
   PD_CHECK(a->B > 0 && a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0, PD_ERR_SHAPE, "pd_conv_wgrad: bad shape");
   PD_CHECK(a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: C0=%d C1=%d must be multiples of 32", a->C0, a->C1);
   PD_CHECK(a->Cout > 0 && a->Cout % 8 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: Cout=%d (channel stride of dy) must be a multiple of 8", a->Cout);
@@ -470,6 +470,7 @@ extern "C" int pd_conv_wgrad(const pd_wgrad_args* a, void* stream) {
     PD_CHECK((size_t)a->B * a->Hout * a->Wout * 4 * a->Cout * (a->dtype == PD_F32 ? 4 : 2) < ((size_t)1 << 31) && (size_t)a->B * a->Hin * a->Win * a->C0 * (a->dtype == PD_F32 ? 4 : 2) < ((size_t)1 << 31),
              PD_ERR_SHAPE, "pd_conv_wgrad: tensors must be < 2 GiB (32-bit buffer offsets)");
     hipStream_t stp = (hipStream_t)stream;
+    if (a->dtype == PD_F16) return launch_wgrad<half_t, 2, 1, 8>(a, stp);
     return a->dtype == PD_BF16 ? launch_wgrad<bf16_t, 2, 1, 8>(a, stp) : launch_wgrad<float, 2, 1, 4>(a, stp);
   }
   PD_CHECK((a->ksize == 3 && (a->stride == 1 || a->stride == 2)) || (a->ksize == 1 && a->stride == 1 && a->pad == 0), PD_ERR_SHAPE,
@@ -493,6 +494,11 @@ extern "C" int pd_conv_wgrad(const pd_wgrad_args* a, void* stream) {
     if (a->stride == 1) return launch_wgrad<bf16_t, 3, 1, 8>(a, st);
     return launch_wgrad<bf16_t, 3, 2, 4>(a, st);
   }
+  if (a->dtype == PD_F16) {      // fp16 training (round 5: --mixed_precision fp16, launch_script_DDIM.sh:56): the same kernel on the f16 MFMA
+    if (a->ksize == 1) return launch_wgrad<half_t, 1, 1, 8>(a, st);
+    if (a->stride == 1) return launch_wgrad<half_t, 3, 1, 8>(a, st);
+    return launch_wgrad<half_t, 3, 2, 4>(a, st);
+  }
   if (a->ksize == 1) return launch_wgrad<float, 1, 1, 4>(a, st);
   if (a->stride == 1) return launch_wgrad<float, 3, 1, 4>(a, st);
   return launch_wgrad<float, 3, 2, 2>(a, st);
@@ -504,6 +510,7 @@ extern "C" int pd_im2col3(const pd_im2col3_args* a, void* stream) {
   const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(im2col3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (float*)a->out, a->B, a->H, a->W, a->C);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(im2col3_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (bf16_t*)a->out, a->B, a->H, a->W, a->C);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(im2col3_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a->x, (half_t*)a->out, a->B, a->H, a->W, a->C);
   else { set_error("pd_im2col3: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

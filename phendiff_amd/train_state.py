@@ -166,6 +166,8 @@ def save_state(trainer, output_dir: str, rank: int = 0, base_lr: Optional[float]
                os.path.join(output_dir, "optimizer.bin"))
     torch.save(lr_scheduler_state_dict(base_lr if base_lr is not None else opt.lr, lr_step if lr_step is not None else opt.t,
                                        current_lr if current_lr is not None else opt.lr), os.path.join(output_dir, "scheduler.bin"))
+    if getattr(opt, "scaler", None) is not None:          # --mixed_precision fp16: accelerate writes the GradScaler's state_dict as scaler.pt
+        torch.save(opt.scaler.state_dict(), os.path.join(output_dir, "scaler.pt"))
     with open(os.path.join(output_dir, f"random_states_{rank}.pkl"), "wb") as f:
         pickle.dump(random_states(), f)
     if opt.ema is not None:
@@ -202,6 +204,9 @@ def load_state(trainer, input_dir: str, rank: int = 0) -> dict:
         opt.t_tail = max([steps.get(n, 0) for n in opt.tail_names])
     g = osd["param_groups"][0]
     opt.lr, opt.betas, opt.eps, opt.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+    spath = os.path.join(input_dir, "scaler.pt")
+    if getattr(opt, "scaler", None) is not None and os.path.exists(spath):      # (a bf16 / fp32 trainer ignores an fp16 run's scaler.pt)
+        opt.scaler.load_state_dict(torch.load(spath, map_location="cpu"))
     if opt.ema is not None:
         off, o = {}, 0
         for n in fnames:

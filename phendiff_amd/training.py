@@ -145,6 +145,38 @@ class DiffusionLoss:
         return loss, grad
 
 
+class LossScaler:
+    """``torch.cuda.amp.GradScaler`` as accelerate builds it for ``--mixed_precision fp16`` (args_parser.py:381-390,
+    launch_script_DDIM.sh:56; accelerate 0.23 passes no arguments: init_scale 2**16, growth 2, backoff 0.5, growth_interval 2000):
+    the loss gradient is multiplied by ``scale`` before the fp16 backward (``pd_diffusion_loss.grad_scale``); the optimizer un-scales
+    the fp32 parameter gradients, SKIPS the step when their norm is not finite and halves the scale, and doubles it after
+    ``growth_interval`` consecutive good steps.  ``state_dict`` is the dict accelerate writes as ``scaler.pt``."""
+
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
+        self.scale, self.growth_factor, self.backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.growth_tracker = int(growth_interval), 0
+        self.skipped = 0                      # steps skipped so far (diagnostic)
+
+    def update(self, found_inf: bool):
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self.growth_tracker = 0
+            self.skipped += 1
+        else:
+            self.growth_tracker += 1
+            if self.growth_tracker == self.growth_interval:
+                self.scale *= self.growth_factor
+                self.growth_tracker = 0
+
+    def state_dict(self):
+        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self.growth_tracker}
+
+    def load_state_dict(self, sd):
+        self.scale, self.growth_factor, self.backoff_factor = float(sd["scale"]), float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval, self.growth_tracker = int(sd["growth_interval"]), int(sd["_growth_tracker"])
+
+
 class FlatAdamWEMA:
     """AdamW (torch defaults of the reference: betas (.95, .999), wd 1e-6, eps 1e-8; args_parser.py:299-321) + global
     grad-norm clipping to ``max_grad_norm`` + diffusers EMA, fused over ONE flat fp32 buffer.  ``params`` are re-pointed
@@ -171,6 +203,7 @@ class FlatAdamWEMA:
         self.ema = self.flat.clone() if use_ema else None
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.ema_kwargs = ema_kwargs or {}
+        self.scaler: Optional[LossScaler] = None      # fp16 training: set by the trainer; the gradients in self.grad then carry scaler.scale
         self.t = 0
         self.runs = None            # [(offset, numel, trainable)] when some parameters are frozen (see set_trainable), else None
         self.tail = None            # (offset, numel): a trailing segment with its own AdamW step count (see set_tail)
@@ -198,6 +231,7 @@ class FlatAdamWEMA:
         if len(flags) != len(self.params):
             raise ValueError("set_trainable: one flag per parameter")
         self.trainable = flags
+        self._frozen_views = None
         if all(flags):
             self.runs = None
             return
@@ -219,21 +253,46 @@ class FlatAdamWEMA:
 
     def step(self, lr: Optional[float] = None, zero_grad: bool = True, tail_active: bool = True):
         """clip_grad_norm_ -> optimizer.step -> zero_grad -> EMA.step (utils_training.py:438-454, 553-556). No host sync:
-        the gradient norm stays on the device (``self.grad_norm``)."""
+        the gradient norm stays on the device (``self.grad_norm``).  With a :class:`LossScaler` (fp16 training) the gradients carry its
+        scale: the norm is taken of the scaled gradients against ``max_grad_norm * scale`` (the same clip decision), ONE host read of
+        that norm per step decides whether the step is skipped (``GradScaler.step``: not finite -> no parameter / moment update, the
+        step count does not advance, EMA still steps -- accelerate's loop calls ``ema.step`` regardless), and the factor the update
+        multiplies the gradients with becomes clip_coef / scale."""
         lib = L.lib()
         st = torch.cuda.current_stream(self.flat.device).cuda_stream
-        self.t += 1
         lr = self.lr if lr is None else lr
         b1, b2 = self.betas
         if self.runs is not None:
-            for off, k, f in self.runs:
-                if not f:
-                    self.grad[off:off + k].zero_()
-        if self.max_grad_norm is not None:
-            L.check(lib.pd_grad_norm(self.grad.data_ptr(), self.grad.numel(), self.partial.data_ptr(), float(self.max_grad_norm),
+            # frozen runs: whatever a fused launch wrote into a frozen member's segment (the q/k/v projection, the stacked time_emb_proj)
+            # must not count in the norm -- ONE multi-tensor launch for all of them (attention fine-tuning alternates: dozens of runs)
+            if getattr(self, "_frozen_views", None) is None or self._frozen_views[0] is not self.grad:
+                self._frozen_views = (self.grad, [self.grad[off:off + k] for off, k, f in self.runs if not f])
+            if self._frozen_views[1]:
+                torch._foreach_zero_(self._frozen_views[1])
+        S = self.scaler.scale if self.scaler is not None else None
+        if self.max_grad_norm is not None or S is not None:
+            max_norm = (float(self.max_grad_norm) if self.max_grad_norm is not None else float("inf")) * (S or 1.0)
+            L.check(lib.pd_grad_norm(self.grad.data_ptr(), self.grad.numel(), self.partial.data_ptr(), max_norm,
                                      self.grad_norm.data_ptr(), self.clip_coef.data_ptr(), st), "pd_grad_norm")
+        if S is not None:
+            found_inf = not math.isfinite(float(self.grad_norm))        # the one host read of an fp16 step (GradScaler's found_inf)
+            self.scaler.update(found_inf)
+            if found_inf:      # skipped step: EMA of the unchanged parameters, gradients zeroed, no step count
+                d = ema_decay(self.t + 1, **self.ema_kwargs) if self.ema is not None else 0.0
+                a = L.AdamWEmaArgs(numel=self.flat.numel(), lr=0.0, beta1=b1, beta2=b2, eps=self.eps, weight_decay=0.0, step_size=0.0,
+                                   bias_correction2_sqrt=1.0, one_minus_decay=1.0 - d, zero_grad=int(zero_grad), clip_coef=None,
+                                   param=self.flat.data_ptr(), grad=self.grad.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
+                                   exp_avg_sq=self.exp_avg_sq.data_ptr(), ema=self.ema.data_ptr() if self.ema is not None else None, ema_only=1)
+                L.check(lib.pd_adamw_ema(C.byref(a), st), "pd_adamw_ema")
+                return
+            if self.max_grad_norm is None:
+                self.clip_coef.fill_(1.0 / S)
+            else:
+                self.clip_coef.mul_(1.0 / S)         # (one element: the factor the update applies to the SCALED gradients)
+            self.grad_norm.mul_(1.0 / S)             # the reported norm is the unscaled gradients'
+        self.t += 1
         d = ema_decay(self.t, **self.ema_kwargs) if self.ema is not None else 0.0
-        clip = self.clip_coef.data_ptr() if self.max_grad_norm is not None else None
+        clip = self.clip_coef.data_ptr() if (self.max_grad_norm is not None or S is not None) else None
 
         def launch(off, numel, t, ema_only=0):
             a = L.AdamWEmaArgs(numel=numel, lr=lr, beta1=b1, beta2=b2, eps=self.eps, weight_decay=self.wd,

@@ -23,7 +23,7 @@ from .packing import pack_conv_weight, upsample_phase_weights, upsample_phase_we
 from .training import mark_requires_grad_calls
 
 # compute_dtype -> (pd_dtype, storage dtype).  "fp16": the reference's `--mixed_precision fp16` (args_parser.py:381-390; img2img_comparison.py:57):
-# fp16 storage + MFMA, fp32 accumulate / statistics / softmax -- an inference mode here (training keeps bf16's fp32 range, no GradScaler)
+# fp16 storage + MFMA, fp32 accumulate / statistics / softmax; since round 5 it trains too (unet_train.UNetTrainer under training.LossScaler)
 _DT = {"f32": (L.PD_F32, torch.float32), "bf16": (L.PD_BF16, torch.bfloat16), "fp16": (L.PD_F16, torch.float16)}
 
 
@@ -259,6 +259,9 @@ class CustomCondUNet2DModel(nn.Module):
         """Forward + input-gradient-only backward plan (d loss / d sample through the UNet, no parameter gradients): what
         ``torch.autograd.grad(losses, images)`` needs in the gradient-guided transfer (utils_Img2Img.py:744-745)."""
         from .unet_train import TrainWeights, UNetTrainPlan
+        if self.compute_dtype == "fp16":
+            # (training in fp16 runs under a loss scale, training.LossScaler; the guidance gradient has none: its fp16 activation gradients underflow)
+            raise NotImplementedError("compute_dtype='fp16' has no gradient-guidance plan: build the model with 'bf16' (or 'f32')")
         key = ("input_grad", B, H, W, str(device), self.compute_dtype)
         p = self._plans.get(key)
         if p is None:

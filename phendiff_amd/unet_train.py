@@ -74,11 +74,8 @@ class TrainWeights:
     """Input-gradient ("dgrad") weights in ``pd_conv``'s packed layout: W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx]."""
 
     def __init__(self, m: CustomCondUNet2DModel, device, tdt):
-        if tdt == torch.float16:
-            # the reference trains fp16 under a GradScaler (accelerate, utils_training.py:436); the engine's reduced-precision
-            # TRAINING mode is bf16 (fp32 exponent range: no loss scaling), fp16 is built for inference plans only
-            raise NotImplementedError("compute_dtype='fp16' is an inference mode: build the model with 'bf16' (or 'f32') for the "
-                                      "backward / gradient-guidance plans")
+        # fp16 (round 5): the reference's `--mixed_precision fp16` training (launch_script_DDIM.sh:56) -- fp16 activations and activation
+        # gradients on the f16 MFMA, fp32 master weights / parameter gradients, a loss scale (training.LossScaler) set up by UNetTrainer
         self.tdt, self.device = tdt, device
         pk = lambda w: pack_conv_weight(dgrad_weight(w.detach().to(device=device, dtype=torch.float32)), tdt)
         lin = lambda w: w.detach()[:, :, None, None]
@@ -832,6 +829,10 @@ class UNetTrainer:
         self.grads = {n: p.grad for n, p in order}
         model.invalidate()
         self.loss_fn = DiffusionLoss(scheduler, dev)
+        # --mixed_precision fp16 (args_parser.py:381-390): fp16 activation gradients need the loss scale accelerate's GradScaler applies
+        if getattr(model, "compute_dtype", None) == "fp16":
+            from .training import LossScaler
+            self.opt.scaler = LossScaler()
         self.device = dev
         self._plans = {}
         self._tw = None
@@ -903,7 +904,7 @@ class UNetTrainer:
         self._cond = labels is not None        # the class table has a gradient only when the labels went through it
         out = torch.empty_like(x)
         plan.forward(x, ts, labels, cemb, out, st)
-        loss, dout = self.loss_fn(out, clean, noise, timesteps)
+        loss, dout = self.loss_fn(out, clean, noise, timesteps, grad_scale=self.opt.scaler.scale if self.opt.scaler is not None else 1.0)
         plan.backward(dout, st, after_op=after_op)
         return loss, out
 

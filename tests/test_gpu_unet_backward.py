@@ -507,3 +507,83 @@ def test_trainer_rebinds_after_the_model_dropped_its_packed_weights():
     l0, o0 = run(False)
     l1, o1 = run(True)
     assert l0 == l1 and torch.equal(o0, o1)
+
+
+# ---- round 5: fp16 training behind the reference's own flag (--mixed_precision fp16: launch_script_DDIM.sh:56, args_parser.py:381-390) ----
+@pytest.mark.parametrize("size", [32, 128])
+def test_fp16_backward_matches_autograd_under_the_loss_scale(size):
+    """fp16 activations and activation gradients (f16 MFMA), fp32 parameter gradients that carry the GradScaler's scale (2**16 at the
+    start, as accelerate builds it): gradients / scale against torch.autograd over the fp32 oracle at fp16's tolerance (11 mantissa bits:
+    between the f32 engine's 2e-4 / 2e-5 and the bf16 engine's 8e-2 / 2e-2)."""
+    from phendiff_amd.unet_train import UNetTrainer
+    r, m = make_pair("super_small", size, "fp16")
+    sched, clean, noise, ts, labels, noisy, target = batch(3, size)
+    loss_ref, ref = oracle_grads(r, noisy, ts, target, labels=labels)
+    tr = UNetTrainer(m, sched, lr=1e-4, use_ema=False)
+    assert tr.opt.scaler is not None and tr.opt.scaler.scale == 65536.0
+    loss, _ = tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 2e-3 * float(loss_ref)          # the reported loss is the unscaled one
+    got = {n: g / tr.opt.scaler.scale for n, g in tr.grads.items()}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    compare(ref, got, 3e-2, 6e-3)
+
+
+def test_fp16_overflow_step_is_skipped_and_the_scale_halves():
+    """GradScaler semantics: a step whose gradients are not finite changes no parameter and no Adam moment, does not advance the step
+    count, zeroes the gradients and halves the scale; the next step trains.  After `growth_interval` good steps the scale doubles."""
+    from phendiff_amd.unet_train import UNetTrainer
+    _, m = make_pair("super_small", 32, "fp16")
+    sched, clean, noise, ts, labels, noisy, target = batch(4, 32)
+    tr = UNetTrainer(m, sched, lr=1e-3, use_ema=True)
+    sc = tr.opt.scaler
+    sc.scale, sc.growth_interval = 2.0 ** 40, 3          # 2^40 x the loss gradient overflows fp16 on its first cast
+    before, mom = tr.opt.flat.clone(), tr.opt.exp_avg.clone()
+    args = (noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda())
+    tr.step(*args, class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    assert sc.scale == 2.0 ** 39 and sc.skipped == 1 and tr.opt.t == 0
+    assert torch.equal(tr.opt.flat, before) and torch.equal(tr.opt.exp_avg, mom) and float(tr.opt.grad.abs().max()) == 0.0
+    assert torch.equal(tr.opt.ema, before)                # EMAModel.step on unchanged parameters
+    sc.scale = 65536.0
+    losses = []
+    for _ in range(3):
+        losses.append(float(tr.step(*args, class_labels=labels.cuda())))
+    torch.cuda.synchronize()
+    assert tr.opt.t == 3 and sc.skipped == 1 and sc.scale == 131072.0 and sc.growth_tracker == 0      # three good steps: doubled
+    assert not torch.equal(tr.opt.flat, before) and torch.isfinite(tr.opt.flat).all() and losses[-1] < losses[0]
+    assert 0.0 < float(tr.opt.grad_norm) < 1e3            # the reported norm is the UNSCALED gradients'
+
+
+def test_fp16_training_tracks_the_bf16_loss_curve_and_checkpoints_its_scaler(tmp_path):
+    """20 optimisation steps from the same weights on the same batches: the fp16 engine under its loss scale follows the bf16
+    engine's losses (two reduced-precision roundings of the same trajectory), and accelerate's `scaler.pt` round-trips."""
+    import os
+    from phendiff_amd.unet_train import UNetTrainer
+    curves = {}
+    for mode in ("bf16", "fp16"):
+        _, m = make_pair("super_small", 32, mode)
+        sched, clean, noise, ts, labels, noisy, target = batch(4, 32)
+        tr = UNetTrainer(m, sched, lr=2e-4, use_ema=False)
+        g = torch.Generator().manual_seed(3)
+        out = []
+        for k in range(20):
+            nz = torch.randn(clean.shape, generator=g)
+            t_k = torch.randint(0, 3000, (4,), generator=g)
+            acp = sched.alphas_cumprod[t_k]
+            nsy = (acp ** 0.5).view(-1, 1, 1, 1) * clean + ((1 - acp) ** 0.5).view(-1, 1, 1, 1) * nz
+            out.append(float(tr.step(nsy.cuda(), t_k.cuda(), clean.cuda(), nz.cuda(), class_labels=labels.cuda())))
+        curves[mode] = out
+        if mode == "fp16":
+            assert tr.opt.scaler.skipped == 0 and tr.opt.t == 20
+            tr.opt.scaler.growth_tracker = 7
+            folder = str(tmp_path / "step_20")
+            tr.save_state(folder)
+            sd = torch.load(os.path.join(folder, "scaler.pt"))
+            assert sd["scale"] == 65536.0 and sd["_growth_tracker"] == 7 and sd["growth_interval"] == 2000
+            tr.opt.scaler.scale, tr.opt.scaler.growth_tracker = 1.0, 0
+            tr.load_state(folder)
+            assert tr.opt.scaler.scale == 65536.0 and tr.opt.scaler.growth_tracker == 7
+    a, b = torch.tensor(curves["bf16"]), torch.tensor(curves["fp16"])
+    assert float(((a - b).abs() / a).max()) < 5e-2, (curves)
+    assert b[-5:].mean() < b[:5].mean()                   # and it trains
