@@ -492,6 +492,7 @@ extern "C" int pd_attn_d64_bwd(const pd_attn_d64_bwd_args* a, void* stream) {
            PD_ERR_SHAPE, "pd_attn_d64_bwd: grid too large");
   if (a->dtype == PD_F32) return launch_attn_d64_bwd<float>(a, (hipStream_t)stream);
   if (a->dtype == PD_BF16) return launch_attn_d64_bwd<bf16_t>(a, (hipStream_t)stream);
+  if (a->dtype == PD_F16) return launch_attn_d64_bwd<half_t>(a, (hipStream_t)stream);      // fp16 training (round 5): under the trainer's loss scale
   set_error("pd_attn_d64_bwd: bad dtype");
   return PD_ERR_ARG;
 }
@@ -509,10 +510,11 @@ extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
   const int grid = pd_layernorm_bwd_blocks(a->rows);
   hipStream_t st = (hipStream_t)stream;
   const int np = (a->C / 8 + 63) / 64;
-  if (a->dtype != PD_F32 && a->dtype != PD_BF16) { set_error("pd_layernorm_bwd: bad dtype"); return PD_ERR_ARG; }
+  if (a->dtype != PD_F32 && a->dtype != PD_BF16 && a->dtype != PD_F16) { set_error("pd_layernorm_bwd: bad dtype"); return PD_ERR_ARG; }
 #define PD_LN_BWD(NP_)                                                                                             \
   do {                                                                                                             \
     if (a->dtype == PD_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, NP_>), dim3(grid), dim3(256), 0, st, *a); \
+    else if (a->dtype == PD_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<half_t, NP_>), dim3(grid), dim3(256), 0, st, *a); \
     else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NP_>), dim3(grid), dim3(256), 0, st, *a);                  \
   } while (0)
   if (np == 1) PD_LN_BWD(1); else if (np == 2) PD_LN_BWD(2); else if (np == 3) PD_LN_BWD(3); else PD_LN_BWD(4);
@@ -533,6 +535,7 @@ extern "C" int pd_token_embedding_grad(const pd_token_embedding_grad_args* a, vo
   const unsigned grid = (unsigned)((a->dim + 255) / 256);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(token_embedding_grad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(token_embedding_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(token_embedding_grad_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_token_embedding_grad: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;
@@ -544,6 +547,7 @@ extern "C" int pd_geglu_bwd(const pd_geglu_bwd_args* a, void* stream) {
   const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(geglu_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->dtype == PD_BF16) hipLaunchKernelGGL(geglu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->dtype == PD_F16) hipLaunchKernelGGL(geglu_bwd_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else { set_error("pd_geglu_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();
   return PD_OK;

@@ -319,7 +319,6 @@ extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
     return wide ? launch_attn_d64<bf16_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<bf16_t, 1>(a, (hipStream_t)stream);
   }
   if (a->dtype == PD_F16) {
-    PD_CHECK(a->lse == nullptr, PD_ERR_UNSUPPORTED, "pd_attn_d64: fp16 is an inference mode (no log-sum-exp output for a backward)");
     const bool wide = a->Nkv >= 512 && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
     return wide ? launch_attn_d64<half_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<half_t, 1>(a, (hipStream_t)stream);
   }

@@ -493,7 +493,7 @@ extern "C" int pd_attn_wide_bwd(const pd_attn_wide_bwd_args* a, void* stream) {
            PD_ERR_SHAPE, "pd_attn_wide_bwd: grid too large");
   if (a->dtype == PD_F32) return dispatch_attn_wide_bwd<float>(a, (hipStream_t)stream);
   if (a->dtype == PD_BF16) return dispatch_attn_wide_bwd<bf16_t>(a, (hipStream_t)stream);
-  PD_CHECK(a->dtype != PD_F16, PD_ERR_UNSUPPORTED, "pd_attn_wide_bwd: fp16 is an inference mode");
+  if (a->dtype == PD_F16) return dispatch_attn_wide_bwd<half_t>(a, (hipStream_t)stream);      // fp16 training (round 5)
   set_error("pd_attn_wide_bwd: bad dtype");
   return PD_ERR_ARG;
 }

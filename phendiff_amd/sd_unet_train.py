@@ -59,11 +59,7 @@ class SDTrainWeights:
     """Input-gradient weights in ``pd_conv``'s packed layout (W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx])."""
 
     def __init__(self, m: SDUNet2DConditionModel, device, tdt):
-        if tdt == torch.float16:
-            # the reference trains fp16 under a GradScaler (accelerate, utils_training.py:436); the engine's reduced-precision
-            # TRAINING mode is bf16 (fp32 exponent range: no loss scaling), fp16 is built for inference plans only
-            raise NotImplementedError("compute_dtype='fp16' is an inference mode: build the model with 'bf16' (or 'f32') for the "
-                                      "backward / gradient-guidance plans")
+        # fp16 (round 5): `--mixed_precision fp16` fine-tuning (args_parser.py:381-390) under training.LossScaler, set up by SDUNetTrainer
         self.tdt, self.device = tdt, device
         pk = lambda w, cp=None: pack_conv_weight(dgrad_weight(w.detach().to(device=device, dtype=torch.float32)), tdt, cp)
         lin = lambda w: w.detach()[:, :, None, None]
@@ -410,6 +406,9 @@ class SDUNetTrainer(UNetTrainer):
         self.grads = {n: p.grad for n, p in order}
         model.invalidate()
         self.loss_fn = DiffusionLoss(scheduler, dev)
+        if getattr(model, "compute_dtype", None) == "fp16":      # --mixed_precision fp16: accelerate's GradScaler (training.LossScaler)
+            from .training import LossScaler
+            self.opt.scaler = LossScaler()
         self.device = dev
         self._plans = {}
         self._tw = None
@@ -470,7 +469,7 @@ class SDUNetTrainer(UNetTrainer):
         ehs = self.encoder_hidden_states(labels, unconditional)
         out = torch.empty_like(x)
         plan.forward(x, ts, ehs, out, st, labels=None if unconditional else labels)
-        loss, dout = self.loss_fn(out, clean, noise, timesteps)
+        loss, dout = self.loss_fn(out, clean, noise, timesteps, grad_scale=self.opt.scaler.scale if self.opt.scaler is not None else 1.0)
         plan.backward(dout, st, after_op=after_op)
         return loss, out
 

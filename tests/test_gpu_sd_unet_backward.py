@@ -200,3 +200,41 @@ def test_sd_save_state_resume_continues_bitwise(tmp_path):
     assert resumed == rest, (rest, resumed)
     assert torch.equal(b.opt.ema, a.opt.ema) and torch.equal(b.opt.flat, a.opt.flat)
     assert torch.equal(b.opt.exp_avg, a.opt.exp_avg) and torch.equal(b.opt.exp_avg_sq, a.opt.exp_avg_sq)
+
+
+# ---- round 5: fp16 fine-tuning behind --mixed_precision fp16 (args_parser.py:381-390), the latent-diffusion trainer ----
+@pytest.mark.parametrize("cfg,size", [(TINY, 16), (SMALL, 32)])
+def test_sd_fp16_backward_matches_autograd_under_the_loss_scale(cfg, size):
+    """fp16 activations / activation gradients through the transformer blocks' backward set (pd_attn_d64_bwd, pd_layernorm_bwd,
+    pd_geglu_bwd, pd_token_wgrad, pd_token_embedding_grad in their f16 forms), fp32 parameter gradients carrying the GradScaler's
+    scale: gradients / scale against torch.autograd over the fp32 oracle at fp16's tolerance."""
+    import phendiff_amd as P
+    r, emb, m, e2 = make_pair(cfg, "fp16")
+    sched, clean, noise, ts, labels, noisy, target = batch(3, size)
+    loss_ref, ref = oracle_grads(r, emb, noisy, ts, target, labels)
+    tr = P.SDUNetTrainer(m, e2, sched, lr=1e-4, use_ema=False)
+    assert tr.opt.scaler is not None and tr.opt.scaler.scale == 65536.0
+    loss, _ = tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 2e-3 * float(loss_ref)
+    got = {n: g / tr.opt.scaler.scale for n, g in tr.grads.items()}
+    assert all(torch.isfinite(g).all() for g in got.values())
+    compare(ref, got, 4e-2, 8e-3)
+
+
+def test_sd_fp16_training_steps_reduce_the_loss_and_skip_on_overflow():
+    import phendiff_amd as P
+    _, _, m, e2 = make_pair(TINY, "fp16")
+    sched, clean, noise, ts, labels, noisy, target = batch(4, 16)
+    tr = P.SDUNetTrainer(m, e2, sched, lr=5e-4, use_ema=True)
+    args = (noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), labels.cuda())
+    tr.opt.scaler.scale = 2.0 ** 40
+    before = tr.opt.flat.clone()
+    tr.step(*args)
+    torch.cuda.synchronize()
+    assert tr.opt.scaler.scale == 2.0 ** 39 and tr.opt.t == 0 and torch.equal(tr.opt.flat, before)
+    tr.opt.scaler.scale = 65536.0
+    losses = [float(tr.step(*args, unconditional=(k == 3))) for k in range(8)]
+    torch.cuda.synchronize()
+    assert tr.opt.t == 8 and tr.opt.scaler.skipped == 1 and torch.isfinite(tr.opt.flat).all()
+    assert min(losses[-3:]) < losses[0]

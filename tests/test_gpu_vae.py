@@ -34,7 +34,7 @@ def test_attention_wide(env, mode, cfg):
     assert rel(out.float(), ref) < (2e-5 if mode == "f32" else 1.5e-2)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])       # fp16: round 5 (training under a loss scale)
 @pytest.mark.parametrize("cfg", [(2, 1, 512, 16), (1, 1, 512, 256), (2, 2, 128, 77), (1, 3, 256, 130), (1, 1, 512, 4)])
 def test_attention_wide_backward(env, mode, cfg):
     """pd_attn_wide_bwd (dQ pass + dK / dV pass, P recomputed from the forward's log-sum-exp) against torch.autograd of
@@ -70,13 +70,10 @@ def test_attention_wide_backward(env, mode, cfg):
     # the log-sum-exp the forward kept (log2 domain) and delta = rowsum(O dO)
     s = (sp(qkv[..., :Cc]) @ sp(qkv[..., Cc:2 * Cc]).transpose(-1, -2)) * D ** -0.5
     assert float((lse.cpu() - torch.logsumexp(s, -1) * 1.4426950408889634).abs().max()) < (1e-4 if mode == "f32" else 3e-2)
-    tol = 3e-5 if mode == "f32" else 2e-2
+    tol = {"f32": 3e-5, "bf16": 2e-2, "fp16": 4e-3}[mode]
     got = dqkv.float().cpu()
     for i, name in enumerate("qkv"):
         assert rel(got[..., i * Cc:(i + 1) * Cc], leaf.grad[..., i * Cc:(i + 1) * Cc]) < tol, (name, mode, cfg)
-    assert lib.pd_attn_wide_bwd(C.byref(L.AttnWideBwdArgs(dtype=L.PD_F16, B=B, heads=heads, D=D, Nq=N, Nkv=N, q=p, k=p, v=p, o=p, dout=p,
-                                                           lse=p, delta=p, dq=p, dk=p, dv=p, q_stride=3 * Cc, kv_stride=3 * Cc, o_stride=Cc,
-                                                           dq_stride=3 * Cc, dkv_stride=3 * Cc)), stream()) == -4     # fp16: inference only
 
 
 def test_attention_wide_rejects_unbuilt_dim(env):
