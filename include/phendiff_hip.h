@@ -31,8 +31,9 @@ extern "C" {
  * structs): 1 = round 1; 2 = round 2's trailing fields (pd_gn_finalize_args.temb/temb_stride, pd_attn_args.kmax2,
  * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
  * fold_ws_bytes + pd_linear_fold_workspace,
- * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase. */
-#define PD_ABI_VERSION 5
+ * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_attn_bwd_args.slab / slab_bytes +
+ * pd_attn_d8_bwd_workspace (the one-pass backward). */
+#define PD_ABI_VERSION 6
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
@@ -230,8 +231,15 @@ typedef struct {
   const void* o; const void* dout;
   const float* lse; float* delta;
   void* dqkv;
+  float* slab;              /* (ABI 6) NULL, or a device workspace of >= pd_attn_d8_bwd_workspace(a) bytes (when that is > 0): the backward then runs
+                               in ONE pass -- P and dS formed once per tile, dK / dV lane-local, dS transposed through LDS for dQ, whose
+                               partial sums per 512-key block land here [key blocks][B][heads][N][8] fp32 and are added in order by a
+                               small reduce launch (bit-identical run to run).  16-bit engines, N >= 512; otherwise the two-kernel path */
+  size_t slab_bytes;
 } pd_attn_bwd_args;
 int pd_attn_d8_bwd(const pd_attn_bwd_args* a, void* stream);
+/* bytes of pd_attn_bwd_args.slab the one-pass backward needs for this shape; 0: not applicable (fp32 engine, N < 512) */
+size_t pd_attn_d8_bwd_workspace(const pd_attn_bwd_args* a);
 
 /* ------------------------------------------------------------------------------------------------
  * pd_ddim_step: one fused DDIM / inverse-DDIM update on NCHW fp32 tensors.

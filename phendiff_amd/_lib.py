@@ -38,7 +38,7 @@ def library_is_current() -> bool:
 PD_F32, PD_BF16, PD_F16 = 0, 1, 2
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp = C.c_void_p
 
@@ -226,7 +226,7 @@ class GuidanceApplyArgs(C.Structure):
 
 class AttnBwdArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("N", C.c_int), ("q", vp), ("k", vp), ("v", vp),
-                ("o", vp), ("dout", vp), ("lse", vp), ("delta", vp), ("dqkv", vp)]
+                ("o", vp), ("dout", vp), ("lse", vp), ("delta", vp), ("dqkv", vp), ("slab", vp), ("slab_bytes", C.c_size_t)]
 
 
 class DdimStepArgs(C.Structure):
@@ -291,6 +291,7 @@ SYMBOLS = {
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
     "pd_pack_weight_batch": (C.c_int, [C.POINTER(PackWeightBatchArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
+    "pd_attn_d8_bwd_workspace": (C.c_size_t, [C.POINTER(AttnBwdArgs)]),
     "pd_attn_d64": (C.c_int, [C.POINTER(AttnD64Args), vp]),
     "pd_token_wgrad": (C.c_int, [C.POINTER(TokenWgradArgs), vp]),
     "pd_token_wgrad_workspace": (C.c_size_t, [C.POINTER(TokenWgradArgs)]),

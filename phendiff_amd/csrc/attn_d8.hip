@@ -919,6 +919,231 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_arg
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward in ONE pass (round 5; 16-bit engines, N >= 512, needs the pd_attn_bwd_args.slab workspace).  The two kernels above
+// each recompute P = exp2(S - lse): 32 exponentials and 10 MFMAs per 32 x 32 tile, on a vector issue port that prices the tile.
+// Here the key stays on the lane (dK, dV lane-local, as in the dK/dV kernel) and dS additionally goes through a wave-private LDS
+// image to come back TRANSPOSED (ds_read_b64_tr_b16: query on the lane, 8 keys per register group) as the B operand of
+// dQ^T += K^T . dS^T: 16 exponentials and 8 MFMAs per tile.
+//   workgroup = 8 waves x NSUB 32-key sub-tiles = 256 NSUB keys of one (sample, head); K, V, K^T fragments and the dK / dV
+//               accumulators live in registers for the whole kernel;
+//   query tiles of 256 (Q / dO row images with their -lse / -delta extension rows, Q^T / dO^T images: the dK/dV kernel's staging;
+//               delta = rowsum(dO o O) is formed while staging, no pre-pass) are walked in a LATIN SQUARE: in step t wave w works on
+//               query sub-tile (w + t) mod 8, so every sub-tile's dQ partial is added by exactly one wave per step into an LDS
+//               accumulator [256 queries][8] -- plain read-modify-write, fixed order, no atomics; one barrier per step;
+//   after the 8 steps the tile's dQ (summed over this workgroup's keys) goes to slab[key block][...] (fp32) or, with one key
+//   block, straight to dqkv; attn_dq_reduce_kernel adds the key blocks in order.  Run-to-run bit-identical.
+constexpr int FUSED_TR_PITCH = 72;        // bytes per key row of the transposition image (64 + 8: 2-way bank conflicts at most)
+template <typename T, int NSUB>
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const pd_attn_bwd_args a, float* __restrict__ slab, int nkb) {
+  static_assert(sizeof(T) == 2, "16-bit element types");
+  using E = Elem<T>;
+  using Ops = AttnOps<T>;
+  constexpr int KROW = 16, QT = 256, KPB = 256 * NSUB;
+  constexpr int ROWS = 2 * QT * KROW;                   // row image + extension rows
+  constexpr int VTB = 9 * Ops::VT_PITCH;
+  // dynamic LDS: qlds[2] | dolds[2] | qtlds[2] | dotlds[2] | transposition images [8 waves] | dQ accumulator [QT][8] fp32
+  constexpr int Q_OFF = 0, DO_OFF = 2 * ROWS, QT_OFF = 4 * ROWS, DOT_OFF = 4 * ROWS + 2 * VTB, TR_OFF = 4 * ROWS + 4 * VTB,
+                DQ_OFF = TR_OFF + 8 * 32 * FUSED_TR_PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int total = nkb * a.heads * a.B;
+  int item = blockIdx.x;
+  if ((total & 7) == 0) item = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int kb = item % nkb;
+  const int head = (item / nkb) % a.heads, b = item / (nkb * a.heads);
+  const int N = a.N, C = a.heads * 8;
+  const size_t bh = ((size_t)b * a.heads + head) * N;
+  const T* qp = (const T*)a.q + bh * 8;
+  const T* dop = (const T*)a.dout + (size_t)b * N * C + head * 8;
+  const T* op = (const T*)a.o + (size_t)b * N * C + head * 8;
+  const float qscale = 0.35355339059327373f * 1.4426950408889634f;
+
+  typename Ops::QF kfr[NSUB], vfr[NSUB];
+  s16x8 kt[NSUB][2];                                    // K^T as the A operand of dQ^T += K^T . dS^T: lane (row d = r < 8, h), k = key 16 s + 8 h + j
+  f32x16 dk[NSUB], dv[NSUB];
+#pragma unroll
+  for (int ks = 0; ks < NSUB; ++ks) {
+    const int key0 = kb * KPB + (wave * NSUB + ks) * 32;
+    const int key = key0 + r, kc = min(key, N - 1);
+    kfr[ks] = Ops::load_q((const T*)a.k + (bh + kc) * 8, h, 1.0f);
+    vfr[ks] = Ops::load_q((const T*)a.v + (bh + kc) * 8, h, 1.0f);
+    Ops::set_ones(kfr[ks], h); Ops::set_ones(vfr[ks], h);
+    dk[ks] = (f32x16)(0.f); dv[ks] = (f32x16)(0.f);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      s16x8 f = (s16x8)(0);
+      if (r < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kk = key0 + 16 * s2 + 8 * h + j;
+          if (kk < N) f[j] = (short)bits16(((const T*)a.k)[(bh + kk) * 8 + r]);      // a key past N adds nothing to dQ
+        }
+      }
+      kt[ks][s2] = f;
+    }
+  }
+
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) {
+    if (tid < QT) {
+      *(T*)(lds + QT_OFF + b2 * VTB + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
+      *(T*)(lds + DOT_OFF + b2 * VTB + 8 * Ops::VT_PITCH + tid * E::BYTES) = E::from_f(0.0f);
+    }
+  }
+  const int vrow_off = (r < 8 ? r : 8) * Ops::VT_PITCH + Ops::vlane_off(h);   // A rows 8..31: the zero row
+  const int ka0 = h ? QT * KROW + r * KROW : r * KROW;                        // h == 1: the extension rows (-lse / -delta terms)
+  constexpr int kst = 32 * KROW;
+  unsigned char* const trw = lds + TR_OFF + wave * (32 * FUSED_TR_PITCH);     // this wave's transposition image [key 32][query 32] T
+  // transposed read (T10): lane 4q + p of a 16-lane group supplies key row q, query columns 4p .. 4p+3 of the group's 16 queries;
+  // lane i receives query i, element q' = key row q'.  This lane: query r, keys 16 s + 8 h + (0..3 | 4..7)
+  const int tr_rd = ((lane & 15) >> 2) * FUSED_TR_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2 + 8 * h * FUSED_TR_PITCH;
+  const int tr_wr = r * FUSED_TR_PITCH + 8 * h;                               // + 16 g: registers 4g .. 4g+3 = queries 8g + 4h + (0..3)
+  float* const dqacc_l = (float*)(lds + DQ_OFF);
+
+  typename E::Frag stq, stdo, sto;
+  float stl = 0.f;
+  auto issue = [&](int q0) {
+    const int query = q0 + tid;
+    if (tid < QT && query < N) {
+      stq = E::load(qp + (size_t)query * 8); stdo = E::load(dop + (size_t)query * C); sto = E::load(op + (size_t)query * C);
+      stl = -a.lse[bh + query];
+    } else { stq = E::zero(); stdo = E::zero(); sto = E::zero(); stl = 0.f; }
+  };
+  auto commit = [&](int b2, int q0) {
+    if (tid < QT) {
+      float qv[8], dv_[8], ov[8];
+      E::unpack(stq, qv);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) qv[d] *= qscale;
+      const typename E::Frag qs = E::pack(qv);
+      E::store(lds + Q_OFF + b2 * ROWS + tid * KROW, qs);
+      E::store(lds + DO_OFF + b2 * ROWS + tid * KROW, stdo);
+      E::unpack(qs, qv);
+      E::unpack(stdo, dv_);
+      E::unpack(sto, ov);
+      float delta = 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) delta += dv_[d] * ov[d];
+      const int vp_ = Ops::vpos(tid);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        *(T*)(lds + QT_OFF + b2 * VTB + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(qv[d]);
+        *(T*)(lds + DOT_OFF + b2 * VTB + d * Ops::VT_PITCH + vp_ * E::BYTES) = E::from_f(dv_[d]);
+      }
+      Ops::store_terms(lds + Q_OFF + b2 * ROWS + (QT + tid) * KROW, stl);
+      Ops::store_terms(lds + DO_OFF + b2 * ROWS + (QT + tid) * KROW, -delta);
+      if (kb == 0 && q0 + tid < N) a.delta[bh + q0 + tid] = delta;            // (kept for callers that read it back)
+    }
+  };
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4s* lp;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  auto body = [&](int cur, int sub, int ks, f32x16& dq) {
+    const typename Ops::KF qa = Ops::load_k(lds + Q_OFF + cur * ROWS + ka0 + sub * kst);
+    const typename Ops::KF doa = Ops::load_k(lds + DO_OFF + cur * ROWS + ka0 + sub * kst);
+    const f32x16 zero = (f32x16)(0.f);
+    f32x16 p = Ops::qk(qa, kfr[ks], zero);            // accumulator register i <-> query (i&3) + 8(i>>2) + 4h of the sub-tile, lane <-> key
+    f32x16 ds = Ops::qk(doa, vfr[ks], zero);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { p[i] = __builtin_amdgcn_exp2f(p[i]); ds[i] *= p[i]; }
+    dv[ks] = Ops::pv(Ops::load_v(lds + DOT_OFF + cur * VTB + vrow_off, sub * 32), p, dv[ks]);
+    // dS packed ONCE: the B operand of dK^T += Q^T . dS and -- the same dwords -- the rows of the transposition image
+    const typename Ops::VF qtf = Ops::load_v(lds + QT_OFF + cur * VTB + vrow_off, sub * 32);
+    uint32_t bw[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bw[s2][j] = Ops::pack_p(ds[8 * s2 + 2 * j], ds[8 * s2 + 2 * j + 1]);
+      const u32x4 bv = {bw[s2][0], bw[s2][1], bw[s2][2], bw[s2][3]};
+      dk[ks] = E::mma16(__builtin_bit_cast(s16x8, qtf.v[s2]), __builtin_bit_cast(s16x8, bv), dk[ks]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                     // registers 4g .. 4g+3 -> 8 bytes at [key r][query 8g + 4h]
+      const u32x2 w2 = {bw[g >> 1][(g & 1) * 2], bw[g >> 1][(g & 1) * 2 + 1]};
+      *(u32x2*)(trw + tr_wr + 16 * g) = w2;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(trw + tr_rd + (16 * s2) * FUSED_TR_PITCH));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(trw + tr_rd + (16 * s2 + 4) * FUSED_TR_PITCH));
+      const s16x8 bt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      dq = E::mma16(kt[ks][s2], bt, dq);
+    }
+  };
+
+  issue(0);
+  commit(0, 0);
+  if (QT < N) issue(QT);
+  *(f32x4*)(lds + DQ_OFF + tid * 16) = (f32x4)(0.f);
+  __syncthreads();
+  for (int q0 = 0, cur = 0; q0 < N; q0 += QT, cur ^= 1) {
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+      const int sub = (wave + t) & 7;
+      if (q0 + sub * 32 < N) {                        // (wave-uniform) padded queries past a ragged end: nothing to add
+        f32x16 dq = (f32x16)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < NSUB; ++ks) body(cur, sub, ks, dq);
+        float* dst = dqacc_l + (sub * 32 + r) * 8 + 4 * h;       // D rows 0..3 (h = 0) / 4..7 (h = 1) = d, in registers 0..3
+        f32x4 acc = *(f32x4*)dst;
+        acc[0] += dq[0]; acc[1] += dq[1]; acc[2] += dq[2]; acc[3] += dq[3];
+        *(f32x4*)dst = acc;
+      }
+      __syncthreads();
+    }
+    {   // the tile's dQ, summed over this workgroup's keys: 512 threads x 16 bytes
+      const int query = q0 + (tid >> 1), half = tid & 1;
+      const f32x4 v = *(f32x4*)(lds + DQ_OFF + tid * 16);
+      *(f32x4*)(lds + DQ_OFF + tid * 16) = (f32x4)(0.f);
+      if (query < N) {
+        if (nkb == 1) {
+          const float sc = 0.35355339059327373f;      // d(scale * q.k)/dq
+          store4((T*)a.dqkv + ((size_t)b * N + query) * (3 * C) + head * 8 + 4 * half, v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+        } else {
+          *(f32x4*)(slab + (((size_t)kb * a.B * a.heads + (size_t)b * a.heads + head) * N + query) * 8 + 4 * half) = v;
+        }
+      }
+    }
+    if (q0 + QT < N) {
+      commit(cur ^ 1, q0 + QT);
+      if (q0 + 2 * QT < N) issue(q0 + 2 * QT);
+    }
+    __syncthreads();
+  }
+  const float ln2 = 0.6931471805599453f;              // Q^T carried scale * log2(e); dK = scale * dS^T q
+#pragma unroll
+  for (int ks = 0; ks < NSUB; ++ks) {
+    const int key = kb * KPB + (wave * NSUB + ks) * 32 + r;
+    if (key < N) {
+      T* dst = (T*)a.dqkv + ((size_t)b * N + key) * (3 * C) + head * 8 + 4 * h;
+      store4(dst + C, dk[ks][0] * ln2, dk[ks][1] * ln2, dk[ks][2] * ln2, dk[ks][3] * ln2);
+      store4(dst + 2 * C, dv[ks][0], dv[ks][1], dv[ks][2], dv[ks][3]);
+    }
+  }
+}
+
+// dq = scale * sum over the key blocks (in order) of the one-pass kernel's partial dQ; one thread per (sample, token, head)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __restrict__ slab, int nkb, int B, int heads, int N, T* __restrict__ dqkv) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // (b * heads + head) * N + n
+  if (i >= (size_t)B * heads * N) return;
+  const int n = (int)(i % N), head = (int)((i / N) % heads), b = (int)(i / ((size_t)N * heads));
+  const size_t per = (size_t)B * heads * N * 8;
+  f32x4 lo = (f32x4)(0.f), hi = (f32x4)(0.f);
+  for (int k = 0; k < nkb; ++k) {
+    lo += *(const f32x4*)(slab + k * per + i * 8);
+    hi += *(const f32x4*)(slab + k * per + i * 8 + 4);
+  }
+  const float sc = 0.35355339059327373f;
+  T* dst = dqkv + ((size_t)b * N + n) * (3 * heads * 8) + head * 8;
+  store4(dst, lo[0] * sc, lo[1] * sc, lo[2] * sc, lo[3] * sc);
+  store4(dst + 4, hi[0] * sc, hi[1] * sc, hi[2] * sc, hi[3] * sc);
+}
+
 }  // namespace pd
 
 extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
@@ -981,11 +1206,51 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
 }
 
 
+// one-pass form: 8 waves x 2 sub-tiles of 32 keys per workgroup
+static constexpr int FUSED_KPB = 512;
+extern "C" size_t pd_attn_d8_bwd_workspace(const pd_attn_bwd_args* a) {
+  if (!a || a->dtype == PD_F32 || a->B < 1 || a->heads < 1 || a->N < FUSED_KPB) return 0;
+  const size_t nkb = ((size_t)a->N + FUSED_KPB - 1) / FUSED_KPB;
+  return nkb * (size_t)a->B * a->heads * a->N * 8 * sizeof(float);      // (one key block writes dq directly, but a uniform answer keeps callers simple)
+}
+
+template <typename T>
+static int launch_attn_bwd_fused(const pd_attn_bwd_args* a, hipStream_t st) {
+  using namespace pd;
+  constexpr int LDS = 4 * (2 * 256 * 16) + 4 * (9 * AttnOps<T>::VT_PITCH) + 8 * 32 * FUSED_TR_PITCH + 256 * 8 * 4;
+  auto kern = attn_bwd_fused_kernel<T, 2>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("pd_attn_d8_bwd: cannot reserve %d bytes of LDS", LDS);
+      return PD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int nkb = (a->N + FUSED_KPB - 1) / FUSED_KPB;
+  PD_CHECK((long long)nkb * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8_bwd: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nkb * a->heads * a->B)), dim3(512), LDS, st, *a, a->slab, nkb);
+  PD_LAUNCH_CHECK();
+  if (nkb > 1) {
+    const size_t rows = (size_t)a->B * a->heads * a->N;
+    hipLaunchKernelGGL(attn_dq_reduce_kernel<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const float*)a->slab, nkb, a->B, a->heads, a->N,
+                       (T*)a->dqkv);
+    PD_LAUNCH_CHECK();
+  }
+  return PD_OK;
+}
+
 extern "C" int pd_attn_d8_bwd(const pd_attn_bwd_args* a, void* stream) {
   using namespace pd;
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_attn_d8_bwd: null args");
   PD_CHECK(a->B > 0 && a->heads > 0 && a->N > 0, PD_ERR_SHAPE, "pd_attn_d8_bwd: bad shape");
   PD_CHECK(a->q && a->k && a->v && a->o && a->dout && a->lse && a->delta && a->dqkv, PD_ERR_ARG, "pd_attn_d8_bwd: null pointer");
+  // one pass (round 5) when the caller brought the workspace.  PD_ATTN_BWD_FUSED=0: diagnostic override (same-box A/B)
+  if (a->slab != nullptr && diag_env("PD_ATTN_BWD_FUSED", 1) != 0) {
+    const size_t need = pd_attn_d8_bwd_workspace(a);
+    if (need > 0 && a->slab_bytes >= need)
+      return a->dtype == PD_BF16 ? launch_attn_bwd_fused<bf16_t>(a, (hipStream_t)stream) : launch_attn_bwd_fused<half_t>(a, (hipStream_t)stream);
+  }
   PD_CHECK((long long)((a->N + 127) / 128) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8_bwd: grid too large");
   const dim3 grid(((a->N + 127) / 128) * a->heads * a->B);
   hipStream_t st = (hipStream_t)stream;

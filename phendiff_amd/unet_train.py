@@ -560,6 +560,12 @@ class UNetTrainPlan(UNetPlan):
         a = L.AttnBwdArgs(dtype=self.code, B=B, heads=e.heads, N=N, q=rec.qkv[0].data_ptr(), k=rec.qkv[1].data_ptr(),
                           v=rec.qkv[2].data_ptr(), o=rec.o.data_ptr(), dout=do.data_ptr(), lse=rec.lse.data_ptr(),
                           delta=delta.data_ptr(), dqkv=dqkv.data_ptr())
+        # one-pass backward (round 5) where the library offers it (16-bit engines, N >= 512): the partial dQ of every 512-key block,
+        # fp32, in a workspace all attention layers of the step share
+        need = int(self.lib.pd_attn_d8_bwd_workspace(C.byref(a)))
+        if need > 0:
+            slab = self._tmp((need // 4,), "attn_dq_slab", torch.float32)
+            a.slab, a.slab_bytes = slab.data_ptr(), need
         self._b(self.lib.pd_attn_d8_bwd, a, "attn_d8_bwd", 10.0 * B * e.heads * N * N * 8, 8.0 * B * N * ch * self._esz())
         self._bias_grad(dqkv, G(n + ".to_q.bias", (n + ".to_k.bias", n + ".to_v.bias")))                       # [dq | dk | dv] biases are adjacent
         self._wgrad(rec.x, None, rec.gn, 0, dqkv, G(n + ".to_q.weight", (n + ".to_k.weight", n + ".to_v.weight")), ksize=1, pad=0)

@@ -312,7 +312,9 @@ def test_upsampler_weight_gradient_through_four_subpixel_phases(env, mode, shape
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [(2, 4, 64), (1, 8, 1024), (2, 8, 200), (1, 2, 16), (1, 3, 300)])
+@pytest.mark.parametrize("cfg", [(2, 4, 64), (1, 8, 1024), (2, 8, 200), (1, 2, 16), (1, 3, 300),
+                                 # round 5, the one-pass form: one key block exactly, three ragged key blocks, ragged queries and keys, two blocks x batch
+                                 (2, 2, 512), (1, 2, 1300), (1, 3, 600), (2, 4, 2048)])
 def test_attention_backward(env, mode, cfg):
     L, lib, _, dev = env
     code, tdt = DT[mode]
@@ -346,6 +348,27 @@ def test_attention_backward(env, mode, cfg):
     tol = 3e-5 if mode == "f32" else 2.5e-2       # bf16: P, dS and the outputs are rounded to 8 mantissa bits
     for name, gg, rr in (("dq", got[0], rq), ("dk", got[1], rk), ("dv", got[2], rv)):
         assert rel(gg, rr) < tol, name
+    # the one-pass form (round 5: a workspace for the per-key-block partial dQ; 16-bit engines, N >= 512) -- same gradients, twice the same bits
+    need = int(lib.pd_attn_d8_bwd_workspace(C.byref(b)))
+    assert (need > 0) == (mode != "f32" and N >= 512)
+    if need:
+        slab = torch.full((need // 4,), float("nan"), device=dev)
+        b.slab, b.slab_bytes = slab.data_ptr(), need
+        runs = []
+        for _ in range(2):
+            dqkv.fill_(float("nan"))
+            L.check(lib.pd_attn_d8_bwd(C.byref(b), stream()), "pd_attn_d8_bwd")
+            torch.cuda.synchronize()
+            runs.append(dqkv.clone())
+        assert torch.equal(runs[0], runs[1])
+        got1 = runs[0].float().cpu().reshape(B, N, 3, heads, 8).permute(2, 0, 3, 1, 4)
+        for name, gg, rr in (("dq", got1[0], rq), ("dk", got1[1], rk), ("dv", got1[2], rv)):
+            assert rel(gg, rr) < tol, ("one pass", name)
+        b.slab_bytes = need - 1                      # a workspace that is too small is not used: the two-kernel path answers
+        dqkv.fill_(float("nan"))
+        L.check(lib.pd_attn_d8_bwd(C.byref(b), stream()), "pd_attn_d8_bwd")
+        torch.cuda.synchronize()
+        assert torch.equal(dqkv.float().cpu().reshape(B, N, 3, heads, 8).permute(2, 0, 3, 1, 4), got)
 
 
 def test_native_comm_world_one_allreduce(env):
