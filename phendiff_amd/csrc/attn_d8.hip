@@ -929,12 +929,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const pd_attn_bwd_arg
 //   workgroup = 8 waves x NSUB 32-key sub-tiles = 256 NSUB keys of one (sample, head); K, V, K^T fragments and the dK / dV
 //               accumulators live in registers for the whole kernel;
 //   query tiles of 256 (Q / dO row images with their -lse / -delta extension rows, Q^T / dO^T images: the dK/dV kernel's staging;
-//               delta = rowsum(dO o O) is formed while staging, no pre-pass) are walked in a LATIN SQUARE: in step t wave w works on
-//               query sub-tile (w + t) mod 8, so every sub-tile's dQ partial is added by exactly one wave per step into an LDS
-//               accumulator [256 queries][8] -- plain read-modify-write, fixed order, no atomics; one barrier per step;
-//   after the 8 steps the tile's dQ (summed over this workgroup's keys) goes to slab[key block][...] (fp32) or, with one key
-//   block, straight to dqkv; attn_dq_reduce_kernel adds the key blocks in order.  Run-to-run bit-identical.
-constexpr int FUSED_TR_PITCH = 72;        // bytes per key row of the transposition image (64 + 8: 2-way bank conflicts at most)
+//               delta = rowsum(dO o O) is formed while staging, no pre-pass).  Every wave walks the tile's 8 query sub-tiles with NO
+//               barrier in between; per sub-tile its NSUB key sub-tiles run as one instruction stream (`step`: shared fragment reads,
+//               all score MFMAs up front, one key sub-tile's transposition round trip hidden behind the other's vector work).
+//               (First version: a Latin-square walk with one barrier per sub-tile into a shared LDS accumulator, 2 waves per SIMD
+//               stalled on the transposition: 1.30 ms per layer = the SUM of the two kernels it replaces; second: software-pipelined
+//               bodies, no step barriers: 1.25 ms.)
+//   at the end of a tile the 8 waves' partial dQ go through LDS (one private block each), are added in wave order and leave for
+//   slab[key block][...] (fp32) or, with one key block, straight to dqkv; attn_dq_reduce_kernel adds the key blocks in order.
+//   Run-to-run bit-identical.
+constexpr int FUSED_TR_PITCH = 72;        // bytes per key row of a transposition image (64 + 8: 2-way bank conflicts at most)
+constexpr int FUSED_TR_IMG = 32 * FUSED_TR_PITCH;
 template <typename T, int NSUB>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const pd_attn_bwd_args a, float* __restrict__ slab, int nkb) {
   static_assert(sizeof(T) == 2, "16-bit element types");
@@ -943,9 +948,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const pd_attn_bwd_a
   constexpr int KROW = 16, QT = 256, KPB = 256 * NSUB;
   constexpr int ROWS = 2 * QT * KROW;                   // row image + extension rows
   constexpr int VTB = 9 * Ops::VT_PITCH;
-  // dynamic LDS: qlds[2] | dolds[2] | qtlds[2] | dotlds[2] | transposition images [8 waves] | dQ accumulator [QT][8] fp32
+  // dynamic LDS: qlds[2] | dolds[2] | qtlds[2] | dotlds[2] | transposition images [8 waves][2] | partial dQ [8 waves][QT][8] fp32
   constexpr int Q_OFF = 0, DO_OFF = 2 * ROWS, QT_OFF = 4 * ROWS, DOT_OFF = 4 * ROWS + 2 * VTB, TR_OFF = 4 * ROWS + 4 * VTB,
-                DQ_OFF = TR_OFF + 8 * 32 * FUSED_TR_PITCH;
+                DQ_OFF = TR_OFF + 8 * 2 * FUSED_TR_IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -997,12 +1002,12 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const pd_attn_bwd_a
   const int vrow_off = (r < 8 ? r : 8) * Ops::VT_PITCH + Ops::vlane_off(h);   // A rows 8..31: the zero row
   const int ka0 = h ? QT * KROW + r * KROW : r * KROW;                        // h == 1: the extension rows (-lse / -delta terms)
   constexpr int kst = 32 * KROW;
-  unsigned char* const trw = lds + TR_OFF + wave * (32 * FUSED_TR_PITCH);     // this wave's transposition image [key 32][query 32] T
+  unsigned char* const trw = lds + TR_OFF + wave * (2 * FUSED_TR_IMG);        // this wave's two transposition images [key 32][query 32] T
   // transposed read (T10): lane 4q + p of a 16-lane group supplies key row q, query columns 4p .. 4p+3 of the group's 16 queries;
   // lane i receives query i, element q' = key row q'.  This lane: query r, keys 16 s + 8 h + (0..3 | 4..7)
   const int tr_rd = ((lane & 15) >> 2) * FUSED_TR_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2 + 8 * h * FUSED_TR_PITCH;
   const int tr_wr = r * FUSED_TR_PITCH + 8 * h;                               // + 16 g: registers 4g .. 4g+3 = queries 8g + 4h + (0..3)
-  float* const dqacc_l = (float*)(lds + DQ_OFF);
+  float* const dq_mine = (float*)(lds + DQ_OFF) + wave * (QT * 8);
 
   typename E::Frag stq, stdo, sto;
   float stl = 0.f;
@@ -1042,64 +1047,82 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const pd_attn_bwd_a
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) v4s* lp;
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  auto body = [&](int cur, int sub, int ks, f32x16& dq) {
+  // One query sub-tile against this wave's NSUB key sub-tiles, as ONE instruction stream: the Q / dO row fragments and the Q^T / dO^T
+  // fragments are read once for all of them, the score MFMAs of every key sub-tile are issued first (the matrix pipe runs them while the
+  // vector pipe starts on the first one's exponentials), and a key sub-tile's dS sits in its transposition image for the length of the
+  // next one's vector work before it is read back -- the LDS round trip is hidden without a second pair of images.
+  auto step = [&](int cur, int sub, f32x16& dq) {
+    // LLVM's MFMA / exp interleaving strategy over the step (same box: none 1.228 ms per configs[1] layer incl. the reduce, (1) 1.300, (2) 1.215,
+    // (3) 1.210; -DPD_ATTN_BWD_IGLP=n builds another)
+#ifndef PD_ATTN_BWD_IGLP
+#define PD_ATTN_BWD_IGLP 3
+#endif
+    __builtin_amdgcn_iglp_opt(PD_ATTN_BWD_IGLP);
     const typename Ops::KF qa = Ops::load_k(lds + Q_OFF + cur * ROWS + ka0 + sub * kst);
     const typename Ops::KF doa = Ops::load_k(lds + DO_OFF + cur * ROWS + ka0 + sub * kst);
-    const f32x16 zero = (f32x16)(0.f);
-    f32x16 p = Ops::qk(qa, kfr[ks], zero);            // accumulator register i <-> query (i&3) + 8(i>>2) + 4h of the sub-tile, lane <-> key
-    f32x16 ds = Ops::qk(doa, vfr[ks], zero);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { p[i] = __builtin_amdgcn_exp2f(p[i]); ds[i] *= p[i]; }
-    dv[ks] = Ops::pv(Ops::load_v(lds + DOT_OFF + cur * VTB + vrow_off, sub * 32), p, dv[ks]);
-    // dS packed ONCE: the B operand of dK^T += Q^T . dS and -- the same dwords -- the rows of the transposition image
+    const typename Ops::VF dotf = Ops::load_v(lds + DOT_OFF + cur * VTB + vrow_off, sub * 32);
     const typename Ops::VF qtf = Ops::load_v(lds + QT_OFF + cur * VTB + vrow_off, sub * 32);
-    uint32_t bw[2][4];
+    const f32x16 zero = (f32x16)(0.f);
+    f32x16 p[NSUB], ds[NSUB];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int ks = 0; ks < NSUB; ++ks) {               // accumulator register i <-> query (i&3) + 8(i>>2) + 4h of the sub-tile, lane <-> key
+      p[ks] = Ops::qk(qa, kfr[ks], zero);
+      ds[ks] = Ops::qk(doa, vfr[ks], zero);
+    }
+    uint32_t bw[NSUB][2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bw[s2][j] = Ops::pack_p(ds[8 * s2 + 2 * j], ds[8 * s2 + 2 * j + 1]);
-      const u32x4 bv = {bw[s2][0], bw[s2][1], bw[s2][2], bw[s2][3]};
-      dk[ks] = E::mma16(__builtin_bit_cast(s16x8, qtf.v[s2]), __builtin_bit_cast(s16x8, bv), dk[ks]);
+    for (int ks = 0; ks < NSUB; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { p[ks][i] = __builtin_amdgcn_exp2f(p[ks][i]); ds[ks][i] *= p[ks][i]; }
+      // dS packed ONCE: the B operand of dK^T += Q^T . dS and -- the same dwords -- the rows of the transposition image
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bw[ks][s2][j] = Ops::pack_p(ds[ks][8 * s2 + 2 * j], ds[ks][8 * s2 + 2 * j + 1]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                   // registers 4g .. 4g+3 -> 8 bytes at [key r][query 8g + 4h]
+        const u32x2 w2 = {bw[ks][g >> 1][(g & 1) * 2], bw[ks][g >> 1][(g & 1) * 2 + 1]};
+        *(u32x2*)(trw + ks * FUSED_TR_IMG + tr_wr + 16 * g) = w2;
+      }
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {                     // registers 4g .. 4g+3 -> 8 bytes at [key r][query 8g + 4h]
-      const u32x2 w2 = {bw[g >> 1][(g & 1) * 2], bw[g >> 1][(g & 1) * 2 + 1]};
-      *(u32x2*)(trw + tr_wr + 16 * g) = w2;
-    }
+    for (int ks = 0; ks < NSUB; ++ks) {
+      dv[ks] = Ops::pv(dotf, p[ks], dv[ks]);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(trw + tr_rd + (16 * s2) * FUSED_TR_PITCH));
-      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(trw + tr_rd + (16 * s2 + 4) * FUSED_TR_PITCH));
-      const s16x8 bt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      dq = E::mma16(kt[ks][s2], bt, dq);
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const u32x4 bv = {bw[ks][s2][0], bw[ks][s2][1], bw[ks][s2][2], bw[ks][s2][3]};
+        dk[ks] = E::mma16(__builtin_bit_cast(s16x8, qtf.v[s2]), __builtin_bit_cast(s16x8, bv), dk[ks]);
+      }
+      // the image read back transposed: dQ^T (rows 0..7 = d) += K^T . dS^T
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(trw + ks * FUSED_TR_IMG + tr_rd + (16 * s2) * FUSED_TR_PITCH));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(trw + ks * FUSED_TR_IMG + tr_rd + (16 * s2 + 4) * FUSED_TR_PITCH));
+        const s16x8 bt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        dq = E::mma16(kt[ks][s2], bt, dq);
+      }
     }
   };
 
   issue(0);
   commit(0, 0);
   if (QT < N) issue(QT);
-  *(f32x4*)(lds + DQ_OFF + tid * 16) = (f32x4)(0.f);
   __syncthreads();
   for (int q0 = 0, cur = 0; q0 < N; q0 += QT, cur ^= 1) {
+    const int nsub = min(8, (N - q0 + 31) / 32);      // (uniform) query sub-tiles of this tile that hold queries
 #pragma unroll 1
-    for (int t = 0; t < 8; ++t) {
-      const int sub = (wave + t) & 7;
-      if (q0 + sub * 32 < N) {                        // (wave-uniform) padded queries past a ragged end: nothing to add
-        f32x16 dq = (f32x16)(0.f);
-#pragma unroll
-        for (int ks = 0; ks < NSUB; ++ks) body(cur, sub, ks, dq);
-        float* dst = dqacc_l + (sub * 32 + r) * 8 + 4 * h;       // D rows 0..3 (h = 0) / 4..7 (h = 1) = d, in registers 0..3
-        f32x4 acc = *(f32x4*)dst;
-        acc[0] += dq[0]; acc[1] += dq[1]; acc[2] += dq[2]; acc[3] += dq[3];
-        *(f32x4*)dst = acc;
-      }
-      __syncthreads();
+    for (int sub = 0; sub < nsub; ++sub) {
+      f32x16 dq = (f32x16)(0.f);                      // dQ^T of the sub-tile (rows 0..7 = d in registers 0..3, h), this wave's keys
+      step(cur, sub, dq);
+      *(f32x4*)(dq_mine + (sub * 32 + r) * 8 + 4 * h) = (f32x4){dq[0], dq[1], dq[2], dq[3]};      // -> this wave's private LDS block
     }
-    {   // the tile's dQ, summed over this workgroup's keys: 512 threads x 16 bytes
+    __syncthreads();                                  // every wave's block is complete (and nobody reads staging buffer `cur` any more)
+    {   // the tile's dQ summed over the 8 waves in order: 512 threads x 16 bytes
       const int query = q0 + (tid >> 1), half = tid & 1;
-      const f32x4 v = *(f32x4*)(lds + DQ_OFF + tid * 16);
-      *(f32x4*)(lds + DQ_OFF + tid * 16) = (f32x4)(0.f);
       if (query < N) {
+        f32x4 v = (f32x4)(0.f);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += *(const f32x4*)((const float*)(lds + DQ_OFF) + w * (QT * 8) + tid * 4);
         if (nkb == 1) {
           const float sc = 0.35355339059327373f;      // d(scale * q.k)/dq
           store4((T*)a.dqkv + ((size_t)b * N + query) * (3 * C) + head * 8 + 4 * half, v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
@@ -1217,7 +1240,7 @@ extern "C" size_t pd_attn_d8_bwd_workspace(const pd_attn_bwd_args* a) {
 template <typename T>
 static int launch_attn_bwd_fused(const pd_attn_bwd_args* a, hipStream_t st) {
   using namespace pd;
-  constexpr int LDS = 4 * (2 * 256 * 16) + 4 * (9 * AttnOps<T>::VT_PITCH) + 8 * 32 * FUSED_TR_PITCH + 256 * 8 * 4;
+  constexpr int LDS = 4 * (2 * 256 * 16) + 4 * (9 * AttnOps<T>::VT_PITCH) + 8 * 2 * FUSED_TR_IMG + 8 * 256 * 8 * 4;
   auto kern = attn_bwd_fused_kernel<T, 2>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -560,9 +560,11 @@ class UNetTrainPlan(UNetPlan):
         a = L.AttnBwdArgs(dtype=self.code, B=B, heads=e.heads, N=N, q=rec.qkv[0].data_ptr(), k=rec.qkv[1].data_ptr(),
                           v=rec.qkv[2].data_ptr(), o=rec.o.data_ptr(), dout=do.data_ptr(), lse=rec.lse.data_ptr(),
                           delta=delta.data_ptr(), dqkv=dqkv.data_ptr())
-        # one-pass backward (round 5) where the library offers it (16-bit engines, N >= 512): the partial dQ of every 512-key block,
-        # fp32, in a workspace all attention layers of the step share
-        need = int(self.lib.pd_attn_d8_bwd_workspace(C.byref(a)))
+        # one-pass backward (round 5; 16-bit engines, N >= 512): the partial dQ of every 512-key block, fp32, in a workspace all attention
+        # layers of the step share.  OPT-IN (PD_ATTN_BWD_FUSED=1): 4-5 % faster than the two kernels as an op (1.21 vs 1.28 ms per
+        # configs[1] layer) and neutral-to-slower on the whole step (2 324 vs 2 339 images/s, 4 alternating rounds:
+        # profiles/r5_ab_attn_bwd_one_pass.log) -- 200 registers hold it at 2 waves per SIMD, where matrix and vector work do not overlap
+        need = int(self.lib.pd_attn_d8_bwd_workspace(C.byref(a))) if __import__("os").environ.get("PD_ATTN_BWD_FUSED", "0") == "1" else 0
         if need > 0:
             slab = self._tmp((need // 4,), "attn_dq_slab", torch.float32)
             a.slab, a.slab_bytes = slab.data_ptr(), need
