@@ -22,7 +22,8 @@ stats() {   # <tag> <log name> <batches> <discard> -- bench args (whose --warmup
 }
 case "$1" in
 head)
-  stats b32 ${R}_bench_under_rocprof_b32.log 6 2 --steps 4 --warmup 2 --batch 32 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
+  # (6 replays of the 10 700-node graph queued back to back crashed rocprofv3 7.2 -- SIGSEGV in the tool 9 s in; 4 replays hold)
+  stats b32 ${R}_bench_under_rocprof_b32.log ${HEAD_BATCHES:-4} ${HEAD_DISCARD:-2} --steps $(( ${HEAD_BATCHES:-4} - ${HEAD_DISCARD:-2} )) --warmup ${HEAD_DISCARD:-2} --batch 32 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
   for x in kernel_stats.csv kernel_stats_whole_run.csv kernel_stats.note; do mv $OUT/${R}_b32_$x $OUT/${R}_kernel_stats_b32${x#kernel_stats}; done
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads > /dev/null 2>$OUT/pmc_$c.err
