@@ -65,6 +65,51 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+class SmiSampler:
+    """Clock and power of card 0 through the timed region (round 5): boxes of the pool differ by +-5.5 % on this power-coupled workload
+    (15.3 - 17.1 images/s for identical sources), so the line says what the chip of THIS run held.  A side thread starts one short
+    `rocm-smi` child process every 2 s (nothing in this process execs; host-side only); failures are swallowed."""
+
+    def __init__(self, period_s=2.0):
+        import threading
+        self.period, self.samples, self._stop = period_s, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def sample():
+        import re
+        import subprocess
+        try:
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
+            j = json.loads(r.stdout[r.stdout.index("{"):])
+            card = j[sorted(k for k in j if k.startswith("card"))[0]]
+            num = lambda v: float(re.search(r"[-+]?\d+(\.\d+)?", str(v)).group(0))      # noqa: E731
+            sclk = next((num(v) for k, v in card.items() if "sclk" in k.lower()), None)
+            power = next((num(v) for k, v in card.items() if "power" in k.lower() and "(w)" in k.lower()), None)
+            return sclk, power
+        except Exception:      # noqa: BLE001
+            return None, None
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            self.samples.append(self.sample())
+
+    def start(self):
+        self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._th.join(15)
+        ok = [s for s in self.samples if s[0]]
+        if not ok:
+            return {"note": "rocm-smi gave no sample"}
+        med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
+        pw = [s[1] for s in ok if s[1]]
+        return {"sclk_mhz_median": med([s[0] for s in ok]), "power_w_median": med(pw) if pw else None, "samples": len(ok),
+                "source": "rocm-smi --showclocks --showpower, every 2 s through the timed region"}
+
+
 def cpu_baseline(model_name, size, S, state_dict, seconds_budget=30.0):
     """The oracle (plain-PyTorch CPU fp32 restatement of the reference path) timed on this box's host cores on a
     bounded sample: B = 1 image, the first k inversion + first k denoising steps of the S-step schedules (per-step
@@ -944,11 +989,13 @@ def main():
     for _ in range(args.warmup):
         one_batch()
     barrier()
+    smi = SmiSampler().start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_batch()
     barrier()
     elapsed = time.perf_counter() - t0
+    box = smi.stop() if smi is not None else None
     elapsed, ranks = reduce_elapsed(dist, elapsed, dev, B * args.steps)
     assert torch.isfinite(host_out).all() and float(host_out.min()) >= 0.0 and float(host_out.max()) <= 1.0
 
@@ -964,6 +1011,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "inference_steps": S, "image_size": size,
                    "hipgraph": not args.no_graph, "concurrent_trajectories": args.streams},
     }
+    if box is not None:
+        res["box"] = box
     # whole-step roofline numbers the north_star asks for (per GPU): algorithmic activation bytes / flops per image
     per_gpu = value / world
     esz = 2.0 if args.dtype == "f32" else 1.0
