@@ -334,6 +334,25 @@ def broadcast_from_rank0_(flat: torch.Tensor, group=None, src: int = 0) -> torch
     return flat
 
 
+def allreduce_mean_ranges_(flat_grad: torch.Tensor, ranges, group=None, bucket_bytes: int = 256 << 20):
+    """:func:`allreduce_mean_` over the trainable runs ``[(offset, numel)]`` of one flat buffer (frozen parameters in between are not
+    exchanged): every collective is issued asynchronously before the first wait, so a layout that alternates frozen and trainable
+    parameters (``--attention_fine_tuning``: dozens of runs) costs one latency, not one per run."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grad
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat_grad
+    per = max(1, bucket_bytes // flat_grad.element_size())
+    views = [flat_grad[o + i:o + min(k, i + per)] for o, k in ranges for i in range(0, k, per)]
+    works = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v in views]
+    for wk in works:
+        wk.wait()
+    torch._foreach_div_(views, float(world))
+    return flat_grad
+
+
 def allreduce_mean_(flat_grad: torch.Tensor, group=None, bucket_bytes: int = 256 << 20):
     """Data-parallel gradient averaging over one flat buffer: what DDP's bucketed all-reduce computes for
     ``accelerator.backward`` (utils_training.py:436, train.py:311-326), as a few LARGE asynchronous all-reduces (RCCL over

@@ -926,10 +926,9 @@ class UNetTrainer:
         if world == 1 and not getattr(self, "force_collectives", False):
             loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb)
         elif not overlap:
-            from .training import allreduce_mean_
+            from .training import allreduce_mean_ranges_
             loss, _ = self.forward_backward(noisy, timesteps, clean, noise, class_labels, class_emb)
-            for off, k in self.opt.trainable_ranges():
-                allreduce_mean_(self.opt.grad[off:off + k], group)
+            allreduce_mean_ranges_(self.opt.grad, self.opt.trainable_ranges(), group)
         else:
             loss = self._forward_backward_overlapped(noisy, timesteps, clean, noise, class_labels, class_emb, group, world,
                                                      bucket_bytes)

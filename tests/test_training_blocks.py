@@ -57,6 +57,13 @@ def _dp_worker(rank, world, port, out):
     F.mse_loss(model(x[lo:hi]), y[lo:hi]).backward()
     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     T.allreduce_mean_(flat, bucket_bytes=64)          # several small buckets on purpose
+    # the non-overlapped path of a partly frozen model: only the trainable runs are exchanged, all collectives in flight together
+    part = torch.arange(40, dtype=torch.float32) * (rank + 1)
+    T.allreduce_mean_ranges_(part, [(2, 5), (10, 1), (20, 17)], bucket_bytes=16)
+    want = torch.arange(40, dtype=torch.float32) * (rank + 1)
+    for o, k in [(2, 5), (10, 1), (20, 17)]:
+        want[o:o + k] = torch.arange(40, dtype=torch.float32)[o:o + k] * 1.5
+    assert torch.equal(part, want)
     if rank == 0:
         out.put(flat.clone())
     dist.destroy_process_group()
