@@ -12,34 +12,9 @@
 #include "pd_common.h"
 #include <type_traits>
 #include "pd_stage.h"
+#include "pd_linear.h"
 
 namespace pd {
-
-struct LinP {
-  long long M;
-  int K, N, N_pad, x_stride;
-  int t_tiles, c_tiles;
-  unsigned xbytes;
-  const void* x; const void* w; const float* bias; const void* residual; void* y;
-  const float* scale; const float* shift;   // optional GroupNorm affine on x: [sample][K], sample = row / rows_per_sample
-  int rows_per_sample;                      // multiple of 128 when scale is set (a token tile never straddles samples)
-  int qkv_heads, B;                         // > 0: head-major q / k / v output [3][B][heads][rows_per_sample][8] (N = 3 * heads * 8)
-  float* stats;                             // optional [B][rows_per_sample / 128][N][2]: per-tile channel (sum, sum of squares) of y
-  float* kmax2;                             // optional (qkv_heads > 0, 16-bit) [B][heads]: atomic max of |k row|^2 as stored
-  long long w_sstride;                      // linear_dma_kernel: bytes between the packed weights of consecutive samples (0: one set for all)
-  int bias_sstride;                         // ... floats between their bias vectors
-};
-
-// gelu(g) = g/2 (1 + erf(g / sqrt 2)), F.gelu's default (exact) form.  The bf16 engine takes erf from Abramowitz-Stegun 7.1.26
-// (|error| < 1.5e-7, far below bf16's 2^-9; one v_exp + one v_rcp + 7 FMAs), the fp32 parity mode calls erff.
-template <int ES> __device__ __forceinline__ float gelu_f(float g) {
-  if constexpr (ES == 4) return 0.5f * g * (1.0f + erff(g * 0.7071067811865476f));
-  const float x = fabsf(g) * 0.7071067811865476f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);     // erf(|g| / sqrt 2)
-  return 0.5f * g + 0.5f * fabsf(g) * e;                                                     // g/2 (1 + sign(g) erf) 
-}
 
 // GLU = true (NC = 2): the weights are packed with the VALUE and GATE rows of FeedForward.net[0].proj (GEGLU) interleaved per
 // 32-channel tile -- packed tile 2u = value channels 32u.., tile 2u+1 = gate channels N/2 + 32u.. -- so a wave's two channel
@@ -1173,6 +1148,20 @@ extern "C" int pd_linear(const pd_linear_args* a, void* stream) {
       //   64^2 qkv .153/.140/.130  out .047/.064/.045  ff2 1280->320 .157/.182/.121 (888 TF/s)     32^2 qkv .102/.103/.099  out .039/.049/.036  ff2 2560->640 .124/.144/.107
       //   16^2 qkv .094/.095/.104  out .044/.044/.051  ff2 .149/.142/.159 -> from 32 768 tokens up, with at least one workgroup per CU (not behind the fused GEGLU:
       //   its (value, gate) tiles pair up inside a wave).  PD_LIN_NC5=0: diagnostic override (same-box A/B)
+      // round 6: the 256 x 256 eight-phase kernel (linear_p8.hip) for the deep / wide layers.  PD_LIN_P8=0 / 1: diagnostic override (off / wherever eligible)
+      {
+        const int p8_env = diag_env("PD_LIN_P8", -1);
+        const long long tiles8 = (long long)t256 * c4;
+        // measured (scripts/bench_linear_p8.py, B = 32, same process, x the round-5 choice): 16^2 level (M = 8192) 1.21 .. 1.46 on every
+        // layer and input gradient, also at 160 tiles on 256 CUs; 32^2 level K = 640 -> N = 5120 / 2560 / 1920: 1.11 / 1.12 / 1.04;
+        // slower for K = 320 (five K tiles: the prologue and the epilogue are a third of the workgroup's life) and for N = 320 / 640
+        // (a 256-wide tile wastes 37 / 17 % of them): those stay on the 320- / 128-channel tiles
+        const bool p8 = p8_env >= 0 ? p8_env == 1 : (a->K >= 640 && a->N_pad >= 1280 && waste4_ok && tiles8 >= 128);
+        if (p8 && dma_env < 2) {
+          p.t_tiles = t256; p.c_tiles = c4;
+          return launch_linear_p8(p, a->dtype, glu, (hipStream_t)stream);
+        }
+      }
       const bool nc5_off = diag_env("PD_LIN_NC5", 1) == 0;
       const bool can5 = !glu && a->N_pad % 320 == 0 && a->N == a->N_pad;
       if (dma_env >= 2 && dma_env <= 4) nc = dma_env;

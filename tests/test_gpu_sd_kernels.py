@@ -397,3 +397,107 @@ def test_linear_gemm_groupnorm_folded_into_per_sample_weights(env, mode, shape):
     a.rows_per_sample = 128
     a.M = B * Ntok
     assert int(lib.pd_linear_fold_workspace(C.byref(a))) == 0
+
+
+# ---- round 6: the 256 x 256 eight-phase GEMM (csrc/linear_p8.hip) -------------------------------------------------------------------
+P8_PLAIN = [(256, 64, 256, 0, 0),          # one K tile: prologue + drain only
+            (300, 128, 256, 1, 0),         # two K tiles, ragged tokens, residual
+            (1000, 320, 320, 1, 0),        # odd number of K tiles; N_pad = 320: second channel tile mostly clamped weight tiles
+            (515, 5120, 1280, 1, 0),       # 80 K tiles
+            (2048 + 77, 640, 1920, 0, 64), # strided input rows, ragged last channel tile
+            (4096, 1280, 2560, 1, 0),      # 16 x 10 tiles: the panel walk over a ragged channel panel (8 + 2)
+            (1280, 192, 200, 0, 0),        # N a multiple of 8 only (N_pad = 224)
+            (9 * 256, 256, 9 * 256, 1, 0)] # 9 x 9 tiles: ragged token panel (4 + 4 + 1) and channel panel (8 + 1), tile count % 8 != 0
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", P8_PLAIN)
+def test_linear_gemm_eight_phase(env, mode, cfg, monkeypatch):
+    """pd_linear on the eight-phase 256 x 256 kernel (forced wherever it is eligible: PD_LIN_P8=1 is read at every dispatch) against
+    F.linear in fp64; the same launch with the kernel switched off must agree with it to the rounding of the output type."""
+    from phendiff_amd.packing import pack_conv_weight
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    M, K, N, with_res, xpad = cfg
+    g = torch.Generator().manual_seed(71)
+    xs = K + xpad
+    xfull = bf16_round(torch.randn(M, xs, generator=g), mode)
+    w = bf16_round(torch.randn(N, K, generator=g) / K ** 0.5, mode)
+    bias = torch.randn(N, generator=g)
+    res = bf16_round(torch.randn(M, N, generator=g), mode) if with_res else None
+    npad = ((N + 31) // 32) * 32
+    wp = pack_conv_weight(w[:, :, None, None], tdt, npad).to(dev)
+    bp = torch.zeros(npad)
+    bp[:N] = bias
+    X, Bv = xfull.to(tdt).to(dev), bp.to(dev)
+    R = res.to(tdt).to(dev) if with_res else None
+    ref = F.linear(xfull[:, :K].double(), w.double(), bias.double()) + (res.double() if with_res else 0)
+    outs = {}
+    for p8 in ("1", "0"):
+        monkeypatch.setenv("PD_LIN_P8", p8)
+        y = torch.full((M + 3, N), float("nan"), dtype=tdt, device=dev)      # three guard rows: nothing may be written past M
+        a = L.LinearArgs(dtype=code, M=M, K=K, N=N, N_pad=npad, x=X.data_ptr(), x_stride=xs, w_packed=wp.data_ptr(), bias=Bv.data_ptr(),
+                         residual=L.ptr(R), y=y.data_ptr())
+        L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+        torch.cuda.synchronize()
+        assert torch.isnan(y[M:].float()).all()
+        outs[p8] = y[:M].float().cpu()
+        assert rel(outs[p8], ref.float()) < {"bf16": 4e-3, "fp16": 5e-4}[mode], p8
+    assert rel(outs["1"], outs["0"]) < {"bf16": 3e-3, "fp16": 4e-4}[mode]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(515, 1280, 5120), (1024, 320, 1280), (300, 64, 256), (2100, 640, 320), (4096, 128, 64)])
+def test_linear_gemm_eight_phase_fused_geglu(env, mode, cfg, monkeypatch):
+    """The fused GEGLU epilogue of the eight-phase kernel: even / odd packed weight tiles = (value, gate) pairs; inner widths that are
+    / are not multiples of the 128-channel output tile."""
+    L, lib, _, dev = env
+    code, tdt = DT[mode]
+    M, K, inner = cfg
+    g = torch.Generator().manual_seed(72)
+    x = bf16_round(torch.randn(M, K, generator=g), mode)
+    w = bf16_round(torch.randn(2 * inner, K, generator=g) / K ** 0.5, mode)
+    bias = torch.randn(2 * inner, generator=g)
+    X, W, Bv = x.to(tdt).to(dev), w.to(dev), bias.to(dev)
+    tile = (K // 32) * 2 * 512
+    wp = torch.full((2 * inner // 32, tile), float("nan"), dtype=tdt, device=dev)
+    for half in (0, 1):
+        src = W[half * inner:(half + 1) * inner].contiguous()
+        a = L.PackWeightArgs(dtype=code, cout=inner, cin=K, cout_pad=inner, cin_pad=K, ksize=1, src_in=K, dgrad=0,
+                             src=src.data_ptr(), dst=wp.data_ptr() + half * tile * wp.element_size(), dst_ct_stride=2 * tile)
+        L.check(lib.pd_pack_weight(C.byref(a), stream()), "pd_pack_weight")
+    proj = F.linear(x.double(), w.double(), bias.double())
+    ref = (proj[:, :inner] * F.gelu(proj[:, inner:])).float()
+    monkeypatch.setenv("PD_LIN_P8", "1")
+    y = torch.full((M + 3, inner), float("nan"), dtype=tdt, device=dev)
+    a = L.LinearArgs(dtype=code, M=M, K=K, N=2 * inner, N_pad=2 * inner, x=X.data_ptr(), x_stride=K, w_packed=wp.data_ptr(),
+                     bias=Bv.data_ptr(), residual=None, y=y.data_ptr(), glu=1)
+    L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+    torch.cuda.synchronize()
+    assert torch.isnan(y[M:].float()).all()
+    assert rel(y[:M].float().cpu(), ref) < {"bf16": 4e-3, "fp16": 5e-4}[mode]
+
+
+def test_linear_gemm_eight_phase_is_deterministic_under_load(env, monkeypatch):
+    """Race screen: the kernel has no atomics and a fixed summation order, so every launch of the same operands must return the same
+    bits.  A DMA piece that lands after its first read (or over a tile still being read) shows up as a changed output: 30 launches of
+    two shapes (whole-chip grids, 20 and 80 K tiles) against the first one."""
+    from phendiff_amd.packing import pack_conv_weight
+    L, lib, _, dev = env
+    monkeypatch.setenv("PD_LIN_P8", "1")
+    g = torch.Generator().manual_seed(73)
+    for M, K, N in ((8192, 1280, 10240), (8192, 5120, 1280)):
+        x = torch.randn(M, K, generator=g).bfloat16().to(dev)
+        w = pack_conv_weight((torch.randn(N, K, generator=g) / K ** 0.5)[:, :, None, None], torch.bfloat16).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        first = None
+        for it in range(30):
+            y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            a = L.LinearArgs(dtype=1, M=M, K=K, N=N, N_pad=N, x=x.data_ptr(), x_stride=K, w_packed=w.data_ptr(), bias=bias.data_ptr(),
+                             residual=None, y=y.data_ptr())
+            L.check(lib.pd_linear(C.byref(a), stream()), "pd_linear")
+            torch.cuda.synchronize()
+            if first is None:
+                first = y
+            else:
+                assert torch.equal(y, first), (M, K, N, it)
