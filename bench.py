@@ -11,7 +11,8 @@ region starts, output = float NHWC [0,1] images in HBM (PNG encode / dataset dec
 
 Images are independent: each rank transfers its own batches, no collective on the data path ("scaling": "weak").
 Rank 0 prints ONE JSON line.  At N = 1 (the driver's default run) that line also carries `side_workloads`: short legs of
-BASELINE.json's other configs -- configs[1] `train`, configs[3] `sd_train`, configs[4] `sd_img2img` in fp16 and bf16 -- each run as a
+BASELINE.json's other configs -- configs[1] `train`, configs[3] `sd_train`, configs[4] `sd_img2img` in fp16 and bf16, and (round 6) the
+reference's own precision for the two pixel configs: `img2img_fp16` (configs[2]) and `train_fp16` (configs[1]) -- each run as a
 child process AFTER the headline's fields are final, each with its own value / ms_per_step / roofline / cpu_baseline
 (`--no-side-workloads` skips them; `--workload X` runs one of them as the main workload).
 """
@@ -66,9 +67,10 @@ def usable_cores():
 
 
 class SmiSampler:
-    """Clock and power of card 0 through the timed region (round 5): boxes of the pool differ by +-5.5 % on this power-coupled workload
+    """Clock and power of card 0 under the workload (round 5): boxes of the pool differ by +-5.5 % on this power-coupled workload
     (15.3 - 17.1 images/s for identical sources), so the line says what the chip of THIS run held.  A side thread starts one short
-    `rocm-smi` child process every 2 s (nothing in this process execs; host-side only); failures are swallowed."""
+    `rocm-smi` child process per period (nothing in this process execs; host-side only); failures are swallowed.  Round 6: never
+    inside the timed region -- `bracket()` samples through a repeat of the timed steps right after it."""
 
     def __init__(self, period_s=2.0):
         import threading
@@ -93,6 +95,20 @@ class SmiSampler:
     def _run(self):
         while not self._stop.wait(self.period):
             self.samples.append(self.sample())
+
+    @classmethod
+    def bracket(cls, run_steps):
+        """no child process inside the timed region (the fork of a large GPU process every 2 s perturbs rank 0 only, and
+        the reported time is the MAX over ranks).  The card's clock / power are read while it runs the SAME steps again right after
+        the timed region (`run_steps()` queues them; the samples are taken while they execute), never while the clock is running."""
+        s = cls(period_s=1.0).start()
+        try:
+            run_steps()
+        finally:
+            out = s.stop()
+        if "source" in out:
+            out["source"] = "rocm-smi --showclocks --showpower, every 1 s through a repeat of the timed steps AFTER the timed region (none inside it)"
+        return out
 
     def start(self):
         self._th.start()
@@ -796,7 +812,7 @@ def main_sd_train(args, P, world, rank, dev, dist):
 # Kernel-selecting diagnostic overrides the library reads from the environment (conv_igemm.hip / linear_gemm.hip / attn_d8.hip /
 # unet.py): a bench line measured under one of them says so, and the default (driver) run is expected to carry none.
 DIAG_ENV = ("PD_LIB", "PD_TW_DMA", "PD_ALLOW_ABI_MISMATCH", "PD_BENCH_REHEARSAL", "PD_LIN_DMA", "PD_CONV_NCO", "PD_CONV_PLAIN", "PD_LIN_NC4", "PD_ATTN_NO_GLDS", "PD_ATTN_LDS_PAD", "PD_PREAPPLY_MIN_COUT", "PD_NO_LINEAR_GRADS", "PD_NO_PREAPPLY_WGRAD",
-            "PD_CONV_PRO", "PD_SUBPIXEL_UP", "PD_LIN_FOLD", "PD_LIN_NC5", "PD_BENCH_NO_SELFTEST", "PD_ATTN_BWD_FUSED", "PD_GN_FUSED", "PD_BENCH_NATIVE_SELFTEST", "PD_BENCH_SELFTEST_STUB", "PD_BENCH_NATIVE_TIMEOUT_S", "PD_ATTN_WPB4", "PD_ATTN64_QB1", "EXTRA_HIPCC_FLAGS")
+            "PD_CONV_PRO", "PD_SUBPIXEL_UP", "PD_LIN_FOLD", "PD_LIN_NC5", "PD_LIN_P8", "PD_BENCH_NO_SELFTEST", "PD_ATTN_BWD_FUSED", "PD_GN_FUSED", "PD_BENCH_NATIVE_SELFTEST", "PD_BENCH_SELFTEST_STUB", "PD_BENCH_NATIVE_TIMEOUT_S", "PD_ATTN_WPB4", "PD_ATTN64_QB1", "EXTRA_HIPCC_FLAGS")
 
 
 def diagnostic_env():
@@ -811,10 +827,15 @@ SIDE_WORKLOADS = (
     ("sd_train",        ["--workload", "sd_train", "--steps", "3", "--warmup", "1"], 120),
     ("sd_img2img_fp16", ["--workload", "sd_img2img", "--dtype", "fp16", "--steps", "1", "--warmup", "1"], 150),
     ("sd_img2img_bf16", ["--workload", "sd_img2img", "--dtype", "bf16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], 90),
+    # round 6: configs[2] and configs[1] at the reference's own precision, `mixed_precision: fp16`
+    # (examples/example_img2img_comparison_conf/general_config.yaml:46, examples/examples_training_scripts/launch_script_DDIM.sh:56):
+    # same batch, same graph replay / LossScaler step, own in-situ roofline; the CPU baseline is the fp32 oracle either way (shared)
+    ("img2img_fp16",    ["--workload", "img2img", "--dtype", "fp16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-sweep"], 60),
+    ("train_fp16",      ["--workload", "train", "--dtype", "fp16", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], 45),
 )
 
 
-def run_side_workloads(budget_s, only=None):
+def run_side_workloads(budget_s, only=None, headline_cpu_baseline=None):
     """Each leg = `python bench.py --workload X ... --no-side-workloads` as a child; its JSON line is attached (trimmed of the
     long prose fields).  A leg that does not fit what is left of the budget is skipped and the line says so."""
     import subprocess
@@ -851,6 +872,12 @@ def run_side_workloads(budget_s, only=None):
     if a.get("cpu_baseline") and "value" in b and not b.get("cpu_baseline"):
         b["cpu_baseline"] = dict(a["cpu_baseline"], shared="timed once in the sd_img2img_fp16 leg (the oracle is fp32 either way)")
         b["gpu_over_cpu"] = round(b["value"] / a["cpu_baseline"]["value"], 1)
+    for leg, src, where in (("train_fp16", out.get("train", {}).get("cpu_baseline"), "the train leg"),
+                            ("img2img_fp16", headline_cpu_baseline, "the headline")):
+        b = out.get(leg, {})
+        if src and "value" in b and not b.get("cpu_baseline"):
+            b["cpu_baseline"] = dict(src, shared=f"timed once in {where} (the oracle is fp32 either way)")
+            b["gpu_over_cpu"] = round(b["value"] / src["value"], 1)
     out["total_wall_s"] = round(time.time() - t_all, 1)
     return out
 
@@ -989,14 +1016,19 @@ def main():
     for _ in range(args.warmup):
         one_batch()
     barrier()
-    smi = SmiSampler().start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_batch()
     barrier()
     elapsed = time.perf_counter() - t0
-    box = smi.stop() if smi is not None else None
     elapsed, ranks = reduce_elapsed(dist, elapsed, dev, B * args.steps)
+    box = None
+    if rank == 0 and world == 1:          # (one-GPU runs only: at N > 1 rank 0 would keep the other ranks waiting at the next barrier)
+        def _again():
+            for _ in range(min(args.steps, 3)):
+                one_batch()
+            torch.cuda.synchronize(dev)
+        box = SmiSampler.bracket(_again)
     assert torch.isfinite(host_out).all() and float(host_out.min()) >= 0.0 and float(host_out.max()) <= 1.0
 
     images = world * B * args.steps
@@ -1181,7 +1213,7 @@ def main():
     if rank == 0 and world == 1 and args.side_workloads:
         # every headline field above is final; the headline's plans stay allocated (a few GB of 288) while the children run
         try:
-            res["side_workloads"] = run_side_workloads(args.side_budget_s)
+            res["side_workloads"] = run_side_workloads(args.side_budget_s, headline_cpu_baseline=res.get("cpu_baseline"))
         except Exception as e:                                   # never lose the headline line to a side leg
             res["side_workloads"] = {"failed": repr(e)}
     if rank == 0:

@@ -39,8 +39,9 @@ typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
  * PD_F16 is the reference's `--mixed_precision fp16` (args_parser.py:381-390): every inference entry point, and -- since round 5 -- the
  * pixel UNet's backward set (pd_conv_wgrad, pd_gn_silu_bwd, pd_attn_d8_bwd + pd_attn_d8's lse, pd_pool2x2_sum, pd_channel_sum, pd_im2col3,
- * pd_token_wgrad) under a loss scale (pd_loss_args.grad_scale; phendiff_amd.training.LossScaler = accelerate's GradScaler).  The
- * latent-diffusion backward set (pd_attn_d64_bwd, pd_attn_wide_bwd, pd_layernorm_bwd, pd_geglu_bwd) returns PD_ERR_UNSUPPORTED for it. */
+ * pd_token_wgrad) and the latent-diffusion backward set (pd_attn_d64_bwd + pd_attn_d64's lse, pd_attn_wide_bwd, pd_layernorm_bwd,
+ * pd_geglu_bwd, pd_token_embedding_grad) under a loss scale (pd_loss_args.grad_scale; phendiff_amd.training.LossScaler = accelerate's
+ * GradScaler): UNetTrainer and SDUNetTrainer both train in fp16. */
 typedef enum { PD_F32 = 0, PD_BF16 = 1, PD_F16 = 2 } pd_dtype;
 typedef enum { PD_PRED_EPSILON = 0, PD_PRED_SAMPLE = 1, PD_PRED_V = 2 } pd_pred_type;
 

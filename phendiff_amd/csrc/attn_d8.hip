@@ -1193,12 +1193,9 @@ extern "C" int pd_attn_d8(const pd_attn_args* a, void* stream) {
   // stream's MFMA-bound convolutions can co-reside on every CU beside this VALU-bound kernel
   static const int lds_pad = getenv("PD_ATTN_LDS_PAD") ? atoi(getenv("PD_ATTN_LDS_PAD")) : 0;
   if (lds_pad > 0 && a->dtype == PD_BF16 && wide) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)attn_kernel<bf16_t, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
-      (void)hipFuncSetAttribute((const void*)attn_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
-      attr_set = true;
-    }
+    static LdsAttr attr_a, attr_b;
+    (void)ensure_lds(attr_a, attn_kernel<bf16_t, 1, 8>, lds_pad);
+    (void)ensure_lds(attr_b, attn_glds_kernel<bf16_t>, lds_pad);
     if (a->kmax2) hipLaunchKernelGGL((attn_glds_kernel<bf16_t>), grid, dim3(512), lds_pad, st, *a);     // the shipped kernel, occupancy-capped
     else hipLaunchKernelGGL((attn_kernel<bf16_t, 1, 8>), grid, dim3(512), lds_pad, st, *a);
     PD_LAUNCH_CHECK();
@@ -1242,13 +1239,10 @@ static int launch_attn_bwd_fused(const pd_attn_bwd_args* a, hipStream_t st) {
   using namespace pd;
   constexpr int LDS = 4 * (2 * 256 * 16) + 4 * (9 * AttnOps<T>::VT_PITCH) + 8 * 2 * FUSED_TR_IMG + 8 * 256 * 8 * 4;
   auto kern = attn_bwd_fused_kernel<T, 2>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      set_error("pd_attn_d8_bwd: cannot reserve %d bytes of LDS", LDS);
-      return PD_ERR_LAUNCH;
-    }
-    attr_set = true;
+  static LdsAttr attr;
+  if (!ensure_lds(attr, kern, LDS)) {
+    set_error("pd_attn_d8_bwd: cannot reserve %d bytes of LDS", LDS);
+    return PD_ERR_LAUNCH;             // (pd_attn_d8_bwd falls back to the two-kernel path)
   }
   const int nkb = (a->N + FUSED_KPB - 1) / FUSED_KPB;
   PD_CHECK((long long)nkb * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8_bwd: grid too large");
@@ -1271,8 +1265,10 @@ extern "C" int pd_attn_d8_bwd(const pd_attn_bwd_args* a, void* stream) {
   // one pass (round 5) when the caller brought the workspace.  PD_ATTN_BWD_FUSED=0: diagnostic override (same-box A/B)
   if (a->slab != nullptr && diag_env("PD_ATTN_BWD_FUSED", 1) != 0) {
     const size_t need = pd_attn_d8_bwd_workspace(a);
-    if (need > 0 && a->slab_bytes >= need)
-      return a->dtype == PD_BF16 ? launch_attn_bwd_fused<bf16_t>(a, (hipStream_t)stream) : launch_attn_bwd_fused<half_t>(a, (hipStream_t)stream);
+    if (need > 0 && a->slab_bytes >= need && (a->dtype == PD_BF16 || a->dtype == PD_F16)) {
+      const int rc = a->dtype == PD_BF16 ? launch_attn_bwd_fused<bf16_t>(a, (hipStream_t)stream) : launch_attn_bwd_fused<half_t>(a, (hipStream_t)stream);
+      if (rc != PD_ERR_LAUNCH) return rc;     // the 154 KB of dynamic LDS could not be reserved on this device: the two kernels below
+    }
   }
   PD_CHECK((long long)((a->N + 127) / 128) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d8_bwd: grid too large");
   const dim3 grid(((a->N + 127) / 128) * a->heads * a->B);

@@ -123,7 +123,11 @@ extern "C" int pd_allreduce_bucket(void* comm, float* buf, size_t count, int mea
   hipStream_t st = (hipStream_t)stream;
   // (no `world > 1` guard: RCCL runs both collectives at one rank too, so a one-rank communicator exercises this branch and its in-place
   // pointer arithmetic -- ADVICE r3)
-  const bool avg_in_collective = mean && cm->world > 1 && R->has_avg;
+  // ncclAvg is a pre-scaled sum (x / W summed).  For a power-of-two world the scaling is exact, so the result is bit-identical to
+  // sum-then-scale -- what the torch exchange of the trainers (all_reduce SUM, then div_) computes; for any other world size the two
+  // round differently, so there the scaling stays a separate pass and the native exchange keeps matching the torch one bit for bit
+  // (ADVICE r5).
+  const bool avg_in_collective = mean && cm->world > 1 && R->has_avg && (cm->world & (cm->world - 1)) == 0;
   const int op = avg_in_collective ? NCCL_AVG : NCCL_SUM;
   if (algo == 1 && count % (size_t)cm->world == 0) {
     const size_t shard = count / cm->world;

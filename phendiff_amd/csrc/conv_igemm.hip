@@ -942,12 +942,8 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   static_assert(NCO == 1 || DB, "NCO = 2 is a double-buffered variant");
   auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO, PLAIN, PRO>;
   if (LDS_BYTES > 64 * 1024) {
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PD_ERR_LAUNCH; }
-      attr_set = true;
-    }
+    static LdsAttr attr;   // per instantiation, per device
+    if (!ensure_lds(attr, kern, LDS_BYTES)) { set_error("pd_conv: cannot reserve %d bytes of LDS", LDS_BYTES); return PD_ERR_LAUNCH; }
   }
   ConvP q = p;
   q.tiles_x = (p.Wout + TW - 1) / TW;

@@ -657,13 +657,10 @@ static int launch_token_wgrad_dma(const TwP& p, hipStream_t st) {
   constexpr int LDS = NBUF * 2 * (FN + FK) * 32 * 64;
   auto kern = token_wgrad_dma_kernel<T, FN, FK, NBUF>;
   if (LDS > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-        set_error("pd_token_wgrad: cannot reserve %d bytes of LDS", LDS);
-        return PD_ERR_LAUNCH;
-      }
-      attr_set = true;
+    static LdsAttr attr;
+    if (!ensure_lds(attr, kern, LDS)) {
+      set_error("pd_token_wgrad: cannot reserve %d bytes of LDS", LDS);
+      return PD_ERR_LAUNCH;
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.splits * p.n_tiles * p.k_tiles)), dim3(256), LDS, st, p);
@@ -679,13 +676,10 @@ static int launch_linear(const LinP& p, hipStream_t st) {
   constexpr int LDS = NC == 4 ? (2 * XT > EPI ? 2 * XT : EPI) : (2 * XT > EPI_ST ? 2 * XT : EPI_ST);
   auto kern = linear_kernel<T, NC, GLU>;
   if (LDS > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-        set_error("pd_linear: cannot reserve %d bytes of LDS", LDS);
-        return PD_ERR_LAUNCH;
-      }
-      attr_set = true;
+    static LdsAttr attr;
+    if (!ensure_lds(attr, kern, LDS)) {
+      set_error("pd_linear: cannot reserve %d bytes of LDS", LDS);
+      return PD_ERR_LAUNCH;
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.t_tiles * p.c_tiles)), dim3(256), LDS, st, p);
@@ -992,13 +986,10 @@ static int launch_linear_dma(const LinP& p, hipStream_t st) {
   constexpr int MAIN = NBUF * BUF, EPI = (NC == 5 ? 128 : 256) * (64 * NC * 2 + 16) + (QKV ? 64 * NC / 8 * 4 : 0);     // QKV: + the per-head key maxima; NC = 5: two token halves in turn
   constexpr int LDS = MAIN > EPI ? MAIN : EPI;
   auto kern = linear_dma_kernel<T, NC, GLU, CK, QKV>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      set_error("pd_linear: cannot reserve %d bytes of LDS", LDS);
-      return PD_ERR_LAUNCH;
-    }
-    attr_set = true;
+  static LdsAttr attr;
+  if (!ensure_lds(attr, kern, LDS)) {
+    set_error("pd_linear: cannot reserve %d bytes of LDS", LDS);
+    return PD_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.t_tiles * p.c_tiles)), dim3(512), LDS, st, p);
   PD_LAUNCH_CHECK();
@@ -1253,13 +1244,10 @@ extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
     hipLaunchKernelGGL(token_wgrad_kernel<half_t>, dim3(grid), dim3(256), LDS, st, p);
   } else {
     constexpr int LDS = 2 * 2 * 4 * 64 * 128;           // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)token_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-        set_error("pd_token_wgrad: cannot reserve %d bytes of LDS", LDS);
-        return PD_ERR_LAUNCH;
-      }
-      attr_set = true;
+    static LdsAttr attr;
+    if (!ensure_lds(attr, token_wgrad_kernel<float>, LDS)) {
+      set_error("pd_token_wgrad: cannot reserve %d bytes of LDS", LDS);
+      return PD_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(token_wgrad_kernel<float>, dim3(grid), dim3(256), LDS, st, p);
   }

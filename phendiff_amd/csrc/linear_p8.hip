@@ -281,8 +281,8 @@ static int launch_p8(const LinP& p, hipStream_t st) {
   constexpr int MAIN = 2 * 4 * 16384, EPI = 256 * (256 * 2 + 16);
   constexpr int LDS = MAIN > EPI ? MAIN : EPI;
   auto kern = linear_p8_kernel<T, GLU>;
-  // (set on every launch: cheap, and correct for a process that drives several devices)
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+  static LdsAttr attr;
+  if (!ensure_lds(attr, kern, LDS)) {
     set_error("pd_linear: cannot reserve %d bytes of LDS", LDS);
     return PD_ERR_LAUNCH;
   }

@@ -29,6 +29,19 @@ static inline int diag_env(const char* name, int dflt) { const char* e = getenv(
     }                                    \
   } while (0)
 
+// A dynamic LDS size above 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize, and that attribute belongs to the function ON ONE
+// DEVICE: one flag per (call site, device), so a process that drives several GPUs sets it on each of them (a function-local
+// `static bool` covered the first device only).  Benign race between host threads: they write the same value.
+struct LdsAttr { bool done[16] = {}; };
+template <typename K> static inline bool ensure_lds(LdsAttr& f, K kern, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  if (dev >= 0 && f.done[dev]) return true;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  if (dev >= 0) f.done[dev] = true;
+  return true;
+}
+
 #define PD_LAUNCH_CHECK()                                              \
   do {                                                                 \
     hipError_t e_ = hipGetLastError();                                 \

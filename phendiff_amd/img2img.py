@@ -104,6 +104,12 @@ def classifier_free_guidance_forward_start(pipe, clean_images, target_class_labe
                 output_type=output_type).images
 
 
+# fp16 engine: the factor the Lp loss gradient carries through the UNet backward (`custom_guided_generation`).  |d loss / d x0| of an
+# Lp norm is <= 1 per element and ~ numel^-1/2 typically (2e-3 at 256 x 256 x 3): times 2^12 it sits mid-range of fp16 with 2^4 of
+# head-room for what the backward adds; a step that overflows anyway halves it.
+GUIDANCE_GRAD_SCALE = 4096.0
+
+
 @torch.no_grad()
 def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labels: torch.Tensor, p: float,
                              guidance_loss_scale: float, num_inference_steps: int, return_losses: bool = False):
@@ -112,7 +118,13 @@ def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labe
     (statistics kept), ``x0 = scheduler.step(...).pred_original_sample``, per-image ``Lp_loss(x0, input_images, p)``
     (``:245-270``), its gradient w.r.t. the image THROUGH the UNet (what ``torch.autograd.grad(losses_seq, images)`` returns:
     ``pd_lp_guidance`` -> input-gradient-only UNet backward), ``images -= guidance_loss_scale * grad``, then the scheduler
-    step with the model output computed before the push.  No autograd graph exists: the backward is the HIP plan."""
+    step with the model output computed before the push.  No autograd graph exists: the backward is the HIP plan.
+
+    fp16 engine (the reference runs this method under ``mixed_precision: fp16``, general_config.yaml:46 -- there autocast keeps the
+    gradient in fp32 where it can; here every activation gradient is fp16): the Lp loss gradient enters the backward times a static
+    power-of-two scale (:data:`GUIDANCE_GRAD_SCALE`, the role accelerate's GradScaler plays in training) and the image gradient is
+    un-scaled before the ``guidance_loss_scale`` push; a step whose gradient is not finite halves the scale and is redone (one host
+    read per step; the scale reached is kept for the following steps)."""
     from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline
     ldm = isinstance(pipe, CustomStableDiffusionImg2ImgPipeline)
     if not ldm and not isinstance(pipe, ConditionalDDIMPipeline):
@@ -141,6 +153,9 @@ def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labe
         plan = unet.input_grad_plan(B, H, W, dev)
         run_forward = lambda ts: plan.forward(images, ts, labels, None, model_out, st)
     model_out, d_out, d_direct, pushed = (torch.empty_like(images) for _ in range(4))
+    fp16 = getattr(unet, "compute_dtype", None) == "fp16"
+    gscale = float(GUIDANCE_GRAD_SCALE) if fp16 else 1.0
+    d_scaled = torch.empty_like(images) if fp16 else None
     splits = max(1, min(64, images[0].numel() // 4096))
     partial = torch.empty(B * splits, dtype=torch.float64, device=dev)
     losses = torch.empty(B, dtype=torch.float32, device=dev)
@@ -149,15 +164,26 @@ def custom_guided_generation(pipe, input_images: torch.Tensor, target_class_labe
     sched.set_timesteps(num_inference_steps)
     for t in sched.timesteps:
         ts = torch.full((B,), float(t), dtype=torch.float32, device=dev)
-        run_forward(ts)
         sa, sb, _, _, _ = sched.step_coefficients(t)
         a = L.LpGuidanceArgs(numel=images.numel(), per_sample=images[0].numel(), pred_type=L.PD_PRED[c.prediction_type],
                              clip=int(bool(c.clip_sample)), clip_range=float(c.clip_sample_range), sqrt_a=sa, sqrt_b=sb,
                              p=float(p), sample=images.data_ptr(), model_out=model_out.data_ptr(), target=target.data_ptr(),
                              partial=partial.data_ptr(), splits=splits, d_model_out=d_out.data_ptr(),
                              d_sample_direct=d_direct.data_ptr(), losses=losses.data_ptr())
-        L.check(lib.pd_lp_guidance(C.byref(a), st), "pd_lp_guidance")
-        plan.backward(d_out, st)
+        while True:
+            run_forward(ts)
+            L.check(lib.pd_lp_guidance(C.byref(a), st), "pd_lp_guidance")
+            if not fp16:
+                plan.backward(d_out, st)
+                break
+            torch.mul(d_out, gscale, out=d_scaled)
+            plan.backward(d_scaled, st)
+            if bool(torch.isfinite(plan.dsample).all()):       # (the one host read of an fp16 step)
+                plan.dsample.mul_(1.0 / gscale)
+                break
+            gscale *= 0.5                                       # overflow somewhere in the fp16 chain: halve and redo the step
+            if gscale < 2.0 ** -10:
+                raise FloatingPointError("gradient-guided transfer (fp16): the UNet input gradient is not finite at any scale")
         g = L.GuidanceApplyArgs(numel=images.numel(), scale=float(guidance_loss_scale), x=images.data_ptr(),
                                 g_direct=d_direct.data_ptr(), g_unet=plan.dsample.data_ptr(), out=pushed.data_ptr())
         L.check(lib.pd_guidance_apply(C.byref(g), st), "pd_guidance_apply")

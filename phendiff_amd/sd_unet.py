@@ -228,8 +228,7 @@ class SDUNet2DConditionModel(nn.Module):
         ``torch.autograd.grad(losses_seq, images)`` needs in the gradient-guided transfer with a latent-diffusion pipeline
         (utils_Img2Img.py:718-745)."""
         from .sd_unet_train import SDTrainWeights, SDUNetTrainPlan
-        if self.compute_dtype == "fp16":      # (fp16 trains under a loss scale; the guidance gradient has none: as the pixel UNet)
-            raise NotImplementedError("compute_dtype='fp16' has no gradient-guidance plan: build the model with 'bf16' (or 'f32')")
+        # (compute_dtype='fp16': the caller scales `dout` / un-scales `dlatents`, as for the pixel UNet -- img2img.custom_guided_generation)
         key = ("input_grad", B, H, W, tokens, str(device), self.compute_dtype)
         p = self._plans.get(key)
         if p is None:

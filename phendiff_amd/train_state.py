@@ -173,7 +173,7 @@ def save_state(trainer, output_dir: str, rank: int = 0, base_lr: Optional[float]
     if opt.ema is not None:
         for slot, (_, mod, prefix) in enumerate(mods):       # one EMAModel per trained module (train.py:224-241)
             mnames = [prefix + n for n, _ in mod.named_parameters() if prefix + n in trainer.params]
-            torch.save(ema_state_dict(opt.ema, fnames, mnames, sizes, opt.t, **{k: v for k, v in opt.ema_kwargs.items()}),
+            torch.save(ema_state_dict(opt.ema, fnames, mnames, sizes, getattr(opt, "t_ema", opt.t), **{k: v for k, v in opt.ema_kwargs.items()}),
                        os.path.join(output_dir, f"custom_checkpoint_{slot}.pkl"))
 
 
@@ -217,13 +217,16 @@ def load_state(trainer, input_dir: str, rank: int = 0) -> dict:
             ema_path = os.path.join(input_dir, f"custom_checkpoint_{slot}.pkl")
             if os.path.exists(ema_path):
                 esd = torch.load(ema_path, map_location="cpu")
-                # the engine derives the EMA decay from the optimizer's step count: a shadow saved at another count would
-                # silently continue on a different decay schedule
-                if int(esd.get("optimization_step", opt.t)) != opt.t:
-                    raise ValueError(f"{ema_path}: EMA optimization_step {esd['optimization_step']} != optimizer step {opt.t}")
+                # EMAModel.optimization_step = optimizer steps + skipped fp16 steps (EMAModel.step runs on every sync step,
+                # utils_training.py:553-556): the decay schedule continues from the SAVED count.  It can never be behind the optimizer.
+                step = int(esd.get("optimization_step", opt.t))
+                if step < opt.t:
+                    raise ValueError(f"{ema_path}: EMA optimization_step {step} < optimizer step {opt.t}")
+                opt.t_ema = step
                 for n, t in zip(mnames, esd["shadow_params"]):
                     opt.ema[off[n]:off[n] + t.numel()].copy_(t.reshape(-1).to(opt.ema.device, torch.float32))
             else:                                                # the reference's behaviour: EMA restarts from the weights
+                opt.t_ema = opt.t
                 for n in mnames:
                     k = trainer.params[n].numel()
                     opt.ema[off[n]:off[n] + k].copy_(opt.flat[off[n]:off[n] + k])

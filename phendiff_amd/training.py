@@ -209,6 +209,10 @@ class FlatAdamWEMA:
         self.tail = None            # (offset, numel): a trailing segment with its own AdamW step count (see set_tail)
         self.tail_names = ()
         self.t_tail = 0
+        # diffusers' EMAModel.optimization_step: EMAModel.step runs on EVERY sync step of the reference's loop, skipped fp16 steps
+        # included (utils_training.py:438-456, 553-556), so it is the optimizer's step count PLUS the skipped steps -- its own counter,
+        # saved / loaded as `optimization_step`, and the decay schedule is derived from it
+        self.t_ema = 0
         self.partial = torch.empty(1024, dtype=torch.float64, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.clip_coef = torch.ones(1, dtype=torch.float32, device=dev)
@@ -256,7 +260,7 @@ class FlatAdamWEMA:
         the gradient norm stays on the device (``self.grad_norm``).  With a :class:`LossScaler` (fp16 training) the gradients carry its
         scale: the norm is taken of the scaled gradients against ``max_grad_norm * scale`` (the same clip decision), ONE host read of
         that norm per step decides whether the step is skipped (``GradScaler.step``: not finite -> no parameter / moment update, the
-        step count does not advance, EMA still steps -- accelerate's loop calls ``ema.step`` regardless), and the factor the update
+        step count does not advance, EMA still steps on its own counter ``t_ema`` -- accelerate's loop calls ``ema.step`` regardless), and the factor the update
         multiplies the gradients with becomes clip_coef / scale."""
         lib = L.lib()
         st = torch.cuda.current_stream(self.flat.device).cuda_stream
@@ -278,7 +282,8 @@ class FlatAdamWEMA:
             found_inf = not math.isfinite(float(self.grad_norm))        # the one host read of an fp16 step (GradScaler's found_inf)
             self.scaler.update(found_inf)
             if found_inf:      # skipped step: EMA of the unchanged parameters, gradients zeroed, no step count
-                d = ema_decay(self.t + 1, **self.ema_kwargs) if self.ema is not None else 0.0
+                self.t_ema += 1
+                d = ema_decay(self.t_ema, **self.ema_kwargs) if self.ema is not None else 0.0
                 a = L.AdamWEmaArgs(numel=self.flat.numel(), lr=0.0, beta1=b1, beta2=b2, eps=self.eps, weight_decay=0.0, step_size=0.0,
                                    bias_correction2_sqrt=1.0, one_minus_decay=1.0 - d, zero_grad=int(zero_grad), clip_coef=None,
                                    param=self.flat.data_ptr(), grad=self.grad.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
@@ -291,7 +296,8 @@ class FlatAdamWEMA:
                 self.clip_coef.mul_(1.0 / S)         # (one element: the factor the update applies to the SCALED gradients)
             self.grad_norm.mul_(1.0 / S)             # the reported norm is the unscaled gradients'
         self.t += 1
-        d = ema_decay(self.t, **self.ema_kwargs) if self.ema is not None else 0.0
+        self.t_ema += 1
+        d = ema_decay(self.t_ema, **self.ema_kwargs) if self.ema is not None else 0.0
         clip = self.clip_coef.data_ptr() if (self.max_grad_norm is not None or S is not None) else None
 
         def launch(off, numel, t, ema_only=0):

@@ -259,9 +259,9 @@ class CustomCondUNet2DModel(nn.Module):
         """Forward + input-gradient-only backward plan (d loss / d sample through the UNet, no parameter gradients): what
         ``torch.autograd.grad(losses, images)`` needs in the gradient-guided transfer (utils_Img2Img.py:744-745)."""
         from .unet_train import TrainWeights, UNetTrainPlan
-        if self.compute_dtype == "fp16":
-            # (training in fp16 runs under a loss scale, training.LossScaler; the guidance gradient has none: its fp16 activation gradients underflow)
-            raise NotImplementedError("compute_dtype='fp16' has no gradient-guidance plan: build the model with 'bf16' (or 'f32')")
+        # compute_dtype='fp16' (the reference's `mixed_precision: fp16` img2img runs, general_config.yaml:46): the activation gradients
+        # are fp16, so the CALLER scales `dout` and un-scales `dsample` (img2img.custom_guided_generation: a static power-of-two scale
+        # on the Lp loss gradient, halved and the step redone when the result is not finite) -- round 6
         key = ("input_grad", B, H, W, str(device), self.compute_dtype)
         p = self._plans.get(key)
         if p is None:

@@ -229,7 +229,7 @@ def test_sd_ddib_graph_replays_the_eager_transfer_bit_for_bit(mode):
 
 
 # ---- gradient-guided transfer, latent-diffusion branch (utils_Img2Img.py:651-760 with a CustomStableDiffusionImg2ImgPipeline) ----------
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2)])      # measured 2.4e-6 / 1.2e-2
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2), ("fp16", 5e-3)])      # measured 2.4e-6 / 1.2e-2
 def test_sd_guidance_gradient_through_unet_matches_autograd(mode, tol):
     """d Lp(x0_pred, target) / d latents through the SD UNet (input-gradient-only backward plan) and the scheduler's x0 formula, one
     step: what ``torch.autograd.grad(losses_seq, images)`` returns with ``pipe.unet(images, t, target_class_embeds)`` (:718-745)."""
@@ -267,14 +267,17 @@ def test_sd_guidance_gradient_through_unet_matches_autograd(mode, tol):
                          target=tg.data_ptr(), partial=partial.data_ptr(), splits=2, d_model_out=d_out.data_ptr(),
                          d_sample_direct=d_dir.data_ptr(), losses=ls.data_ptr())
     L.check(L.lib().pd_lp_guidance(C.byref(a), st), "pd_lp_guidance")
-    plan.backward(d_out, st)
+    from phendiff_amd.img2img import GUIDANCE_GRAD_SCALE
+    S = float(GUIDANCE_GRAD_SCALE) if mode == "fp16" else 1.0      # fp16 engine: the static scale of the guided transfer (round 6)
+    plan.backward(d_out * S, st)
     torch.cuda.synchronize()
-    assert rel(out, mo.detach()) < (2e-5 if mode == "f32" else 3e-2)
-    assert rel(ls, losses.detach()) < (1e-5 if mode == "f32" else 2e-2)
-    assert rel(d_dir + plan.dsample, want) < tol
+    assert torch.isfinite(plan.dsample).all()
+    assert rel(out, mo.detach()) < {"f32": 2e-5, "bf16": 3e-2, "fp16": 4e-3}[mode]
+    assert rel(ls, losses.detach()) < {"f32": 1e-5, "bf16": 2e-2, "fp16": 3e-3}[mode]
+    assert rel(d_dir + plan.dsample / S, want) < tol
 
 
-@pytest.mark.parametrize("mode,tol_lat,tol_img", [("f32", 5e-5, 2e-4), ("bf16", 8e-2, 1e-1)])
+@pytest.mark.parametrize("mode,tol_lat,tol_img", [("f32", 5e-5, 2e-4), ("bf16", 8e-2, 1e-1), ("fp16", 1e-2, 2e-2)])
 def test_sd_gradient_guided_transfer_matches_golden(mode, tol_lat, tol_img):
     """_linear_interp_custom_guidance_inverted_start with the latent-diffusion pipeline, end to end, against the committed oracle
     vectors (tests/golden/make_golden.py --sd-guided: tiny stack, 32x32 images = 16x16 latents, S = 3, p = 2, loss scale 0.5 -- raised
