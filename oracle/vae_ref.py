@@ -153,14 +153,49 @@ class AutoencoderKLRef(nn.Module):
 
 
 # ---- VaeImageProcessor (diffusers image_processor.py; the members the reference pipeline touches) -----------------------
-def vae_preprocess_ref(image: torch.Tensor) -> torch.Tensor:
-    """Tensor input: 4-channel tensors (latents) are returned untouched; others are expected in [0, 1] and mapped to
-    [-1, 1] unless they already hold negative values (then returned as they are, with a warning in diffusers)."""
-    if image.ndim == 3:
-        image = image.unsqueeze(0)
-    if image.shape[1] == 4:
-        return image
-    return image if float(image.min()) < 0 else 2.0 * image - 1.0
+def vae_preprocess_ref(image, vae_scale_factor: int = 8, do_resize: bool = True, do_normalize: bool = True) -> torch.Tensor:
+    """``VaeImageProcessor.preprocess`` of diffusers 0.18.2 (image_processor.py; called at
+    custom_pipeline_stable_diffusion_img2img.py:638), every accepted input: a PIL image / numpy array / tensor or a list of
+    one kind.  PIL: resized DOWN to multiples of ``vae_scale_factor`` (lanczos), uint8 / 255, NHWC -> NCHW.  numpy: NHWC (or HWC
+    each) float in [0, 1] -> NCHW.  Tensors: 3-d ones are stacked, 4-d ones concatenated; 4-channel tensors (latents) are returned
+    untouched.  Sizes that are not multiples of the scale factor are refused (numpy / tensor).  Then [0, 1] -> [-1, 1] unless the
+    data already holds negative values (returned as they are, with a deprecation warning in diffusers)."""
+    import numpy as np
+    try:
+        from PIL import Image
+        pil_t = Image.Image
+    except Exception:      # pragma: no cover
+        pil_t, Image = (), None
+    kinds = (pil_t, np.ndarray, torch.Tensor) if pil_t else (np.ndarray, torch.Tensor)
+    if isinstance(image, kinds):
+        image = [image]
+    elif not (isinstance(image, list) and len(image) > 0 and all(isinstance(i, kinds) for i in image)):
+        raise ValueError("Input is in incorrect format: PIL image, numpy array, tensor or a list of them")
+    f = vae_scale_factor
+    if pil_t and isinstance(image[0], pil_t):
+        if do_resize:
+            image = [im.resize((im.width - im.width % f, im.height - im.height % f), resample=Image.LANCZOS) for im in image]
+        arr = np.stack([np.array(im).astype(np.float32) / 255.0 for im in image], axis=0)
+        if arr.ndim == 3:
+            arr = arr[..., None]
+        image = torch.from_numpy(arr.transpose(0, 3, 1, 2))
+    elif isinstance(image[0], np.ndarray):
+        arr = np.concatenate(image, axis=0) if image[0].ndim == 4 else np.stack(image, axis=0)
+        if arr.ndim == 3:
+            arr = arr[..., None]
+        image = torch.from_numpy(arr.transpose(0, 3, 1, 2))
+        if do_resize and (image.shape[2] % f or image.shape[3] % f):
+            raise ValueError(f"images must have height and width divisible by {f}, got {tuple(image.shape[2:])}")
+    else:
+        # (one 4-d tensor: torch.cat of a single tensor would only copy it)
+        image = (image[0] if len(image) == 1 else torch.cat(image, dim=0)) if image[0].ndim == 4 else torch.stack(image, dim=0)
+        if image.shape[1] == 4:
+            return image
+        if do_resize and (image.shape[2] % f or image.shape[3] % f):
+            raise ValueError(f"images must have height and width divisible by {f}, got {tuple(image.shape[2:])}")
+    if float(image.min()) < 0:
+        do_normalize = False
+    return 2.0 * image - 1.0 if do_normalize else image
 
 
 def vae_postprocess_ref(image: torch.Tensor, output_type: str = "np"):

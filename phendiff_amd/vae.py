@@ -428,20 +428,52 @@ class VaeDecodePlan(_VaePlan):
 
 # ---- VaeImageProcessor (diffusers image_processor.py; the members the reference pipeline touches) -----------------------
 class VaeImageProcessor:
-    """``preprocess`` (tensor inputs, ``custom_pipeline_stable_diffusion_img2img.py:638``) and ``postprocess``
+    """``preprocess`` (PIL / numpy / tensor inputs and lists of them, ``custom_pipeline_stable_diffusion_img2img.py:638``) and ``postprocess``
     (``:717-721``: ``(x/2+.5).clamp(0,1)`` -> "pt" | "np" NHWC float | "pil"; "latent" passes through)."""
 
-    def __init__(self, vae_scale_factor: int = 8, do_normalize: bool = True):
-        self.config = SimpleNamespace(vae_scale_factor=vae_scale_factor, do_normalize=do_normalize)
+    def __init__(self, vae_scale_factor: int = 8, do_normalize: bool = True, do_resize: bool = True):
+        self.config = SimpleNamespace(vae_scale_factor=vae_scale_factor, do_normalize=do_normalize, do_resize=do_resize)
 
-    def preprocess(self, image):
-        if not torch.is_tensor(image):
-            raise NotImplementedError("phendiff_amd: VaeImageProcessor.preprocess takes tensors (the reference's data loaders yield tensors)")
-        if image.ndim == 3:
-            image = image.unsqueeze(0)
-        if image.shape[1] == 4:                               # latents pass untouched
-            return image
-        if self.config.do_normalize and float(image.min()) >= 0:   # [0, 1] -> [-1, 1]; already-normalised tensors are left alone
+    def preprocess(self, image, height=None, width=None):
+        """Every input kind diffusers 0.18.2 accepts (image_processor.py ``preprocess``; the reference calls it at
+        custom_pipeline_stable_diffusion_img2img.py:638): a PIL image / numpy array / tensor, or a list of one kind.  Host-side
+        formatting only -- PIL images are resized down to multiples of ``vae_scale_factor`` (lanczos) and become NCHW float in [0, 1];
+        numpy arrays are NHWC (or HWC each); 3-d tensors are stacked, 4-d ones concatenated; 4-channel tensors (latents) pass
+        untouched; numpy / tensor sizes that are not multiples of the scale factor are refused.  Then [0, 1] -> [-1, 1], unless the
+        data already holds negative values.  The result stays on the device of a tensor input and is a CPU tensor otherwise (the
+        pipeline moves it, ``prepare_latents``)."""
+        import numpy as np
+        from PIL import Image
+        kinds = (Image.Image, np.ndarray, torch.Tensor)
+        if isinstance(image, kinds):
+            image = [image]
+        elif not (isinstance(image, list) and len(image) > 0 and all(isinstance(i, kinds) for i in image)):
+            raise ValueError("Input is in incorrect format: PIL image, numpy array, tensor or a list of them")
+        f = self.config.vae_scale_factor
+        resize = getattr(self.config, "do_resize", True)
+        if isinstance(image[0], Image.Image):
+            if resize:
+                image = [im.resize(((width or im.width) - (width or im.width) % f, (height or im.height) - (height or im.height) % f),
+                                   resample=Image.LANCZOS) for im in image]
+            arr = np.stack([np.array(im).astype(np.float32) / 255.0 for im in image], axis=0)
+            if arr.ndim == 3:
+                arr = arr[..., None]
+            image = torch.from_numpy(np.ascontiguousarray(arr.transpose(0, 3, 1, 2)))
+        elif isinstance(image[0], np.ndarray):
+            arr = np.concatenate(image, axis=0) if image[0].ndim == 4 else np.stack(image, axis=0)
+            if arr.ndim == 3:
+                arr = arr[..., None]
+            image = torch.from_numpy(np.ascontiguousarray(arr.transpose(0, 3, 1, 2)))
+            if resize and (image.shape[2] % f or image.shape[3] % f):
+                raise ValueError(f"images must have height and width divisible by {f}, got {tuple(image.shape[2:])}")
+        else:
+            # (one 4-d tensor: torch.cat of a single tensor would only copy it)
+            image = (image[0] if len(image) == 1 else torch.cat(image, dim=0)) if image[0].ndim == 4 else torch.stack(image, dim=0)
+            if image.shape[1] == 4:                           # latents pass untouched
+                return image
+            if resize and (image.shape[2] % f or image.shape[3] % f):
+                raise ValueError(f"images must have height and width divisible by {f}, got {tuple(image.shape[2:])}")
+        if self.config.do_normalize and float(image.min()) >= 0:   # [0, 1] -> [-1, 1]; already-normalised data is left alone
             image = 2.0 * image - 1.0
         return image
 

@@ -283,3 +283,25 @@ def test_sd_training_param_order_keeps_fused_projections_adjacent():
     cover = sorted((s, e) for s, e, _ in buckets)
     assert cover[0][0] == 0 and cover[-1][1] == sum(sizes) and all(a[1] == b[0] for a, b in zip(cover[:-1], cover[1:]))
     assert [r for _, _, r in buckets] == sorted(r for _, _, r in buckets)
+
+
+def test_vae_image_processor_accepts_every_input_kind_of_the_reference():
+    """phendiff_amd's VaeImageProcessor.preprocess is host-side formatting (no kernel): PIL / numpy / tensor / lists give exactly the
+    oracle's restatement of diffusers 0.18.2 (custom_pipeline_stable_diffusion_img2img.py:638)."""
+    from PIL import Image
+    from oracle import vae_preprocess_ref
+    from phendiff_amd.vae import VaeImageProcessor
+    ip = VaeImageProcessor(vae_scale_factor=8)
+    rng = np.random.default_rng(1)
+    u8 = rng.integers(0, 256, size=(21, 34, 3), dtype=np.uint8)
+    arr = rng.random((2, 16, 8, 3), dtype=np.float32)
+    t = torch.rand(3, 16, 16)
+    for inp in (Image.fromarray(u8), [Image.fromarray(u8), Image.fromarray(u8[:, ::-1].copy())], arr, [arr[0], arr[1]], arr * 2 - 1,
+                t, [t, t], torch.rand(2, 3, 8, 8), torch.rand(2, 3, 8, 8) * 2 - 1):
+        got, want = ip.preprocess(inp), vae_preprocess_ref(inp)
+        assert got.dtype == torch.float32 and torch.equal(got, want)
+    lat = torch.randn(2, 4, 5, 5)
+    assert ip.preprocess(lat) is lat or torch.equal(ip.preprocess(lat), lat)
+    for bad in (rng.random((1, 12, 8, 3), dtype=np.float32), torch.rand(1, 3, 12, 8), "x", []):
+        with pytest.raises(ValueError):
+            ip.preprocess(bad)

@@ -53,3 +53,32 @@ def test_image_processor():
     out = vae_postprocess_ref(torch.tensor([[[[-3.0, 0.0], [0.5, 3.0]]]]).repeat(1, 3, 1, 1), "np")
     assert out.shape == (1, 2, 2, 3) and np.allclose(out[0, :, :, 0], [[0, 0.5], [0.75, 1.0]])
     assert vae_postprocess_ref(lat, "latent") is lat
+
+
+def test_image_processor_pil_numpy_and_list_inputs():
+    """VaeImageProcessor.preprocess (diffusers 0.18.2 image_processor.py; custom_pipeline_stable_diffusion_img2img.py:638): PIL images
+    are resized down to multiples of the VAE scale factor and land in [-1, 1] NCHW; numpy NHWC in [0, 1] likewise; lists are batched;
+    sizes that are not multiples of 8 are refused for numpy / tensors; data that is already negative is not normalised again."""
+    import pytest
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    u8 = rng.integers(0, 256, size=(19, 27, 3), dtype=np.uint8)          # H = 19, W = 27 -> resized to 16 x 24
+    out = vae_preprocess_ref(Image.fromarray(u8))
+    assert tuple(out.shape) == (1, 3, 16, 24) and float(out.min()) >= -1 and float(out.max()) <= 1
+    u8b = rng.integers(0, 256, size=(16, 24, 3), dtype=np.uint8)          # no resize: exact values
+    out = vae_preprocess_ref([Image.fromarray(u8b), Image.fromarray(u8b[::-1].copy())])
+    want = torch.from_numpy(u8b.astype(np.float32) / 255.0).permute(2, 0, 1) * 2 - 1
+    assert tuple(out.shape) == (2, 3, 16, 24) and torch.equal(out[0], want) and torch.equal(out[1], want.flip(1))
+    arr = rng.random((2, 16, 8, 3), dtype=np.float32)
+    out = vae_preprocess_ref(arr)
+    assert torch.equal(out, torch.from_numpy(arr).permute(0, 3, 1, 2) * 2 - 1)
+    out = vae_preprocess_ref([arr[0], arr[1]])                            # list of HWC arrays: stacked
+    assert torch.equal(out, torch.from_numpy(arr).permute(0, 3, 1, 2) * 2 - 1)
+    neg = arr * 2 - 1
+    assert torch.equal(vae_preprocess_ref(neg), torch.from_numpy(neg).permute(0, 3, 1, 2))      # already in [-1, 1]
+    t = torch.rand(3, 8, 8)
+    assert torch.equal(vae_preprocess_ref([t, t]), torch.stack([t, t]) * 2 - 1)
+    with pytest.raises(ValueError):
+        vae_preprocess_ref(rng.random((1, 12, 8, 3), dtype=np.float32))   # 12 % 8 != 0
+    with pytest.raises(ValueError):
+        vae_preprocess_ref("not an image")
