@@ -32,8 +32,8 @@ extern "C" {
  * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
  * fold_ws_bytes + pd_linear_fold_workspace,
  * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_attn_bwd_args.slab / slab_bytes +
- * pd_attn_d8_bwd_workspace (the one-pass backward). */
-#define PD_ABI_VERSION 6
+ * pd_attn_d8_bwd_workspace (the one-pass backward); 7 = round 6: pd_gn_bwd_args.mod / mod_stride / dmod (scale_shift ResNet blocks train). */
+#define PD_ABI_VERSION 7
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
@@ -324,6 +324,13 @@ typedef struct {
   float* sum0; float* sum1;              /* optional out [B][splits][C0] / [B][splits][C1]: per-channel sums of the dx0 / dx1 values
                                             this call stores (feeds pd_channel_sum with x = NULL: the producer's bias /
                                             time-embedding gradients without another pass over dx) */
+  /* (ABI 7) resnet_time_scale_shift = "scale_shift" (cond_unet_2d.py:180,191,225; diffusers ResnetBlock2D: h = norm2(h) * (1 + scale)
+   * + shift with [scale | shift] = time_emb_proj(silu(temb))): the norm's affine is modulated per sample,
+   *   gamma_n = gamma (1 + scale_n),  beta_n = beta (1 + scale_n) + shift_n,
+   * mod = the forward's projection rows, row n at mod + n * mod_stride holding [scale (C) | shift (C)] (C1 must be 0).  dgamma / dbeta
+   * then accumulate sum_n (1 + scale_n) x the per-sample sums, and dmod (same row layout, written "=") receives
+   *   d scale_n = gamma * sum(dy xhat) + beta * sum(dy),   d shift_n = sum(dy). */
+  const float* mod; int mod_stride; float* dmod;
 } pd_gn_bwd_args;
 int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream);
 

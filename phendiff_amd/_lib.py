@@ -38,7 +38,7 @@ def library_is_current() -> bool:
 PD_F32, PD_BF16, PD_F16 = 0, 1, 2
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp = C.c_void_p
 
@@ -83,7 +83,8 @@ class GnBwdArgs(C.Structure):
                 ("silu", C.c_int), ("x0", vp), ("x1", vp), ("dz0", vp), ("dz1", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
                 ("beta", vp), ("partial", vp), ("splits", C.c_int), ("coef", vp), ("dx0", vp), ("dx1", vp),
                 ("accumulate0", C.c_int), ("accumulate1", C.c_int), ("dgamma", vp), ("dbeta", vp),
-                ("dz_combined", C.c_int), ("res", vp), ("sum0", vp), ("sum1", vp)]
+                ("dz_combined", C.c_int), ("res", vp), ("sum0", vp), ("sum1", vp),
+                ("mod", vp), ("mod_stride", C.c_int), ("dmod", vp)]
 
 
 class Pool2x2Args(C.Structure):

@@ -50,7 +50,13 @@ struct GnPiece {
     for (int j = 0; j < 8; ++j) {
       const int g = (c8 + j) / gs;
       mu[j] = a.mean[n * a.groups + g]; rs[j] = a.rstd[n * a.groups + g];
-      sc[j] = rs[j] * a.gamma[c8 + j]; sh[j] = a.beta[c8 + j] - mu[j] * sc[j];     // y = sc*x + sh (the forward's affine)
+      float gm = a.gamma[c8 + j], bt = a.beta[c8 + j];
+      if (a.mod) {            // scale_shift ResNet: the affine of THIS sample, gamma (1 + scale_n), beta (1 + scale_n) + shift_n
+        const float* row = a.mod + (size_t)n * a.mod_stride;
+        const float s1p = 1.0f + row[c8 + j];
+        gm *= s1p; bt = bt * s1p + row[C + c8 + j];
+      }
+      sc[j] = rs[j] * gm; sh[j] = bt - mu[j] * sc[j];     // y = sc*x + sh (the forward's affine)
     }
   }
 };
@@ -116,7 +122,17 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_ar
         const double* in = a.partial + (((size_t)n * a.splits + sp) * C + c) * 2;
         d1 += in[0]; d2 += in[1];
       }
-      s1[c] = d1 * (double)a.gamma[c]; s2[c] = d2 * (double)a.gamma[c];
+      double gm = (double)a.gamma[c];
+      if (a.mod) {
+        const float* row = a.mod + (size_t)n * a.mod_stride;
+        if (a.dmod) {        // d scale_n = gamma sum(dy xhat) + beta sum(dy), d shift_n = sum(dy)
+          float* drow = a.dmod + (size_t)n * a.mod_stride;
+          drow[c] = (float)(gm * d2 + (double)a.beta[c] * d1);
+          drow[C + c] = (float)d1;
+        }
+        gm *= 1.0 + (double)row[c];
+      }
+      s1[c] = d1 * gm; s2[c] = d2 * gm;
     }
     __syncthreads();
     if (tid < a.groups) {
@@ -133,7 +149,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_ar
     const int terms = a.B * a.splits;
     for (int t = tid; t < terms; t += 256) {
       const double* in = a.partial + ((size_t)t * C + c) * 2;
-      d1 += in[0]; d2 += in[1];
+      const double wgt = a.mod ? 1.0 + (double)a.mod[(size_t)(t / a.splits) * a.mod_stride + c] : 1.0;     // (1 + scale_n) of the term's sample
+      d1 += wgt * in[0]; d2 += wgt * in[1];
     }
 #pragma unroll
     for (int msk = 1; msk < 64; msk <<= 1) { d1 += __shfl_xor(d1, msk); d2 += __shfl_xor(d2, msk); }
@@ -417,6 +434,9 @@ extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
   PD_CHECK(a->x0 && a->dz0 && a->mean && a->rstd && a->gamma && a->beta && a->partial && a->coef && a->splits >= 1, PD_ERR_ARG, "pd_gn_silu_bwd: null pointer");
   PD_CHECK((a->C1 == 0) == (a->x1 == nullptr) && (a->C1 == 0 || a->dz_combined) == (a->dz1 == nullptr), PD_ERR_ARG, "pd_gn_silu_bwd: source 1 mismatch");
   PD_CHECK(a->dx0 || a->dx1, PD_ERR_ARG, "pd_gn_silu_bwd: no output");
+  PD_CHECK(a->mod == nullptr || (a->C1 == 0 && a->mod_stride >= 2 * a->C0), PD_ERR_SHAPE,
+           "pd_gn_silu_bwd: the scale_shift modulation needs one source and rows of [scale | shift] (mod_stride >= 2 C)");
+  PD_CHECK(a->dmod == nullptr || a->mod != nullptr, PD_ERR_ARG, "pd_gn_silu_bwd: dmod without mod");
   hipStream_t st = (hipStream_t)stream;
   const dim3 agrid((unsigned)(a->B * a->splits), (unsigned)((C + GN_CHUNK - 1) / GN_CHUNK));
   if (a->dtype == PD_F32) {

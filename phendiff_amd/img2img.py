@@ -278,15 +278,44 @@ def shard_batches(num_batches: int, rank: int, world_size: int, even_batches: bo
     return mine
 
 
-def _refuse_class_modes_in_graph(plan, who):
-    """The captured trajectories pass one int64 label per (step, image) row and capture `temb_rows` once: that is the
-    `nn.Embedding` class table (every shipped config) or no class conditioning.  `class_embed_type` "identity" (the rows ARE
-    float embedding vectors) and "timestep" (a second embedding MLP whose scratch tensors would be allocated inside the capture)
-    run through the eager loops (`inversion` / `ddib` / the pipeline call) only."""
-    mode = getattr(plan.w, "class_mode", None)
-    if mode is not None:
-        raise NotImplementedError(f"{who}: class_embed_type={mode!r} is not captured into a hipGraph; use the eager loop "
-                                  "(img2img.ddib / ConditionalDDIMPipeline.__call__)")
+class _ClassRows:
+    """Per-(step, image) class conditioning of a captured trajectory, for every ``class_embed_type`` (cond_unet_2d.py:146-153,
+    295-309).  The graph captures ONE ``pd_temb`` over all rows (+ one more for the class MLP of "timestep"); what changes between
+    replays is the CONTENT of static buffers, filled by ``fill`` on the runner's stream before the replay:
+      * nn.Embedding table (every shipped config) or no class conditioning: one int64 label per row;
+      * "identity": the rows ARE the fp32 embedding vectors, [rows][time_embed_dim];
+      * "timestep": the labels as fp32 go through the class MLP inside the graph (pre-allocated rows / scratch: a capture must not
+        allocate), whose output rows the main ``pd_temb`` adds."""
+
+    def __init__(self, plan, rows: int, device):
+        self.plan, self.rows = plan, rows
+        self.mode = getattr(plan.w, "class_mode", None)
+        tdim = plan.m.time_embed_dim
+        self.labels = torch.zeros((rows,), dtype=torch.int64, device=device) if self.mode is None else None
+        self.emb = torch.zeros((rows, tdim), dtype=torch.float32, device=device) if self.mode in ("identity", "timestep") else None
+        if self.mode == "timestep":
+            self.vals = torch.zeros((rows,), dtype=torch.float32, device=device)
+            self.scratch = torch.empty((rows, plan.w.proj_dim), dtype=torch.float32, device=device)
+
+    def fill(self, sl: slice, steps: int, B: int, cond: torch.Tensor):
+        """Rows ``sl`` (= ``steps`` x ``B``) <- the batch's conditioning repeated for every step."""
+        dev = self.plan.device
+        if self.mode is None:
+            self.labels[sl].view(steps, B).copy_(cond.to(device=dev, dtype=torch.int64).view(1, B).expand(steps, B))
+        elif self.mode == "identity":
+            rows = cond.to(device=dev, dtype=torch.float32)
+            if rows.numel() != B * self.emb.shape[1]:
+                raise ValueError(f"class_embed_type='identity': pass the (B, time_embed_dim) embedding rows, got {tuple(cond.shape)}")
+            self.emb[sl].view(steps, B, -1).copy_(rows.view(1, B, -1).expand(steps, B, -1))
+        else:
+            self.vals[sl].view(steps, B).copy_(cond.to(device=dev, dtype=torch.float32).view(1, B).expand(steps, B))
+
+    def temb(self, ts_rows, st, out):
+        """The launches that turn the rows into the [rows][proj_dim] projection table (captured)."""
+        plan = self.plan
+        if self.mode == "timestep":
+            plan._class_rows_timestep(None, self.rows, st, emb=self.emb, scratch=self.scratch, vals=self.vals)
+        plan.temb_rows(ts_rows, self.labels, self.emb, st, rows=self.rows, out=out)
 
 
 class DDIBGraph:
@@ -331,7 +360,6 @@ class DDIBGraph:
             self.use_graph = use_graph
             return
         self.plan = unet.new_plan(B, H, W, dev) if private_plan else unet.plan_for(B, H, W, dev)
-        _refuse_class_modes_in_graph(self.plan, "DDIBGraph")
         # schedulers (host tables)
         self.inv = DDIMInverseScheduler.from_config(pipe.scheduler.config, variant=variant)
         self.inv.set_timesteps(S)
@@ -349,7 +377,7 @@ class DDIBGraph:
         self.images = torch.empty((B, H, W, cin), dtype=torch.float32, device=dev)
         self.images_u8 = torch.empty((B, H, W, cin), dtype=torch.uint8, device=dev)
         self.ts_rows = torch.empty((nsteps * B,), dtype=torch.float32, device=dev)
-        self.label_rows = torch.empty((nsteps * B,), dtype=torch.int64, device=dev)
+        self.class_rows = _ClassRows(self.plan, nsteps * B, dev)
         ts_host = torch.tensor(self.inv_ts + self.gen_ts, dtype=torch.float32).repeat_interleave(B)
         self.ts_rows.copy_(ts_host)
         self.temb = torch.empty((nsteps * B, self.plan.w.proj_dim), dtype=torch.float32, device=dev)
@@ -377,7 +405,7 @@ class DDIBGraph:
     def _enqueue(self, st):
         lib, plan, B = self.lib, self.plan, self.B
         n_inv = len(self.inv_ts)
-        plan.temb_rows(self.ts_rows, self.label_rows, None, st, rows=self.ts_rows.numel(), out=self.temb)
+        self.class_rows.temb(self.ts_rows, st, self.temb)
         row_bytes = plan.w.proj_dim * 4
         for i, a in enumerate(self.step_args):
             plan.run(self.x.data_ptr(), self.temb.data_ptr() + i * B * row_bytes, self.model_out.data_ptr(), st)
@@ -431,10 +459,8 @@ class DDIBGraph:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self.x.copy_(clean_images, non_blocking=True)
-            o = orig_class_labels.to(device=self.device, dtype=torch.int64)
-            t = target_class_labels.to(device=self.device, dtype=torch.int64)
-            self.label_rows[: n_inv * B].view(n_inv, B).copy_(o.view(1, B).expand(n_inv, B))
-            self.label_rows[n_inv * B:].view(n_gen, B).copy_(t.view(1, B).expand(n_gen, B))
+            self.class_rows.fill(slice(0, n_inv * B), n_inv, B, orig_class_labels)
+            self.class_rows.fill(slice(n_inv * B, (n_inv + n_gen) * B), n_gen, B, target_class_labels)
             if self.use_graph:
                 L.check(self.lib.pd_graph_launch(self.graph, self.stream.cuda_stream), "pd_graph_launch")
             else:
@@ -611,7 +637,6 @@ class CFGForwardStartGraph:
         if B > unet.max_batch(H, W):
             raise ValueError(f"batch_size {B} exceeds what one launch plan holds at {H}x{W} ({unet.max_batch(H, W)} images)")
         self.plan = unet.plan_for(B, H, W, dev)
-        _refuse_class_modes_in_graph(self.plan, "CFGForwardStartGraph")
         cin = unet.config.in_channels
         sch = pipe.scheduler
         sch.set_timesteps(S)
@@ -628,7 +653,7 @@ class CFGForwardStartGraph:
         self.images = torch.empty((B, H, W, cin), dtype=torch.float32, device=dev)
         self.images_u8 = torch.empty((B, H, W, cin), dtype=torch.uint8, device=dev)
         self.ts_rows = torch.tensor(self.ts, dtype=torch.float32).repeat_interleave(B).to(dev)
-        self.label_rows = torch.empty((n * B,), dtype=torch.int64, device=dev)
+        self.class_rows = _ClassRows(self.plan, n * B, dev)
         self.zero_emb = torch.zeros((n * B, unet.time_embed_dim), dtype=torch.float32, device=dev)
         pd = self.plan.w.proj_dim
         self.temb_c = torch.empty((n * B, pd), dtype=torch.float32, device=dev)
@@ -667,7 +692,7 @@ class CFGForwardStartGraph:
     def _enqueue(self, st):
         lib, plan, B = self.lib, self.plan, self.B
         rows = self.ts_rows.numel()
-        plan.temb_rows(self.ts_rows, self.label_rows, None, st, rows=rows, out=self.temb_c)
+        self.class_rows.temb(self.ts_rows, st, self.temb_c)
         if self.do_cfg:
             plan.temb_rows(self.ts_rows, None, self.zero_emb, st, rows=rows, out=self.temb_u)
         L.check(lib.pd_add_noise(C.byref(self.noise_args), st), "pd_add_noise")
@@ -687,8 +712,7 @@ class CFGForwardStartGraph:
         with torch.cuda.stream(self.stream):
             self.clean.copy_(clean_images, non_blocking=True)
             self.noise.copy_(noise, non_blocking=True)
-            t = target_class_labels.to(device=self.device, dtype=torch.int64)
-            self.label_rows.view(n, B).copy_(t.view(1, B).expand(n, B))
+            self.class_rows.fill(slice(0, n * B), n, B, target_class_labels)
             if self.use_graph:
                 L.check(self.lib.pd_graph_launch(self.graph, self.stream.cuda_stream), "pd_graph_launch")
             else:

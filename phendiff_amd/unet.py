@@ -647,8 +647,6 @@ class UNetPlan:
         pre = e.cout >= self.PREAPPLY_MIN_COUT
         z1 = z2 = None
         ss = getattr(e, "scale_shift", False)       # the latent-diffusion plan's entries have no such switch
-        if ss and self.train:
-            raise NotImplementedError("the backward plan implements resnet_time_scale_shift = 'default' only")
         # "default": the projected embedding is added by conv1's epilogue; "scale_shift": it modulates norm2's affine instead
         t1 = None if ss else e.temb_off
         gn1 = self._gn(x0, x1, e.g1, e.be1, e.eps)
@@ -879,13 +877,18 @@ class UNetPlan:
         L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
         return out
 
-    def _class_rows_timestep(self, labels, rows, stream):
+    def _class_rows_timestep(self, labels, rows, stream, emb=None, scratch=None, vals=None):
         """``class_embedding(time_proj(class_labels))`` through ``pd_temb`` with the class MLP's weights: its ``emb`` output is the
-        row block the main call adds (the projections it also computes land in a scratch table)."""
+        row block the main call adds (the projections it also computes land in a scratch table).  ``emb`` / ``scratch`` / ``vals``:
+        pre-allocated buffers ([rows][time_embed_dim], [rows][proj_dim], the labels as fp32 [rows]) -- a hipGraph capture must not
+        allocate (img2img._ClassRows)."""
         w, c = self.w, self.m.config
-        emb = torch.empty((rows, self.m.time_embed_dim), dtype=torch.float32, device=self.device)
-        scratch = torch.empty((rows, w.proj_dim), dtype=torch.float32, device=self.device)
-        vals = labels.to(device=self.device, dtype=torch.float32).contiguous()
+        if emb is None:
+            emb = torch.empty((rows, self.m.time_embed_dim), dtype=torch.float32, device=self.device)
+        if scratch is None:
+            scratch = torch.empty((rows, w.proj_dim), dtype=torch.float32, device=self.device)
+        if vals is None:
+            vals = labels.to(device=self.device, dtype=torch.float32).contiguous()
         a = L.TembArgs(rows=rows, c0=c.block_out_channels[0], tdim=self.m.time_embed_dim, proj_dim=w.proj_dim,
                        flip_sin_to_cos=int(c.flip_sin_to_cos), freq_shift=float(c.freq_shift), num_classes=0,
                        timesteps=vals.data_ptr(), labels=None, class_emb=None, w1=w.cw1T.data_ptr(), b1=w.cb1.data_ptr(),

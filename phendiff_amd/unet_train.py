@@ -40,7 +40,7 @@ def training_param_order(m: CustomCondUNet2DModel) -> List[Tuple[str, torch.nn.P
     """(name, parameter) pairs in the order the flat training buffers use: all ``time_emb_proj`` weights (then biases)
     stacked in module order -- one [proj_dim][tdim] matrix, as ``pd_temb`` sees them --, each attention's
     to_q / to_k / to_v weights (then biases) adjacent -- the fused [3C][C] projection --, then everything else, the class
-    embedding table LAST (it receives no gradient on unconditional steps: torch's AdamW then skips it, so it is a tail
+    embedding's parameters LAST (they receive no gradient on unconditional steps: torch's AdamW then skips them, so they are a tail
     segment of the flat optimizer with its own step count)."""
     named = dict(m.named_parameters())
     out, seen = [], set()
@@ -59,10 +59,13 @@ def training_param_order(m: CustomCondUNet2DModel) -> List[Tuple[str, torch.nn.P
                 for which in ("to_q", "to_k", "to_v"):
                     take(f"{n}.{which}.{suffix}")
     for n in named:
-        if n not in seen and n != "class_embedding.weight":
+        if n not in seen and not n.startswith("class_embedding."):
             take(n)
-    if "class_embedding.weight" in named:
-        take("class_embedding.weight")
+    # the class embedding LAST: the nn.Embedding table, or (class_embed_type = "timestep", cond_unet_2d.py:146-153) the four tensors
+    # of the class MLP -- none of them receives a gradient on an unconditional step
+    for n in named:
+        if n.startswith("class_embedding."):
+            take(n)
     return out
 
 
@@ -133,16 +136,18 @@ class UNetTrainPlan(UNetPlan):
         self.frozen = frozenset(frozen)
         # the time-embedding chain (d proj -> time_emb_proj -> time_embedding MLP -> class table) runs iff one of its parameters trains
         self._temb_trains = self.param_grads and any(
-            n not in self.frozen for n in (grads or {}) if ".time_emb_proj." in n or n.startswith("time_embedding.") or n == "class_embedding.weight")
-        if self.param_grads and getattr(w, "class_mode", None) == "timestep":
-            # class_embed_type "timestep" (cond_unet_2d.py:146-153): inference plans only -- the class MLP has no gradient launches (no
-            # shipped config sets it).  "identity" trains: the rows are an INPUT (nn.Identity has no parameter, nothing to differentiate)
-            raise NotImplementedError(f"the backward plan implements the nn.Embedding class table and identity rows only (class_embed_type={w.class_mode!r})")
+            n not in self.frozen for n in (grads or {}) if ".time_emb_proj." in n or n.startswith("time_embedding.") or n.startswith("class_embedding."))
+        # class_embed_type "timestep" (cond_unet_2d.py:146-153, 301-305): the class MLP's forward keeps its sinusoid / pre-activation rows
+        # for the three gradient launches `_temb_bwd` adds (round 6).  "identity": the rows are an INPUT (nothing to differentiate)
+        self._class_mlp = getattr(w, "class_mode", None) == "timestep"
+        self._class_mlp_ran = False
         self.dsample = self._f32(B, m.config.in_channels, H, W) if input_grad else None
         if self.param_grads:
             self._check_layout()
         c0, tdim = m.config.block_out_channels[0], m.time_embed_dim
         self.t_feat, self.t_z1, self.t_emb = self._f32(B, c0), self._f32(B, tdim), self._f32(B, tdim)
+        if self._class_mlp:
+            self.c_feat, self.c_z1, self.c_emb, self.c_scratch = self._f32(B, c0), self._f32(B, tdim), self._f32(B, tdim), self._f32(B, w.proj_dim)
         self.temb_table = self._f32(B, w.proj_dim)
         self.bwd_ops: List[_Op] = []
         self.grad_ready: Dict[str, int] = {}   # parameter name -> index of the last backward op that writes its gradient
@@ -185,6 +190,22 @@ class UNetTrainPlan(UNetPlan):
             labels = None
             if class_emb is not None and class_emb.numel() != self.B * self.m.time_embed_dim:
                 raise ValueError(f"class_embed_type='identity': {class_emb.numel()} elements for {self.B} rows of {self.m.time_embed_dim}")
+        self._class_mlp_ran = False
+        if self._class_mlp:
+            # class_embedding(time_proj(class_labels)) (cond_unet_2d.py:301-305) through pd_temb with the class MLP's weights, keeping
+            # the sinusoid rows and the pre-activation for its backward; rows given directly (class_emb: the unconditional steps'
+            # zeros, utils_training.py:507-515) bypass the MLP, which then receives no gradient
+            if class_emb is None and labels is not None:
+                w, c = self.w, self.m.config
+                vals = labels.to(dtype=torch.float32).contiguous()
+                ca = L.TembArgs(rows=self.B, c0=c.block_out_channels[0], tdim=self.m.time_embed_dim, proj_dim=w.proj_dim,
+                                flip_sin_to_cos=int(c.flip_sin_to_cos), freq_shift=float(c.freq_shift), num_classes=0,
+                                timesteps=vals.data_ptr(), labels=None, class_emb=None, w1=w.cw1T.data_ptr(), b1=w.cb1.data_ptr(),
+                                w2=w.cw2T.data_ptr(), b2=w.cb2.data_ptr(), class_table=None, wp=w.wpT.data_ptr(), bp=w.bp.data_ptr(),
+                                emb=self.c_emb.data_ptr(), proj=self.c_scratch.data_ptr(), feat=self.c_feat.data_ptr(), z1=self.c_z1.data_ptr())
+                L.check(self.lib.pd_temb(C.byref(ca), stream), "pd_temb (class MLP)")
+                class_emb, self._class_mlp_ran, self._class_vals = self.c_emb, True, vals
+            labels = None
         a.timesteps, a.labels, a.class_emb = timesteps.data_ptr(), L.ptr(labels), L.ptr(class_emb)
         a.emb, a.proj = self.t_emb.data_ptr(), self.temb_table.data_ptr()
         a.feat, a.z1 = self.t_feat.data_ptr(), self.t_z1.data_ptr()
@@ -353,7 +374,9 @@ class UNetTrainPlan(UNetPlan):
             self.ops = ops
         return y
 
-    def _gn_bwd(self, gn, dz, silu, *, combined=False, res=None, wname=None):
+    def _gn_bwd(self, gn, dz, silu, *, combined=False, res=None, wname=None, mod_off=None):
+        """``mod_off``: column of this norm's [scale | shift] block in the step's projection table (scale_shift ResNet blocks,
+        pd_gn_bwd_args.mod): the backward then also writes d [scale | shift] into the same columns of ``self.dproj``."""
         s = self.gn_saved[id(gn[0])]
         x0, x1 = s.x0, s.x1
         B, h, w, c0 = x0.shape
@@ -371,6 +394,9 @@ class UNetTrainPlan(UNetPlan):
                         accumulate0=int(g0[1]), accumulate1=int(g1[1]) if g1 else 0,
                         dgamma=L.ptr(dgam), dbeta=L.ptr(dbet),
                         dz_combined=1 if (combined and c1) else 0, res=L.ptr(res))
+        if mod_off is not None:
+            a.mod, a.mod_stride = self.temb_table.data_ptr() + 4 * mod_off, self.w.proj_dim
+            a.dmod = self.dproj.data_ptr() + 4 * mod_off if self._temb_trains else None
         g0[1] = True
         if g1:
             g1[1] = True
@@ -534,11 +560,17 @@ class UNetTrainPlan(UNetPlan):
         else:
             res = dout
         dz2 = self._dgrad(dout, te.w2d, e.cout)
-        self._gn_bwd(rec.gn2, dz2, 1, wname=n + ".norm2")
+        ss = getattr(e, "scale_shift", False)
+        # "scale_shift" (cond_unet_2d.py:180,191,225): the projection modulates norm2's affine, h = norm2(h1) (1 + scale) + shift; its
+        # gradient [d scale | d shift] comes out of the GroupNorm backward (pd_gn_bwd_args.mod / dmod) instead of conv1's epilogue
+        self._gn_bwd(rec.gn2, dz2, 1, wname=n + ".norm2", mod_off=e.temb_off if ss else None)
         dh1 = self._g(rec.h1)[0]
-        # d time_emb_proj output [n][co] = sum over pixels of d h1 (the projection is broadcast over the pixels)
-        per = self.dproj[:, e.temb_off:]
-        self._bias_grad(dh1, G(n + ".conv1.bias"), per_sample=per, per_stride=self.w.proj_dim)
+        if ss:
+            self._bias_grad(dh1, G(n + ".conv1.bias"))
+        else:
+            # d time_emb_proj output [n][co] = sum over pixels of d h1 (the projection is broadcast over the pixels)
+            per = self.dproj[:, e.temb_off:]
+            self._bias_grad(dh1, G(n + ".conv1.bias"), per_sample=per, per_stride=self.w.proj_dim)
         if rec.z1 is not None:
             self._wgrad(rec.z1, None, None, 0, dh1, G(n + ".conv1.weight"))
         else:
@@ -628,6 +660,20 @@ class UNetTrainPlan(UNetPlan):
             self._emb_grad_args = L.EmbeddingGradArgs(rows=B, dim=tdim, num_classes=m.class_embedding.weight.shape[0], labels=None,
                                                       d=demb.data_ptr(), dtable=G("class_embedding.weight").data_ptr())
             self._emb_grad_at = len(self.bwd_ops)
+        if self._class_mlp and any(n.startswith("class_embedding.") and n not in self.frozen for n in self.grads):
+            # emb = time_embedding(...) + class_embedding(time_proj(labels)): the class MLP sees the same d emb.  These three launches run
+            # only on steps whose labels went through the MLP (`backward` skips the [start, end) range otherwise)
+            dcz1 = self._f32(B, tdim)
+            start = len(self.bwd_ops)
+            self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=tdim, out_dim=tdim, x_silu=1, dy=demb.data_ptr(),
+                    x=self.c_z1.data_ptr(), dw=G("class_embedding.linear_2.weight").data_ptr(),
+                    db=G("class_embedding.linear_2.bias").data_ptr()), "linear_wgrad")
+            self._b(lib.pd_linear_dgrad, L.LinearDgradArgs(rows=B, in_dim=tdim, out_dim=tdim, dy=demb.data_ptr(),
+                    w=P["class_embedding.linear_2.weight"].data_ptr(), pre=self.c_z1.data_ptr(), dx=dcz1.data_ptr()), "linear_dgrad")
+            self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=c0, out_dim=tdim, x_silu=0, dy=dcz1.data_ptr(),
+                    x=self.c_feat.data_ptr(), dw=G("class_embedding.linear_1.weight").data_ptr(),
+                    db=G("class_embedding.linear_1.bias").data_ptr()), "linear_wgrad")
+            self._class_mlp_ops = (start, len(self.bwd_ops))
         self._b(lib.pd_linear_wgrad, L.LinearWgradArgs(rows=B, in_dim=tdim, out_dim=tdim, x_silu=1, dy=demb.data_ptr(),
                 x=self.t_z1.data_ptr(), dw=G("time_embedding.linear_2.weight").data_ptr(),
                 db=G("time_embedding.linear_2.bias").data_ptr()), "linear_wgrad")
@@ -645,7 +691,10 @@ class UNetTrainPlan(UNetPlan):
         byref, check = C.byref, L.check
         labels = getattr(self, "_labels", None)
         emb_at = getattr(self, "_emb_grad_at", -1)
+        skip0, skip1 = getattr(self, "_class_mlp_ops", (0, 0)) if not getattr(self, "_class_mlp_ran", False) else (0, 0)
         for i, op in enumerate(self.bwd_ops):
+            if skip0 <= i < skip1:            # class MLP (class_embed_type = "timestep") on a step whose rows bypassed it
+                continue
             if i == emb_at and labels is not None:
                 self._emb_grad_args.labels = labels.data_ptr()
                 check(self.lib.pd_embedding_grad(byref(self._emb_grad_args), stream), "pd_embedding_grad")
@@ -785,6 +834,9 @@ class _Repacker:
             lambda: w.bp.copy_(torch.as_strided(first.bias.data, (pd_,), (1,))),
             lambda: w.conv_out_b[:co].copy_(m.conv_out.bias.data),
         ]
+        if getattr(w, "class_mode", None) == "timestep":      # the class MLP's transposed weights (its biases alias the parameters)
+            ce = m.class_embedding
+            self.small += [lambda: w.cw1T.copy_(ce.linear_1.weight.data.t()), lambda: w.cw2T.copy_(ce.linear_2.weight.data.t())]
         for t in (w.b1, w.b2, w.conv_in_b):
             pass  # alias the master parameters (fp32, contiguous, same device): nothing to refresh
         self._alias_check = [(w.b1, te.linear_1.bias), (w.b2, te.linear_2.bias), (w.conv_in_b, m.conv_in.bias),
@@ -826,8 +878,9 @@ class UNetTrainer:
         self.frozen = frozenset(n for (n, _), f in zip(order, flags) if not f)
         self.opt = FlatAdamWEMA([p for _, p in order], lr, use_ema=use_ema, max_grad_norm=max_grad_norm, **adamw)
         self.opt.set_trainable(flags)
-        if order[-1][0] == "class_embedding.weight" and flags[-1]:
-            self.opt.set_tail(order[-1][1].numel(), ("class_embedding.weight",))
+        tail = [(n, p, f) for (n, p), f in zip(order, flags) if n.startswith("class_embedding.")]
+        if tail and all(f for _, _, f in tail):
+            self.opt.set_tail(sum(p.numel() for _, p, _ in tail), tuple(n for n, _, _ in tail))
         self._cond = True
         # DDP's wrap-time broadcast (train.py:311-326): rank 0's parameters everywhere; the EMA shadow starts from them
         broadcast_from_rank0_(self.opt.flat, group)

@@ -107,6 +107,83 @@ def test_centered_input_and_identity_class_rows_train(mode, per_tol, glob_tol):
     assert rel(plan.dsample, x.grad) < (2e-5 if mode == "f32" else 4e-2)
 
 
+BWD_VARIANTS = [dict(resnet_time_scale_shift="scale_shift"), dict(class_embed_type="timestep"),
+                dict(center_input_sample=True, resnet_time_scale_shift="scale_shift", class_embed_type="timestep")]
+
+
+@pytest.mark.parametrize("mode,per_tol,glob_tol", [("f32", 2e-4, 2e-5), ("bf16", 8e-2, 2e-2), ("fp16", 3e-2, 6e-3)])
+@pytest.mark.parametrize("variant", BWD_VARIANTS, ids=lambda v: "+".join(sorted(v)))
+def test_scale_shift_resnets_and_the_timestep_class_mlp_train(mode, per_tol, glob_tol, variant):
+    """Round 6: the two constructor switches whose backward was refused until now (cond_unet_2d.py:146-153,180,191,225).
+    ``resnet_time_scale_shift = "scale_shift"``: h = norm2(h1) (1 + scale) + shift -- the GroupNorm backward works on the per-sample
+    affine and returns d [scale | shift] (pd_gn_bwd_args.mod / dmod), which feeds the stacked time_emb_proj gradient.
+    ``class_embed_type = "timestep"``: emb += class_embedding(time_proj(labels)) -- the class MLP gets the time-embedding MLP's three
+    gradient launches on d emb; a step whose rows bypass it (class_emb given: the unconditional steps) leaves its gradients at zero.
+    Parameter gradients, d loss / d sample, and three optimisation steps against torch on the oracle."""
+    import phendiff_amd as P
+    from oracle import CondUNet2DRef
+    from phendiff_amd.unet_train import UNetTrainer
+    torch.manual_seed(3)
+    cfg = dict(P.UNET_CONFIGS["super_small"], sample_size=32, **variant)
+    keys = CondUNet2DRef.__init__.__code__.co_varnames
+    r = CondUNet2DRef(**{k: v for k, v in cfg.items() if k in keys}).eval()
+    m = P.CustomCondUNet2DModel(compute_dtype=mode, **cfg)
+    m.load_state_dict(r.state_dict())
+    m = m.to("cuda:0")
+    sched, clean, noise, ts, labels, noisy, target = batch(3, 32)
+    x = noisy.clone().requires_grad_(True)
+    for p in r.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    out = r(x, ts, class_labels=labels).sample
+    loss_ref = torch.nn.functional.mse_loss(out, target)
+    loss_ref.backward()
+    ref = {n: p.grad.clone() for n, p in r.named_parameters()}
+    tr = UNetTrainer(m, sched, lr=1e-4, use_ema=False)
+    scale = tr.opt.scaler.scale if tr.opt.scaler is not None else 1.0
+    loss, _ = tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda())
+    torch.cuda.synchronize()
+    assert set(ref) == set(tr.grads)
+    assert abs(float(loss) - float(loss_ref.detach())) < {"f32": 1e-5, "bf16": 5e-3, "fp16": 2e-3}[mode] * float(loss_ref.detach())
+    compare(ref, {n: g / scale for n, g in tr.grads.items()}, per_tol, glob_tol)
+    if variant.get("class_embed_type") == "timestep":
+        # rows given directly (an unconditional step's zeros, utils_training.py:507-515): the class MLP is bypassed and gets no gradient.
+        # (The reference itself cannot take this path with class_embed_type = "timestep" -- cond_unet_2d.py:302 calls
+        # time_proj(class_labels) on None -- so there is no oracle value: the engine's superset is checked for what it must not do.)
+        tr.opt.grad.zero_()
+        zeros = torch.zeros(3, m.time_embed_dim)
+        tr.forward_backward(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_emb=zeros.cuda())
+        torch.cuda.synchronize()
+        assert all(float(g.abs().max()) == 0.0 for n, g in tr.grads.items() if n.startswith("class_embedding."))
+        assert all(torch.isfinite(g).all() for g in tr.grads.values()) and float(tr.grads["conv_in.weight"].abs().max()) > 0
+        assert tr.opt.tail_names == tuple(n for n in tr.grads if n.startswith("class_embedding.")) and len(tr.opt.tail_names) == 4
+    # d loss / d sample through the same plan (the gradient-guided transfer's gradient)
+    if mode != "fp16":
+        plan = m.input_grad_plan(3, 32, 32, torch.device("cuda:0"))
+        st = torch.cuda.current_stream().cuda_stream
+        o = torch.empty(3, 3, 32, 32, device="cuda:0")
+        plan.forward(noisy.cuda().contiguous(), ts.cuda().float(), labels.cuda(), None, o, st)
+        dout = (2.0 / o.numel()) * (o - target.cuda())
+        plan.backward(dout.contiguous(), st)
+        torch.cuda.synchronize()
+        assert rel(plan.dsample, x.grad) < (2e-5 if mode == "f32" else 4e-2)
+    if mode == "f32":
+        # three optimisation steps track torch.optim.AdamW on the oracle (the re-pack refreshes the class MLP's transposed weights)
+        tr2 = UNetTrainer(m, sched, lr=2e-4, use_ema=False)
+        opt = torch.optim.AdamW(r.parameters(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+        for _ in range(3):
+            lr_, _ = oracle_grads(r, noisy, ts, target, labels=labels)
+            torch.nn.utils.clip_grad_norm_(r.parameters(), 1.0)
+            opt.step()
+            lg = float(tr2.step(noisy.cuda(), ts.cuda(), clean.cuda(), noise.cuda(), class_labels=labels.cuda()))
+            assert abs(lg - float(lr_)) < 2e-4 * abs(float(lr_))
+        torch.cuda.synchronize()
+        sd = r.state_dict()
+        num = sum(float((p.detach().cpu() - sd[n]).double().pow(2).sum()) for n, p in m.named_parameters())
+        den = sum(float(sd[n].double().pow(2).sum()) for n, _ in m.named_parameters())
+        assert (num / den) ** 0.5 < 1e-5
+
+
 def test_inference_after_training_steps_sees_the_updated_upsampler_phase_kernels():
     """The sub-pixel upsamplers multiply with PRE-SUMMED copies of the 3x3 weights (four 2x2 phase kernels): the re-pack after every
     optimizer step has to refresh them too -- an inference forward of the trained model (train.py's evaluation generation runs in the same

@@ -93,31 +93,53 @@ def test_unet_forward_config_variants(mode, tol, variant):
             ref = r(x, t, class_labels=labels).sample
         got = m(x.cuda(), t, class_labels=labels.cuda()).sample
         assert rel(got, ref) < tol, (mode, variant, t)
-    # the same model through the DDIB transfer, eager and as one hipGraph (per-step embedding rows baked into the nodes)
-    if variant.get("class_embed_type") is None:
-        from oracle import DDIMSchedulerRef, ConditionalDDIMPipelineRef, ddib_ref
-        cfg = dict(P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
-        ilab = synth_batch(3, 32)[1]
-        want, _ = ddib_ref(ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**cfg)), x, ilab, 1 - ilab, 2)
-        pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**cfg))
-        got = P.ddib(pipe, x.cuda(), ilab.cuda(), (1 - ilab).cuda(), 2)
-        assert rel(got, want) < (2e-5 if mode == "f32" else 2e-2)
-        runner = P.DDIBGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
-        got_g = runner.run(x.cuda(), ilab.cuda(), (1 - ilab).cuda()).images
-        assert np.array_equal(got_g.cpu().numpy(), got)
+    # the same model through the DDIB transfer, eager and as one hipGraph -- every class_embed_type (round 6: the captured trajectory
+    # holds its conditioning in static row buffers, img2img._ClassRows: int64 labels | fp32 "identity" rows | fp32 label values that go
+    # through the class MLP inside the graph)
+    from oracle import DDIMSchedulerRef, ConditionalDDIMPipelineRef, ddib_ref
+    scfg = dict(P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"])
+    kind = variant.get("class_embed_type")
+    if kind == "identity":
+        g5 = torch.Generator().manual_seed(6)
+        orig, target = labels, torch.randn(3, m.time_embed_dim, generator=g5)
+    elif kind == "timestep":
+        orig, target = labels, torch.tensor([1.0, 0.0, 3.0])
     else:
-        # the captured trajectories pass one int64 label per row: the other class-embedding forms are refused at construction
-        # (they used to read rows * time_embed_dim floats from that buffer), and a short buffer is refused by temb_rows
-        pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**P.SCHEDULER_CONFIGS["3k_steps_clipping_rescaling"]))
-        with pytest.raises(NotImplementedError, match="class_embed_type"):
-            P.DDIBGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
-        with pytest.raises(NotImplementedError, match="class_embed_type"):
-            P.CFGForwardStartGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
-        if variant.get("class_embed_type") == "identity":
-            plan = m.plan_for(3, 32, 32, torch.device("cuda:0"))
-            with pytest.raises(ValueError, match="time_embed_dim"):
-                plan.temb_rows(torch.zeros(3, device="cuda"), torch.zeros(3, dtype=torch.int64, device="cuda"), None,
-                               torch.cuda.current_stream().cuda_stream)
+        orig = synth_batch(3, 32)[1]
+        target = 1 - orig
+    rpipe = ConditionalDDIMPipelineRef(r, DDIMSchedulerRef(**scfg))
+    pipe = P.ConditionalDDIMPipeline(m, P.DDIMScheduler(**scfg))
+    if kind == "identity":
+        # the pipeline takes embedding ROWS as `class_emb` (check_inputs: class_labels is 1-D, pipeline_conditionial_ddim.py:99-105), so
+        # `_ddib` is spelled out: inversion under the original rows, then the pipeline call with the target rows
+        from oracle import inversion_ref
+        kw = dict(w=0, num_inference_steps=2, add_forward_noise_to_image=False, frac_diffusion_skipped=0)
+        want = rpipe(class_labels=target, start_image=inversion_ref(rpipe, x, orig, 2), **kw).images      # (the oracle's pipeline has no check_inputs)
+        eager = lambda o, t: pipe(None, class_emb=t.cuda(), start_image=P.inversion(pipe, x.cuda(), o.cuda(), 2), output_type="numpy", **kw).images
+    else:
+        want, _ = ddib_ref(rpipe, x, orig, target, 2)
+        eager = lambda o, t: P.ddib(pipe, x.cuda(), o.cuda(), t.cuda(), 2)
+    got = eager(orig, target)
+    assert rel(got, want) < (2e-5 if mode == "f32" else 2e-2)
+    runner = P.DDIBGraph(pipe, batch_size=3, num_inference_steps=2, height=32, width=32)
+    got_g = runner.run(x.cuda(), orig.cuda(), target.cuda()).images
+    assert np.array_equal(got_g.cpu().numpy(), got)
+    got_g2 = runner.run(x.cuda(), target.cuda(), orig.cuda()).images            # a replay with other conditioning: the buffers, not the nodes
+    assert np.array_equal(got_g2.cpu().numpy(), eager(target, orig))
+    # CFG forward-start as one graph against its eager form (cond + uncond evaluations, fused guidance step)
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(8)).cuda()
+    cfgg = P.CFGForwardStartGraph(pipe, batch_size=3, num_inference_steps=4, height=32, width=32, frac_diffusion_skipped=0.5, guidance_scale=2.5)
+    a1 = cfgg.run(x.cuda(), target.cuda(), noise).images.cpu().numpy()
+    eager = P.CFGForwardStartGraph(pipe, batch_size=3, num_inference_steps=4, height=32, width=32, frac_diffusion_skipped=0.5, guidance_scale=2.5,
+                                   use_graph=False)
+    assert np.array_equal(a1, eager.run(x.cuda(), target.cuda(), noise).images.cpu().numpy())
+    if kind == "identity":
+        plan = m.plan_for(3, 32, 32, torch.device("cuda:0"))
+        with pytest.raises(ValueError, match="time_embed_dim"):      # a short row buffer is refused, not read past its end
+            plan.temb_rows(torch.zeros(3, device="cuda"), torch.zeros(3, dtype=torch.int64, device="cuda"), None,
+                           torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(ValueError, match="identity"):
+            runner.run(x.cuda(), torch.zeros(3, dtype=torch.int64).cuda(), target.cuda())
 
 
 def test_unet_forward_small_denoiser_f32():
