@@ -32,7 +32,8 @@ extern "C" {
  * pd_linear_args.kmax2_out), PD_F16 and pd_zero / pd_gn_apply / pd_attn_wide; 3 = round 3; 4 = round 4 (pd_comm_query, pd_linear_args.fold_ws /
  * fold_ws_bytes + pd_linear_fold_workspace,
  * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_attn_bwd_args.slab / slab_bytes +
- * pd_attn_d8_bwd_workspace (the one-pass backward); 7 = round 6: pd_gn_bwd_args.mod / mod_stride / dmod (scale_shift ResNet blocks train). */
+ * pd_attn_d8_bwd_workspace (the one-pass backward); 7 = round 6: pd_gn_bwd_args.mod / mod_stride / dmod (scale_shift ResNet blocks train);
+ * pd_resize_tf1, pd_conv_rect, pd_pool2d, pd_fc_f32 (the evaluation metrics' feature extractor). */
 #define PD_ABI_VERSION 7
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
@@ -662,6 +663,33 @@ int pd_event_create(void** ev);
 int pd_event_record(void* ev, void* stream);
 int pd_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int pd_event_destroy(void* ev);
+
+/* ------------------------------------------------------------------------------------------------
+ * (ABI 7) The evaluation metrics' feature extractor: FID / IS / KID as torch_fidelity.calculate_metrics computes them for
+ * utils_training.py:948-1001 (per class at evaluation time) and utils_Img2Img.py:462-563 (after a class-transfer experiment) run the
+ * "inception-v3-compat" network (TF-Slim InceptionV3 of the original FID code) over uint8 images.  csrc/metric_kernels.hip; host side
+ * phendiff_amd/metrics.py (BatchNorm folded into weights / bias at pack time; statistics in fp64 on the host).
+ *   pd_resize_tf1: x uint8 NHWC [N][H][W][3] -> y NHWC [N][OH][OW][32] in `dtype` (channels 3..31 zero):
+ *       v = bilinear(x) with source coordinate = destination index * scale (scale_y = H / OH, scale_x = W / OW as fp32; no half-pixel
+ *       centres, neighbours floor / min(floor + 1, size - 1): interpolate_bilinear_2d_like_tensorflow1x), y = (v - sub) / div.
+ *   pd_conv_rect: y[b][oy][ox][y_co + co] = relu?(bias[co] + sum W[co][ci][ky][kx] x[b][oy stride + ky - pad_h][ox stride + kx - pad_w][ci])
+ *       for co < Cout_pad; x NHWC with channel stride x_cs (>= Cin, Cin % 32 == 0), y NHWC with channel stride y_cs (the output is a
+ *       channel SLICE of a wider tensor: the concatenation of the Inception branches); w_packed = pd_conv's fragment order with
+ *       taps = KH * KW (tap = ky * KW + kx), [Cout_pad/32][Cin/32][taps][2][64][8]; bias fp32 [Cout_pad].
+ *   pd_pool2d: mode 0 max / 1 average with count_include_pad = False over k x k windows (stride, pad; padding never wins a max),
+ *       NHWC -> a channel slice of y; mode 2: global average over Hin x Win -> y fp32 [B][C].
+ *   pd_fc_f32: y[r][o] = sum_k x[r][k] wt[k][o] (+ bias[o]), fp32 (wt = the Linear weight transposed, [in][out]). */
+typedef struct { int dtype; int N, H, W, OH, OW; float scale_y, scale_x, sub, div; const unsigned char* x; void* y; } pd_resize_tf1_args;
+int pd_resize_tf1(const pd_resize_tf1_args* a, void* stream);
+typedef struct {
+  int dtype; int B, Hin, Win, Cin, Hout, Wout, Cout_pad, KH, KW, stride, pad_h, pad_w, relu;
+  const void* x; int x_cs; const void* w_packed; const float* bias; void* y; int y_cs, y_co;
+} pd_conv_rect_args;
+int pd_conv_rect(const pd_conv_rect_args* a, void* stream);
+typedef struct { int dtype; int B, Hin, Win, C, Hout, Wout, k, stride, pad, mode; const void* x; int x_cs; void* y; int y_cs, y_co; } pd_pool2d_args;
+int pd_pool2d(const pd_pool2d_args* a, void* stream);
+typedef struct { int rows, in_dim, out_dim; const float* x; const float* wt; const float* bias; float* y; } pd_fc_f32_args;
+int pd_fc_f32(const pd_fc_f32_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pd_comm_*: the data-parallel gradient exchange -- DistributedDataParallel's bucketed all-reduce under accelerator.backward(loss)

@@ -40,3 +40,7 @@ from .pipeline_ref import (  # noqa: F401
 )
 from .eval_generation_ref import (  # noqa: F401
     EMASwapRef, eval_batch_sizes_ref, eval_generation_ddim_ref, eval_generation_sd_ref, latents_preview_ref, split_ref)
+from .inception_ref import (  # noqa: F401
+    InceptionV3FeaturesRef, randomize_inception_, tf1_bilinear_resize_ref, fid_statistics_ref, fid_from_statistics_ref, isc_ref, kid_ref,
+    calculate_metrics_ref,
+)

@@ -264,6 +264,28 @@ class ZeroArgs(C.Structure):
     _fields_ = [("ptr", vp), ("bytes", C.c_size_t)]
 
 
+class ResizeTf1Args(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
+                ("scale_y", C.c_float), ("scale_x", C.c_float), ("sub", C.c_float), ("div", C.c_float), ("x", vp), ("y", vp)]
+
+
+class ConvRectArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int), ("Hout", C.c_int),
+                ("Wout", C.c_int), ("Cout_pad", C.c_int), ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int),
+                ("pad_w", C.c_int), ("relu", C.c_int), ("x", vp), ("x_cs", C.c_int), ("w_packed", vp), ("bias", vp), ("y", vp),
+                ("y_cs", C.c_int), ("y_co", C.c_int)]
+
+
+class Pool2dArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("C", C.c_int), ("Hout", C.c_int),
+                ("Wout", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("mode", C.c_int), ("x", vp),
+                ("x_cs", C.c_int), ("y", vp), ("y_cs", C.c_int), ("y_co", C.c_int)]
+
+
+class FcF32Args(C.Structure):
+    _fields_ = [("rows", C.c_int), ("in_dim", C.c_int), ("out_dim", C.c_int), ("x", vp), ("wt", vp), ("bias", vp), ("y", vp)]
+
+
 # every symbol include/phendiff_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "pd_abi_version": (C.c_int, []),
@@ -319,6 +341,10 @@ SYMBOLS = {
     "pd_diffusion_loss": (C.c_int, [C.POINTER(LossArgs), vp]),
     "pd_grad_norm": (C.c_int, [vp, C.c_int64, vp, C.c_float, vp, vp, vp]),
     "pd_adamw_ema": (C.c_int, [C.POINTER(AdamWEmaArgs), vp]),
+    "pd_resize_tf1": (C.c_int, [C.POINTER(ResizeTf1Args), vp]),
+    "pd_conv_rect": (C.c_int, [C.POINTER(ConvRectArgs), vp]),
+    "pd_pool2d": (C.c_int, [C.POINTER(Pool2dArgs), vp]),
+    "pd_fc_f32": (C.c_int, [C.POINTER(FcF32Args), vp]),
     "pd_graph_begin": (C.c_int, [vp]),
     "pd_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "pd_graph_launch": (C.c_int, [vp, vp]),

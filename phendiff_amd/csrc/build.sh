@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 if [ "$1" = "--clean" ]; then rm -rf "$HERE/build"; rm -f "$OUT" "$OUT.manifest.json"; fi
 mkdir -p "$HERE/build"
 pids=()
-SRCS="conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels vae_kernels sd_bwd_kernels linear_gemm linear_p8 comm_rccl"
+SRCS="conv_igemm attn_d8 small_kernels train_kernels backward_kernels wgrad sd_kernels vae_kernels sd_bwd_kernels linear_gemm linear_p8 metric_kernels comm_rccl"
 for f in $SRCS; do
   X=""
   # attention (forward d = 8, backward d = 64): keep MFMA accumulators in VGPRs (the softmax / its derivative work on them;

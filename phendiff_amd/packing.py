@@ -13,12 +13,12 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cout_pad: int | None =
     2 KiB (fp32) of contiguous memory, already in the A-operand layout of ``v_mfma_f32_32x32x16_bf16``
     (and, with the k order shared by A and B, of the 8 x ``v_mfma_f32_32x32x2_f32`` fp32 form).
     """
-    assert w.ndim == 4 and w.shape[2] == w.shape[3]
-    cout, cin, k, _ = w.shape
+    assert w.ndim == 4
+    cout, cin, kh, kw = w.shape          # rectangular kernels (pd_conv_rect: 1x7, 7x1, 1x3, 3x1): tap = ky * KW + kx
     assert cin % 32 == 0, "input channels must be a multiple of 32"
     cp = cout_pad or cout
     assert cp % 32 == 0 and cp >= cout
-    taps = k * k
+    taps = kh * kw
     wf = torch.zeros((cp, cin, taps), dtype=torch.float32, device=w.device)
     wf[:cout] = w.reshape(cout, cin, taps).float()
     # [ct, r, chunk, s, h, j, tap] -> [ct, chunk, tap, s, h, r, j]
