@@ -355,8 +355,13 @@ def main_train(args, P, world, rank, dev, dist):
             ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS[args.dtype], "TFLOP/s"
         else:
             ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        groups, tnote = _pmc_traffic(prof, "train") if (B, size, args.model) == (112, 128, "super_small") else ({}, "PMC passes exist for the default shape only")
+        traffic = next((e["hbm_bytes_per_launch"] for e in groups.values() if kind in e["kinds"]), None)
+        textra = {"traffic_by_group": {g: {k: e[k] for k in ("kinds", "hbm_bytes_per_launch", "ratio")} for g, e in groups.items()}} if groups else {}
+        if tnote:
+            textra["traffic_note"] = tnote
         res["roofline"] = {"kernel": kind, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": traffic, **textra,
                            "launches_per_step": round(d["launches"]), "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                            "share_of_fwd_bwd": round(d["ms"] / total_ms, 3),
                            "method": "HIP events between consecutive launches of one forward + backward (same plan and buffers)",
@@ -626,6 +631,14 @@ def _timed_steps(args, dev, dist, step, units_per_rank):
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed, ranks = reduce_elapsed(dist, elapsed, dev, units_per_rank)
+    if dist is None and not getattr(args, "no_box", False):
+        # the clock / power the card holds under THIS workload (round 6: the latent-diffusion legs run at the board's power cap too --
+        # LAB_r6 section 1), sampled through a repeat of up to 3 steps after the timed region, never inside it
+        def _again():
+            for _ in range(min(args.steps, 3)):
+                step()
+            torch.cuda.synchronize(dev)
+        ranks = dict(ranks, box=SmiSampler.bracket(_again))
     return elapsed, out, ranks
 
 
@@ -690,7 +703,34 @@ def _in_situ_launch_ms(plan, kind, stream, forwards=72, discard=12):
     return sum(slot_means) / len(slot_means), slot_means, n
 
 
-def _plan_roofline(prof, dtype, method):
+def _pmc_traffic(prof, workload):
+    """HBM bytes per launch-plan op from the committed one-step PMC passes of this workload (profiles/r6_hbm_traffic_<workload>.json,
+    scripts/collect_traffic_step.py), for every kernel group of scripts/kernel_kinds.py; {} when the file is missing or was measured on
+    other kernel sources.  A group covers one or more plan kinds (conv_kernel serves forward convolutions AND input gradients): its
+    measured bytes are set against the summed algorithmic bytes and launches of those kinds."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        from kernel_kinds import GROUP_KINDS
+        from phendiff_amd._lib import source_hash
+        fname = f"r6_hbm_traffic_{workload}.json"
+        j = json.load(open(os.path.join(ROOT, "profiles", fname)))
+    except (OSError, ValueError, ImportError):
+        return {}, f"profiles/r6_hbm_traffic_{workload}.json missing"
+    if j.get("sources_sha256") != source_hash():
+        return {}, f"profiles/{fname} was measured on other kernel sources (re-run scripts/collect_profiles.sh pmc_side)"
+    out = {}
+    for grp, e in j.get("groups", {}).items():
+        kinds = [k for k in GROUP_KINDS.get(grp, []) if k in prof]
+        if not kinds:
+            continue
+        launches = sum(prof[k]["launches"] for k in kinds)
+        alg = sum(prof[k]["bytes"] for k in kinds)
+        out[grp] = {"kinds": kinds, "hbm_bytes_per_step": round(e["hbm_bytes"]), "hbm_bytes_per_launch": round(e["hbm_bytes"] / max(launches, 1)),
+                    "algorithmic_bytes_per_step": round(alg), "ratio": round(e["hbm_bytes"] / alg, 3) if alg > 0 else None, "source": f"profiles/{fname}"}
+    return out, None
+
+
+def _plan_roofline(prof, dtype, method, workload=None):
     total_ms = sum(d["ms"] for d in prof.values())
     kind, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
     mfma = d["flops"] > 0
@@ -698,8 +738,19 @@ def _plan_roofline(prof, dtype, method):
         ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS[dtype], "TFLOP/s"
     else:
         ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+    traffic, tnote, groups = None, None, {}
+    if workload is not None:
+        groups, tnote = _pmc_traffic(prof, workload)
+        for grp, e in groups.items():
+            if kind in e["kinds"]:
+                traffic = e["hbm_bytes_per_launch"]
+                if len(e["kinds"]) > 1:
+                    tnote = f"group {grp} = kinds {e['kinds']} (one kernel template serves them all): bytes per launch averaged over the group"
+    extra = {"traffic_by_group": {g: {k: e[k] for k in ("kinds", "hbm_bytes_per_launch", "ratio")} for g, e in groups.items()}} if groups else {}
+    if tnote:
+        extra["traffic_note"] = tnote
     return {"kernel": kind, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak, "unit": unit,
-            "frac": round(ach / peak, 4), "traffic": None, "launches": round(d["launches"]),
+            "frac": round(ach / peak, 4), "traffic": traffic, **extra, "launches": round(d["launches"]),
             "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4), "share": round(d["ms"] / total_ms, 3), "method": method,
             "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "per_kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["ms"] > 0 and v["flops"] > 0}}
@@ -744,7 +795,7 @@ def main_sd_img2img(args, P, world, rank, dev, dist):
         plan = next(p for k, p in unet._plans.items() if k[0] == B)
         prof = plan._profile_ops(plan.ops, torch.cuda.current_stream(dev).cuda_stream, reps=2)
         res["roofline"] = _plan_roofline(prof, args.dtype, "HIP events between consecutive launches of one SD-UNet forward (same plan "
-                                                           "and buffers as the timed region; 2*S of them per step)")
+                                                           "and buffers as the timed region; 2*S of them per step)", workload="sd_img2img")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_sd_img2img(P, size, S)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
@@ -795,7 +846,7 @@ def main_sd_train(args, P, world, rank, dev, dist):
             for k, d in plan._profile_ops(ops, st, reps=1).items():
                 prof[f"{title}.{k}"] = d
         torch.cuda.synchronize(dev)
-        res["roofline"] = _plan_roofline(prof, args.dtype, "HIP events between consecutive launches of one forward + backward (same plan and buffers)")
+        res["roofline"] = _plan_roofline(prof, args.dtype, "HIP events between consecutive launches of one forward + backward (same plan and buffers)", workload=args.workload)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_sd_train(P, size)
         res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
@@ -860,12 +911,12 @@ def run_side_workloads(budget_s, only=None, headline_cpu_baseline=None):
             continue
         j = json.loads(line)
         roof = j.get("roofline") or {}
-        keep_roof = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "launches_per_step",
+        keep_roof = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_by_group", "traffic_note", "launches", "launches_per_step",
                                            "avg_launch_ms", "share", "share_of_fwd_bwd", "per_kernel_ms", "per_kernel_tflops") if k in roof}
         out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
                      "warmup": j["warmup"], "dtype": j["dtype"], "n_gpus": j["n_gpus"], "workload": j["config"]["workload"],
                      "batch_per_gpu": j["config"].get("batch_per_gpu"), "roofline": keep_roof,
-                     "cpu_baseline": j.get("cpu_baseline"), "gpu_over_cpu": j.get("gpu_over_cpu"),
+                     "cpu_baseline": j.get("cpu_baseline"), "gpu_over_cpu": j.get("gpu_over_cpu"), "box": j.get("box"),
                      "leg_wall_s": round(time.time() - t0, 1)}
     # the latent-diffusion CPU baseline is the fp32 oracle whatever the engine's storage type: timed once (fp16 leg), quoted on both
     a, b = out.get("sd_img2img_fp16", {}), out.get("sd_img2img_bf16", {})
@@ -954,11 +1005,20 @@ def main():
         # PD_BENCH_REHEARSAL=1 (tests/test_gpu_bench_two_ranks.py): N ranks on the ONE GPU of a test box over gloo -- RCCL refuses two
         # ranks per device -- so that the whole N > 1 control flow (barriers, the all_gather of the ranks' clocks, rank 0's line)
         # is exercised before the driver's 8-GPU run.  The line says so (`rehearsal`); never a measurement.
-        if os.environ.get("PD_BENCH_REHEARSAL"):
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            if os.environ.get("PD_BENCH_REHEARSAL"):
+                local_rank = local_rank % max(torch.cuda.device_count(), 1)
+                dist.init_process_group("gloo")
+            else:
+                if os.environ.get("PD_BENCH_FAIL_INIT") == str(rank):          # tests: this rank's process group cannot be formed
+                    raise RuntimeError("PD_BENCH_FAIL_INIT: simulated init_process_group failure")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        except Exception as e:                                   # noqa: BLE001
+            # a rank that cannot join the process group has nothing to time: one line, non-zero exit (the launcher then ends the others);
+            # nothing here re-executes a process that touched the GPU
+            print(f"bench.py: rank {rank}/{world}: init_process_group failed: {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist is not None and not os.environ.get("PD_BENCH_NO_SELFTEST"):

@@ -26,6 +26,8 @@ def main():
     for _ in range(2):
         out = m(x, ts, ehs).sample
     torch.cuda.synchronize()
+    if os.environ.get("PD_PMC_FORWARDS_ONLY"):      # scripts/collect_profiles.sh pmc_side: exactly two forwards under the counters, nothing else
+        return
     n = 5
     t0 = time.perf_counter()
     for _ in range(n):

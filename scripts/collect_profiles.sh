@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end evidence on the GPU box: rocprofv3 kernel-trace summaries + bench lines, copied to gpurun_out/profiles_new/
-# (then committed under profiles/).  The PMC summaries carry the hash of the kernel sources they were measured on; bench.py quotes
+# (then committed under profiles/).  Targets: head | train | sd | pmc_side.  The PMC summaries carry the hash of the kernel sources they were measured on; bench.py quotes
 # them only while that hash matches the tree.  Usage: bash scripts/collect_profiles.sh head|train|sd
 set -e
 cd "$(dirname "$0")/.."
@@ -54,6 +54,24 @@ sd)
   mv $OUT/${R}_sd_img2img_b32_kernel_stats.csv $OUT/${R}_sd_img2img_kernel_stats_b32.csv
   stats sd_train_b32 ${R}_sd_train_bench_under_rocprof_b32.log 12 4 --workload sd_train --steps 8 --warmup 4 --no-roofline --no-cpu-baseline --no-side-workloads
   mv $OUT/${R}_sd_train_b32_kernel_stats.csv $OUT/${R}_sd_train_kernel_stats_b32.csv
+  ;;
+pmc_side)
+  # round 6: HBM traffic of the side workloads -- one step each under --pmc FETCH_SIZE / WRITE_SIZE (separate passes;
+  # the program after `--` is python3 itself), summed per kernel group (scripts/collect_traffic_step.py) -> profiles/${R}_hbm_traffic_<workload>.json
+  for wl in train sd_train sd_img2img; do
+    # train / sd_train: ONE optimisation step (= one pass of the plan's forward + backward ops).  sd_img2img: the roofline leg's unit is one
+    # SD-UNet forward (the trajectory also runs the VAE through the same conv kernels), so the counters run over two bare UNet forwards
+    if [ $wl = sd_img2img ]; then cmd="scripts/bench_sd_unet.py 32"; passes=2; export PD_PMC_FORWARDS_ONLY=1
+    else cmd="bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-side-workloads"; passes=1; unset PD_PMC_FORWARDS_ONLY; fi
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_${wl}_$c -- python3 $cmd > /dev/null 2>$OUT/pmc_${wl}_$c.err
+    done
+    python3 scripts/collect_traffic_step.py $R $wl "$(ls /tmp/pmcs_${wl}_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls /tmp/pmcs_${wl}_WRITE_SIZE/*/*_counter_collection.csv | head -1)" "$cmd" $passes > $OUT/traffic_$wl.txt
+    cp profiles/${R}_hbm_traffic_$wl.json $OUT/
+    cat $OUT/traffic_$wl.txt
+    rm -rf /tmp/pmcs_${wl}_FETCH_SIZE /tmp/pmcs_${wl}_WRITE_SIZE
+  done
+  unset PD_PMC_FORWARDS_ONLY
   ;;
 esac
 ls -la $OUT

@@ -39,3 +39,14 @@ def test_reduce_elapsed_reports_every_rank():
     import bench
     el, info = bench.reduce_elapsed(None, 2.0, "cpu", 64)
     assert el == 2.0 and info == {"rccl_world_size": 1, "per_rank_units_per_s": [32.0]}
+
+
+def test_a_rank_whose_process_group_init_fails_exits_non_zero_with_one_line():
+    """a rank that cannot join the process group prints ONE line and exits 3 (no traceback wall, no hang) -- before
+    anything touched the GPU in that process.  The failure is simulated (PD_BENCH_FAIL_INIT=<rank>); runs on the CPU box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("PD_BENCH_PRINT_LAUNCH", "PD_BENCH_REHEARSAL")}
+    env.update(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", PD_BENCH_FAIL_INIT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py:")]
+    assert r.returncode == 3 and len(lines) == 1 and "rank 1/2" in lines[0] and "init_process_group failed" in lines[0], r.stderr[-1500:]
+    assert "Traceback" not in r.stderr
