@@ -101,8 +101,8 @@ def _synthetic_sets(n, size, seed):
     return make(torch.tensor([0.0, 0.0, 0.0]).view(1, 3, 1, 1)), make(torch.tensor([0.15, -0.1, 0.05]).view(1, 3, 1, 1))
 
 
-# measured on MI355X (profiles/r6_parity_errors.json): features f32 ~2e-6 / bf16 ~1.3e-2 / fp16 ~1.6e-3
-@pytest.mark.parametrize("mode,tol,stol", [("f32", 2e-5, 1e-3), ("bf16", 3e-2, 8e-2), ("fp16", 4e-3, 1e-2)])
+# measured on MI355X (profiles/r6_parity_errors.json): features f32 8.1e-7 / bf16 3.4e-3 / fp16 4.6e-4 -> tolerances ~3x
+@pytest.mark.parametrize("mode,tol,stol", [("f32", 5e-6, 1e-3), ("bf16", 1e-2, 8e-2), ("fp16", 1.5e-3, 1e-2)])
 def test_inception_features_and_the_three_scalars_vs_oracle(mode, tol, stol):
     """64 + 64 synthetic 64 x 64 images through the HIP InceptionV3 (random-init: structure parity) and through the oracle: pool3
     features, un-biased logits, and FID / IS / KID (kid_subset_size 32) as the reference's calculate_metrics call returns them."""
