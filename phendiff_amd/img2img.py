@@ -571,7 +571,8 @@ class SDDDIBGraph:
             ta.timesteps, ta.labels, ta.class_emb = self.ts_rows.data_ptr() + 4 * i * B, None, None
             ta.emb, ta.proj = plan.temb_emb.data_ptr(), plan.temb_table.data_ptr()
             L.check(lib.pd_temb(C.byref(ta), st), "pd_temb")
-            plan.run(self.latents.data_ptr(), plan.temb_table.data_ptr(), self.model_out.data_ptr(), st)
+            # the cross-attention k / v projections only on the first step of a phase (the context is the phase's class): round 6
+            plan.run(self.latents.data_ptr(), plan.temb_table.data_ptr(), self.model_out.data_ptr(), st, context=(i == 0 or i == n_inv))
             L.check(lib.pd_ddim_step(C.byref(a), st), "pd_ddim_step")
             if i == n_inv - 1:
                 self.inverted.copy_(self.latents)

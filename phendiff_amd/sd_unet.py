@@ -401,6 +401,9 @@ class SDUNetPlan(UNetPlan):
         y2 = self._layernorm(h1, e.ln2)
         q2 = lin(y2, e.wq2, zb, ch)
         kv = lin(self.ehs, e.wkv2, zb, 2 * ch)
+        # k / v of the cross attention depend on the class context only -- not on the latents, not on the timestep: a sampling loop
+        # projects them ONCE per context (`run(..., context=False)` skips these ops; 16 launches, 1.6 % of a forward at B = 32) -- round 6
+        self.ops[-1].ctx = not self.train
         a2, lse2 = self._attention(q2.data_ptr(), ch, kv.data_ptr(), kv.data_ptr() + ch * esz, 2 * ch, e.heads, N, self.tokens)
         a2 = a2.view(B, h, w, ch)
         h2 = lin(a2, e.wo2, e.bo2, ch, residual=h1)
@@ -479,17 +482,26 @@ class SDUNetPlan(UNetPlan):
         self._cur = (None, None, None)
 
     def forward(self, sample, ts, ehs, out, stream):
-        """fp32 NCHW latents + (B,) timesteps + (B, tokens, D) encoder_hidden_states -> fp32 NCHW prediction."""
-        self.ehs.view(self.B, self.tokens, -1).copy_(ehs)             # dtype cast (plumbing); stays on the device
+        """fp32 NCHW latents + (B,) timesteps + (B, tokens, D) encoder_hidden_states -> fp32 NCHW prediction.
+        Inference plans keep the cross-attention k / v of the last context: the SAME tensor object, unmodified since (torch's version
+        counter; the plan holds a reference, so the identity cannot be recycled), skips the copy and the 16 context projections --
+        what every step after the first of a sampling loop sees (custom_pipeline_stable_diffusion_img2img.py:667-686 passes one
+        `class_labels_embeds` tensor to all steps)."""
+        wver = getattr(self.w, "version", 0)        # (bumped by the training re-pack: the weights the cached k / v were projected with)
+        fresh = self.train or ehs is not getattr(self, "_ctx_src", None) or (ehs._version, wver) != self._ctx_ver
+        if fresh:
+            self.ehs.view(self.B, self.tokens, -1).copy_(ehs)             # dtype cast (plumbing); stays on the device
+            self._ctx_src, self._ctx_ver = ehs, (ehs._version, wver)
         a = self.temb_args
         a.rows = self.B
         a.timesteps, a.labels, a.class_emb = ts.data_ptr(), None, None
         a.emb, a.proj = self.temb_emb.data_ptr(), self.temb_table.data_ptr()     # emb given: wide projections run split
         L.check(self.lib.pd_temb(C.byref(a), stream), "pd_temb")
-        self.run(sample.data_ptr(), self.temb_table.data_ptr(), out.data_ptr(), stream)
+        self.run(sample.data_ptr(), self.temb_table.data_ptr(), out.data_ptr(), stream, context=fresh)
         self.keepalive = (sample, ts, ehs, out)
 
-    def run(self, x_ptr, temb_ptr, out_ptr, stream):
+    def run(self, x_ptr, temb_ptr, out_ptr, stream, context=True):
+        """``context=False``: the conditioning (``self.ehs``) is what the previous ``run`` saw -- its k / v projections are kept."""
         if self._cur != (x_ptr, temb_ptr, out_ptr):
             self._in_args.x = x_ptr
             self._out_args.y = out_ptr
@@ -498,6 +510,8 @@ class SDUNetPlan(UNetPlan):
             self._cur = (x_ptr, temb_ptr, out_ptr)
         byref, check = C.byref, L.check
         for op in self.ops:
+            if op.ctx and not context:
+                continue
             rc = op.fn(byref(op.args), stream)
             if rc:
                 check(rc, op.what)

@@ -273,6 +273,7 @@ class _SDRepacker:
         self.lib = L.lib()
         self.jobs, self.small, self.pre = [], [], []
         self.jobs_device = m.conv_in.weight.device
+        self.w = w
         code = w.code
 
         def job(dst, src, cout, cin, k, *, dgrad=0, cout_pad=None, cin_pad=None, ct_stride=None, dst_off=0):
@@ -363,6 +364,7 @@ class _SDRepacker:
         with torch.no_grad():
             for f in self.small:
                 f()
+        self.w.version = getattr(self.w, "version", 0) + 1      # inference plans drop what they cached of the old weights (cross-attention k / v)
 
 
 class SDUNetTrainer(UNetTrainer):
