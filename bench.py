@@ -863,7 +863,7 @@ def main_sd_train(args, P, world, rank, dev, dist):
 # Kernel-selecting diagnostic overrides the library reads from the environment (conv_igemm.hip / linear_gemm.hip / attn_d8.hip /
 # unet.py): a bench line measured under one of them says so, and the default (driver) run is expected to carry none.
 DIAG_ENV = ("PD_LIB", "PD_TW_DMA", "PD_ALLOW_ABI_MISMATCH", "PD_BENCH_REHEARSAL", "PD_LIN_DMA", "PD_CONV_NCO", "PD_CONV_PLAIN", "PD_LIN_NC4", "PD_ATTN_NO_GLDS", "PD_ATTN_LDS_PAD", "PD_PREAPPLY_MIN_COUT", "PD_NO_LINEAR_GRADS", "PD_NO_PREAPPLY_WGRAD",
-            "PD_CONV_PRO", "PD_SUBPIXEL_UP", "PD_LIN_FOLD", "PD_LIN_NC5", "PD_LIN_P8", "PD_BENCH_NO_SELFTEST", "PD_ATTN_BWD_FUSED", "PD_GN_FUSED", "PD_BENCH_NATIVE_SELFTEST", "PD_BENCH_SELFTEST_STUB", "PD_BENCH_NATIVE_TIMEOUT_S", "PD_ATTN_WPB4", "PD_ATTN64_QB1", "EXTRA_HIPCC_FLAGS")
+            "PD_CONV_PRO", "PD_SUBPIXEL_UP", "PD_LIN_FOLD", "PD_LIN_NC5", "PD_LIN_P8", "PD_TW_XCD", "PD_CONV_XCD", "PD_ATTN64_BWD_XCD", "PD_BENCH_NO_SELFTEST", "PD_ATTN_BWD_FUSED", "PD_GN_FUSED", "PD_BENCH_NATIVE_SELFTEST", "PD_BENCH_SELFTEST_STUB", "PD_BENCH_NATIVE_TIMEOUT_S", "PD_ATTN_WPB4", "PD_ATTN64_QB1", "EXTRA_HIPCC_FLAGS")
 
 
 def diagnostic_env():

@@ -160,11 +160,19 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
 
   // ---- block -> (pixel tile, co tile, sample) = (x, y, z): the co tiles of one pixel tile are tiles-per-image blocks
   // apart in dispatch order, i.e. on the same XCD / L2 whenever tiles-per-image % 8 == 0 (speed only)
-  const int co_t = blockIdx.y;
-  const int n = blockIdx.z;
+  // co_major (round 6; layers whose weights outweigh their input activations): the work list runs channel tile -> sample -> pixel tile and
+  // every XCD takes a contiguous run of it (xcd_chunk_index), so a channel tile's weights are streamed through ONE L2, not eight
+  int co_t = blockIdx.y, n = blockIdx.z, bx = blockIdx.x;
+  if (p.co_major) {
+    const int gx = gridDim.x, gxz = gridDim.x * gridDim.z;
+    const int idx = xcd_chunk_index((int)pd_lin_block(), gxz * (int)gridDim.y);
+    co_t = idx / gxz;
+    const int rem = idx - co_t * gxz;
+    n = rem / gx; bx = rem - n * gx;
+  }
   int tx, ty;
-  if (p.tiles_x_shift >= 0) { tx = blockIdx.x & (p.tiles_x - 1); ty = blockIdx.x >> p.tiles_x_shift; }
-  else { ty = blockIdx.x / p.tiles_x; tx = blockIdx.x - ty * p.tiles_x; }
+  if (p.tiles_x_shift >= 0) { tx = bx & (p.tiles_x - 1); ty = bx >> p.tiles_x_shift; }
+  else { ty = bx / p.tiles_x; tx = bx - ty * p.tiles_x; }
   PD_STAMP(0);
   const int y0 = ty * TH, x0 = tx * TW;
 
@@ -953,6 +961,17 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   q.n_co_tiles = (p.Cout_pad + 63) / 64;
   if (q.stat_tiles == 0) q.stat_tiles = q.tiles_x * q.tiles_y;                 // ordinary launch: the statistic tiles are this launch's tiles
   else { q.stat_tiles *= q.tiles_x * q.tiles_y; q.stat_tile_base *= q.tiles_x * q.tiles_y; }      // phase launch: (phases, phase index) so far
+  {
+    // channel-tile-major XCD order: OPT-IN (PD_CONV_XCD=1: whenever the grid has >= 64 workgroups; 2: where the weights outweigh the input
+    // activations).  Measured (docs/LAB_r6.md section 9, same box): with rule 2 the latent-diffusion trajectory is 1.1 % SLOWER (9.686 vs
+    // 9.789 images/s) and the fine-tuning step 0.8 % slower -- the weights the XCDs re-read come out of the Infinity Cache cheaply, the
+    // activations every XCD then has to read do not pay for it.  Default: the sample-major order of rounds 1-5.
+    const long long es = (long long)sizeof(T), cin = (long long)p.C0 + p.C1;
+    const long long wbytes = (long long)p.Cout_pad * cin * KS * KS * es, abytes = (long long)p.B * p.Hin * p.Win * cin * es;
+    const long long blocks = (long long)q.tiles_x * q.tiles_y * (q.n_co_tiles / NCO) * p.B;
+    const int env = diag_env("PD_CONV_XCD", 0);
+    q.co_major = blocks >= 64 && blocks < (1ll << 30) && !p.im2col3 && (env == 1 || (env == 2 && wbytes > abytes));
+  }
   hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.n_co_tiles / NCO, p.B), dim3(256), LDS_BYTES, st, q);
   PD_LAUNCH_CHECK();
   return PD_OK;

@@ -216,6 +216,14 @@ template <> struct Elem<half_t> {
   static __device__ __forceinline__ half_t from_f(float v) { return f2h(v); }
 };
 
+// XCD-aware work order (speed only: MI355X_MICROARCH "Workgroup dispatch": blocks b, b + 8, b + 16, ... share an XCD and its 4-MiB L2).  Returns the
+// position in a work list of `total` items such that XCD label b % 8 takes a CONTIGUOUS run of the list -- bijective for any total -- in
+// dispatch order: neighbours in the list (which share operand panels) then run on one L2 instead of on eight.
+__device__ __forceinline__ int xcd_chunk_index(int b, int total) {
+  const int x = b & 7, j = b >> 3, q = total >> 3, r = total & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 // store 4 consecutive output elements
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
   *(f32x4*)p = (f32x4){a, b, c, d};

@@ -30,6 +30,9 @@ struct ConvP {
   int pad_x, out_step, out_oy, out_ox, stat_tile_base, stat_tiles;
   // input-side phase (pd_conv_args.phase_in): source pixel (in_step iy + in_oy, in_step ix + in_ox) of a tensor in_step times as large
   int in_step, in_oy, in_ox;
+  // round 6: 1 = walk the grid output-channel-tile-major with a contiguous run of that list per XCD (weights larger than the input
+  // activations -- the 8^2 / 16^2 levels of the latent-diffusion UNet: every XCD used to stream ALL weights through its L2)
+  int co_major;
 };
 
 }  // namespace pd

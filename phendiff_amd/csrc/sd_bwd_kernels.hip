@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void attn_d64_delta_kernel(const pd_attn_d64_b
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_args a) {
+__global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_args a, const int xcd_order) {
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using X = D64<T>;
@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nqb = (a.Nq + 127) / 128;
-  const int qb = blockIdx.x % nqb, head = (blockIdx.x / nqb) % a.heads, b = blockIdx.x / (nqb * a.heads);
+  // round 6: the query blocks of one (sample, head) stream the SAME K / V: one XCD takes a contiguous run of the block list (the forward
+  // kernel always did; PMC before: 3.4 x the algorithmic bytes left L2).  PD_ATTN64_BWD_XCD=0: diagnostic override (same-box A/B)
+  const int item = xcd_order ? xcd_chunk_index((int)blockIdx.x, nqb * a.heads * a.B) : (int)blockIdx.x;
+  const int qb = item % nqb, head = (item / nqb) % a.heads, b = item / (nqb * a.heads);
   const T* qp = (const T*)a.q + (size_t)b * a.Nq * a.q_stride + head * 64;
   const T* kp = (const T*)a.k + (size_t)b * a.Nkv * a.kv_stride + head * 64;
   const T* vp = (const T*)a.v + (size_t)b * a.Nkv * a.kv_stride + head * 64;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd_args a) {
+__global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd_args a, const int xcd_order) {
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using X = D64<T>;
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nkb = (a.Nkv + 127) / 128;
-  const int kblk = blockIdx.x % nkb, head = (blockIdx.x / nkb) % a.heads, b = blockIdx.x / (nkb * a.heads);
+  const int item = xcd_order ? xcd_chunk_index((int)blockIdx.x, nkb * a.heads * a.B) : (int)blockIdx.x;      // (as the dQ kernel: a head's key blocks share Q / dO)
+  const int kblk = item % nkb, head = (item / nkb) % a.heads, b = item / (nkb * a.heads);
   const T* qp = (const T*)a.q + (size_t)b * a.Nq * a.q_stride + head * 64;
   const T* kp = (const T*)a.k + (size_t)b * a.Nkv * a.kv_stride + head * 64;
   const T* vp = (const T*)a.v + (size_t)b * a.Nkv * a.kv_stride + head * 64;
@@ -457,21 +461,18 @@ static int launch_attn_d64_bwd(const pd_attn_d64_bwd_args* a, hipStream_t st) {
   constexpr int LDS_DQ = 2 * 2 * TB, LDS_DKV = 2 * (2 * TB + 2 * 64 * 4);
   auto kq = attn_d64_dq_kernel<T>;
   auto kkv = attn_d64_dkv_kernel<T>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ) != hipSuccess ||
-        hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV) != hipSuccess) {
-      set_error("pd_attn_d64_bwd: cannot reserve %d / %d bytes of LDS", LDS_DQ, LDS_DKV);
-      return PD_ERR_LAUNCH;
-    }
-    attr_done = true;
+  static LdsAttr attr_q, attr_kv;
+  if (!ensure_lds(attr_q, kq, LDS_DQ) || !ensure_lds(attr_kv, kkv, LDS_DKV)) {
+    set_error("pd_attn_d64_bwd: cannot reserve %d / %d bytes of LDS", LDS_DQ, LDS_DKV);
+    return PD_ERR_LAUNCH;
   }
+  const int xcd_order = diag_env("PD_ATTN64_BWD_XCD", 1) != 0;
   const size_t nd = (size_t)a->B * a->Nq * a->heads * 8;
   hipLaunchKernelGGL(attn_d64_delta_kernel<T>, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, *a);
   PD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kq, dim3(((a->Nq + 127) / 128) * a->heads * a->B), dim3(256), LDS_DQ, st, *a);
+  hipLaunchKernelGGL(kq, dim3(((a->Nq + 127) / 128) * a->heads * a->B), dim3(256), LDS_DQ, st, *a, xcd_order);
   PD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kkv, dim3(((a->Nkv + 127) / 128) * a->heads * a->B), dim3(256), LDS_DKV, st, *a);
+  hipLaunchKernelGGL(kkv, dim3(((a->Nkv + 127) / 128) * a->heads * a->B), dim3(256), LDS_DKV, st, *a, xcd_order);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }

@@ -285,13 +285,10 @@ template <typename T, int QB>
 static int launch_attn_d64(const pd_attn_d64_args* a, hipStream_t st) {
   constexpr int LDS = 2 * 64 * (D64<T>::KP + D64<T>::VP);
   auto kern = attn_d64_kernel<T, QB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      set_error("pd_attn_d64: cannot reserve %d bytes of LDS", LDS);
-      return PD_ERR_LAUNCH;
-    }
-    attr_done = true;
+  static LdsAttr attr;
+  if (!ensure_lds(attr, kern, LDS)) {
+    set_error("pd_attn_d64: cannot reserve %d bytes of LDS", LDS);
+    return PD_ERR_LAUNCH;
   }
   constexpr int QPB = 128 * QB;
   hipLaunchKernelGGL(kern, dim3(((a->Nq + QPB - 1) / QPB) * a->heads * a->B), dim3(256), LDS, st, *a);

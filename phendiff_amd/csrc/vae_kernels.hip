@@ -176,13 +176,10 @@ template <typename T, int D>
 static int launch_attn_wide(const pd_attn_wide_args* a, hipStream_t st) {
   constexpr int LDS = WideCfg<T, D>::LDS;
   auto kern = attn_wide_kernel<T, D>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      set_error("pd_attn_wide: cannot reserve %d bytes of LDS", LDS);
-      return PD_ERR_LAUNCH;
-    }
-    attr_done = true;
+  static LdsAttr attr;
+  if (!ensure_lds(attr, kern, LDS)) {
+    set_error("pd_attn_wide: cannot reserve %d bytes of LDS", LDS);
+    return PD_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(((a->Nq + 31) / 32) * a->heads * a->B), dim3(256), LDS, st, *a);
   PD_LAUNCH_CHECK();
@@ -367,14 +364,10 @@ static int launch_attn_wide_bwd(const pd_attn_wide_bwd_args* a, hipStream_t st) 
   constexpr int LDS = WideCfg<T, D>::LDS + 64 * 4;
   auto kq = attn_wide_bwd_kernel<T, D, false>;
   auto kkv = attn_wide_bwd_kernel<T, D, true>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      set_error("pd_attn_wide_bwd: cannot reserve %d bytes of LDS", LDS);
-      return PD_ERR_LAUNCH;
-    }
-    attr_done = true;
+  static LdsAttr attr_q, attr_kv;
+  if (!ensure_lds(attr_q, kq, LDS) || !ensure_lds(attr_kv, kkv, LDS)) {
+    set_error("pd_attn_wide_bwd: cannot reserve %d bytes of LDS", LDS);
+    return PD_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kq, dim3(((a->Nq + 31) / 32) * a->heads * a->B), dim3(256), LDS, st, *a);
   PD_LAUNCH_CHECK();

@@ -422,13 +422,10 @@ static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
   p.bytesdy = (unsigned)((size_t)a->B * a->Hout * a->Wout * a->Cout * es * (a->phase ? 4 : 1));
   p.x0 = a->x0; p.x1 = a->x1; p.scale = a->scale; p.shift = a->shift; p.dy = a->dy; p.slab = a->slab;
   auto kern = wgrad_kernel<T, KS, STRIDE, TH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES) != hipSuccess) {
-      set_error("pd_conv_wgrad: cannot reserve %d bytes of LDS", Cf::LDS_BYTES);
-      return PD_ERR_LAUNCH;
-    }
-    attr_done = true;
+  static LdsAttr attr;
+  if (!ensure_lds(attr, kern, Cf::LDS_BYTES)) {
+    set_error("pd_conv_wgrad: cannot reserve %d bytes of LDS", Cf::LDS_BYTES);
+    return PD_ERR_LAUNCH;
   }
   const unsigned grid = (unsigned)((p.nwork + 7) / 8 * 8);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cf::LDS_BYTES, st, p);
