@@ -102,8 +102,11 @@ class SmiSampler:
         the reported time is the MAX over ranks).  The card's clock / power are read while it runs the SAME steps again right after
         the timed region (`run_steps()` queues them; the samples are taken while they execute), never while the clock is running."""
         s = cls(period_s=1.0).start()
+        t0 = time.time()
         try:
             run_steps()
+            while time.time() - t0 < 2.5:          # short steps (training): keep the card under the workload until a sample or two exist
+                run_steps()
         finally:
             out = s.stop()
         if "source" in out:
@@ -329,6 +332,12 @@ def main_train(args, P, world, rank, dev, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed, ranks = reduce_elapsed(dist, elapsed, dev, B * args.steps)
+    if dist is None and not args.no_box:      # clock / power under this workload, through a repeat of the steps AFTER the timed region
+        def _again():
+            for _ in range(min(args.steps, 3)):
+                step()
+            torch.cuda.synchronize(dev)
+        ranks = dict(ranks, box=SmiSampler.bracket(_again))
     assert torch.isfinite(loss).all()
     value = world * B * args.steps / elapsed
     res = {
@@ -979,6 +988,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", dest="sweep", action="store_false", help="img2img: skip the B = 16 / 64 side measurements")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-box", action="store_true", help="skip the rocm-smi clock / power samples (they run through a REPEAT of the timed steps "
+                    "after the timed region: profiled runs that count batches or bytes per step must not see those extra steps)")
     ap.add_argument("--no-side-workloads", dest="side_workloads", action="store_false",
                     help="img2img on 1 GPU: skip the short legs of configs[1] (train), configs[3] (sd_train) and configs[4] (sd_img2img, "
                          "fp16 and bf16) that are attached to the line as `side_workloads`")
@@ -1083,7 +1094,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed, ranks = reduce_elapsed(dist, elapsed, dev, B * args.steps)
     box = None
-    if rank == 0 and world == 1:          # (one-GPU runs only: at N > 1 rank 0 would keep the other ranks waiting at the next barrier)
+    if rank == 0 and world == 1 and not args.no_box:          # (one-GPU runs only: at N > 1 rank 0 would keep the other ranks waiting at the next barrier)
         def _again():
             for _ in range(min(args.steps, 3)):
                 one_batch()
@@ -1171,7 +1182,7 @@ def main():
         same_workload = B == 32 and args.dtype == "bf16" and size == 256 and args.model == "super_small"
         for stem, field in (("hbm_traffic.json", "traffic"), ("mfma_busy.json", "pipes")):
             j = None
-            for rnd in ("r5", "r4", "r3"):          # the newest collection whose file exists (the source hash decides whether it is quoted)
+            for rnd in ("r6", "r5", "r4", "r3"):    # the newest collection whose file exists (the source hash decides whether it is quoted)
                 fname = f"{rnd}_{stem}"
                 try:
                     j = json.load(open(os.path.join(ROOT, "profiles", fname)))
@@ -1179,7 +1190,7 @@ def main():
                 except (OSError, ValueError):
                     continue
             if j is None:
-                pmc_note = f"profiles/r5_{stem} missing"
+                pmc_note = f"profiles/r6_{stem} missing"
                 continue
             if j.get("sources_sha256") != source_hash():
                 pmc_note = f"profiles/{fname} was measured on other kernel sources (re-run scripts/collect_profiles.sh head)"

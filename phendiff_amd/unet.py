@@ -914,7 +914,10 @@ class UNetPlan:
             e = C.c_void_p()
             L.check(lib.pd_event_create(C.byref(e)), "pd_event_create")
             evs.append(e)
-        acc = {}
+        # per launch the MEDIAN over the passes (round 6: a mean let one multi-millisecond hiccup of the box -- another process's burst, a clock
+        # ramp -- triple a kind's figure on the driver's line); at least three passes
+        reps = max(int(reps), 3)
+        per_op = [[] for _ in ops]
         for _ in range(reps):
             for i, op in enumerate(ops):
                 L.check(lib.pd_event_record(evs[i], stream), "pd_event_record")
@@ -923,11 +926,14 @@ class UNetPlan:
             ms = C.c_float()
             for i, op in enumerate(ops):
                 L.check(lib.pd_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)), "pd_event_elapsed_ms")
-                d = acc.setdefault(op.what, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
-                d["ms"] += ms.value / reps
-                d["launches"] += 1.0 / reps
-                d["flops"] += op.flops / reps
-                d["bytes"] += op.bytes / reps
+                per_op[i].append(ms.value)
+        acc = {}
+        for op, samples in zip(ops, per_op):
+            d = acc.setdefault(op.what, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            d["ms"] += sorted(samples)[len(samples) // 2]
+            d["launches"] += 1.0
+            d["flops"] += op.flops
+            d["bytes"] += op.bytes
         for e in evs:
             lib.pd_event_destroy(e)
         return acc

@@ -14,7 +14,7 @@ mkdir -p $OUT
 stats() {   # <tag> <log name> <batches> <discard> -- bench args (whose --warmup + --steps == batches)
   local tag=$1 log=$2 batches=$3 discard=$4; shift 4
   local d=/tmp/prof_$tag
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py "$@" > $OUT/$log 2>$OUT/$log.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py "$@" --no-box > $OUT/$log 2>$OUT/$log.err
   cp "$(ls $d/*/*_kernel_stats.csv | head -1)" $OUT/${R}_${tag}_kernel_stats_whole_run.csv
   python3 scripts/steady_stats.py "$(ls $d/*/*_kernel_trace.csv | head -1)" $batches $discard $OUT/${R}_${tag}_kernel_stats.csv 2> $OUT/${R}_${tag}_kernel_stats.note
   cat $OUT/${R}_${tag}_kernel_stats.note
@@ -26,11 +26,11 @@ head)
   stats b32 ${R}_bench_under_rocprof_b32.log ${HEAD_BATCHES:-4} ${HEAD_DISCARD:-2} --steps $(( ${HEAD_BATCHES:-4} - ${HEAD_DISCARD:-2} )) --warmup ${HEAD_DISCARD:-2} --batch 32 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads
   for x in kernel_stats.csv kernel_stats_whole_run.csv kernel_stats.note; do mv $OUT/${R}_b32_$x $OUT/${R}_kernel_stats_b32${x#kernel_stats}; done
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads > /dev/null 2>$OUT/pmc_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads --no-box > /dev/null 2>$OUT/pmc_$c.err
   done
   python3 scripts/collect_traffic.py $R "$(ls /tmp/pmc_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls /tmp/pmc_WRITE_SIZE/*/*_counter_collection.csv | head -1)" > $OUT/traffic.txt
   cp profiles/${R}_hbm_traffic.json $OUT/
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_busy -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads > /dev/null 2>$OUT/pmc_busy.err
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_busy -- python3 bench.py --steps 1 --warmup 0 --batch 32 --inference-steps 2 --no-cpu-baseline --no-roofline --no-sweep --no-side-workloads --no-box > /dev/null 2>$OUT/pmc_busy.err
   python3 scripts/collect_mfma_busy.py $R "$(ls /tmp/pmc_busy/*/*_counter_collection.csv | head -1)" > $OUT/mfma_busy.txt
   cp profiles/${R}_mfma_busy.json $OUT/
   # the default line last: it quotes the two PMC summaries just written (same kernel sources by construction)
@@ -62,7 +62,7 @@ pmc_side)
     # train / sd_train: ONE optimisation step (= one pass of the plan's forward + backward ops).  sd_img2img: the roofline leg's unit is one
     # SD-UNet forward (the trajectory also runs the VAE through the same conv kernels), so the counters run over two bare UNet forwards
     if [ $wl = sd_img2img ]; then cmd="scripts/bench_sd_unet.py 32"; passes=2; export PD_PMC_FORWARDS_ONLY=1
-    else cmd="bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-side-workloads"; passes=1; unset PD_PMC_FORWARDS_ONLY; fi
+    else cmd="bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-side-workloads --no-box"; passes=1; unset PD_PMC_FORWARDS_ONLY; fi
     for c in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_${wl}_$c -- python3 $cmd > /dev/null 2>$OUT/pmc_${wl}_$c.err
     done
