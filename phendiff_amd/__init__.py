@@ -24,3 +24,4 @@ from .sd_unet import SDUNet2DConditionModel, CustomEmbedding, class_emb_to_encod
 from .vae import AutoencoderKL, VaeImageProcessor, DiagonalGaussianDistribution, SD_VAE_CONFIG  # noqa: F401
 from .sd_pipeline import CustomStableDiffusionImg2ImgPipeline, hack_class_embedding  # noqa: F401
 from .sd_unet_train import SDUNetTrainer, SDUNetTrainPlan, sd_training_param_order  # noqa: F401
+from . import metrics  # noqa: F401,E402  (FID / IS / KID: InceptionV3Features, calculate_metrics, class_metrics_hook)

@@ -105,15 +105,26 @@ def _bcast_worker(rank, world, port, out):
 
 def test_rank0_parameter_broadcast_at_wrap_time():
     import torch.multiprocessing as mp
+    import queue
     ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = dict((r, (a, b)) for r, a, b in (out.get(timeout=120) for _ in range(2)))
-    for p in procs:
-        p.join(60); assert p.exitcode == 0
+    for attempt in range(3):          # (the free port is probed, released, then bound by rank 0: another process can take it in between -- retry on a new one)
+        out = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            got = dict((r, (a, b)) for r, a, b in (out.get(timeout=120) for _ in range(2)))
+        except queue.Empty:
+            got = None
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+        if got is not None and all(p.exitcode == 0 for p in procs):
+            break
+    else:
+        raise AssertionError("two-rank gloo rendezvous failed three times")
     assert not torch.equal(got[0][0], got[1][0])                       # they did start apart
     assert torch.equal(got[0][1], got[0][0]) and torch.equal(got[1][1], got[0][0])
     x = torch.ones(3)
