@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The CPU oracle (plain torch on the host cores) is most of the GPU suite's wall time.  A GPU box shows every core of the host (256) but
+    gives a job the share of ONE GPU (16): torch's default of 128 intra-op threads on 16 cores made the oracle 2-6 x slower and the suite's
+    time box-dependent (590-720 s).  Cap the pool at the share; child processes inherit the cap through OMP_NUM_THREADS."""
+    try:
+        import torch
+        n = max(1, min(16, len(os.sched_getaffinity(0))))
+        torch.set_num_threads(n)
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, n // 2)))
+    except Exception:      # noqa: BLE001
+        pass
+
+
 def pytest_collection_modifyitems(config, items):
     """A box without an MI355X skips the gpu-marked tests even when they are not deselected with -m "not gpu"."""
     import torch
