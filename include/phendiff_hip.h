@@ -33,7 +33,7 @@ extern "C" {
  * fold_ws_bytes + pd_linear_fold_workspace,
  * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_attn_bwd_args.slab / slab_bytes +
  * pd_attn_d8_bwd_workspace (the one-pass backward); 7 = round 6: pd_gn_bwd_args.mod / mod_stride / dmod (scale_shift ResNet blocks train);
- * pd_resize_tf1, pd_conv_rect, pd_pool2d, pd_fc_f32 (the evaluation metrics' feature extractor). */
+ * pd_resize_tf1, pd_conv_rect, pd_pool2d, pd_fc_f32 (the evaluation metrics' feature extractor); pd_pack_weight_args.dst2 / dst2_ct_stride. */
 #define PD_ABI_VERSION 7
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
@@ -400,6 +400,11 @@ typedef struct {
   int dtype;
   int cout, cin, cout_pad, cin_pad, ksize, src_in, dgrad;
   const float* src; void* dst; long long dst_ct_stride;
+  /* (ABI 7) optional, dgrad = 0 only: the SAME source blocks also written as the input-gradient packing -- what a second call with
+   * dgrad = 1, cout / cin (and their pads) swapped and dst = dst2 would write -- from one read of the fp32 master weights
+   * (an optimizer step re-packs every weight both ways: half the re-pack's HBM reads).  dst2_ct_stride: elements between
+   * consecutive 32-row (input-channel) tiles of dst2, >= (cout_pad/32) * ksize^2 * 1024. */
+  void* dst2; long long dst2_ct_stride;
 } pd_pack_weight_args;
 int pd_pack_weight(const pd_pack_weight_args* a, void* stream);
 

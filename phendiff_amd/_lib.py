@@ -126,7 +126,7 @@ class WgradArgs(C.Structure):
 class PackWeightArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("cout", C.c_int), ("cin", C.c_int), ("cout_pad", C.c_int), ("cin_pad", C.c_int),
                 ("ksize", C.c_int), ("src_in", C.c_int), ("dgrad", C.c_int), ("src", vp), ("dst", vp),
-                ("dst_ct_stride", C.c_longlong)]
+                ("dst_ct_stride", C.c_longlong), ("dst2", vp), ("dst2_ct_stride", C.c_longlong)]
 
 
 class PackWeightBatchArgs(C.Structure):

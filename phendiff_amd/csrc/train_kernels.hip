@@ -49,7 +49,25 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* partia
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, int64_t n, double* partial) {
   __shared__ double sm[4];
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = x[i]; acc += v * v; }
+  if ((((size_t)x) & 15) == 0) {
+    // round 6: 16-byte loads, two in flight per lane (the 4-byte form ran the 3.46-GB gradient of the SD-2.1 UNet at 2.3 TB/s: 1.5 ms per step);
+    // fixed summation order (deterministic), squares and sums in fp64 as before
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+      const f32x4 a = ((const f32x4*)x)[i], b = ((const f32x4*)x)[i + stride];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const double va = a[j], vb = b[j]; acc += va * va; acc += vb * vb; }
+    }
+    if (i < n4) {
+      const f32x4 a = ((const f32x4*)x)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const double va = a[j]; acc += va * va; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const double v = x[(n4 << 2) + threadIdx.x]; acc += v * v; }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = x[i]; acc += v * v; }
+  }
   const double t = block_sum(acc, sm);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }

@@ -359,6 +359,22 @@ __device__ __forceinline__ void pack_weight_block(const pd_pack_weight_args& a, 
     T* dst = (T*)a.dst + (size_t)ct * a.dst_ct_stride + ((((size_t)chunk * taps + tap) * 2 + sidx) * 64 + lane) * 8;
     Elem<T>::store(dst, Elem<T>::pack(v));
   }
+  if (!a.dgrad && a.dst2) {
+    // round 6: the input-gradient packing of the same 32 x 32 source block (its tile (ci chunk) x chunk (co tile) transposed, taps flipped)
+    // from the LDS tile already loaded: the separate dgrad job read every master weight a second time
+    for (int f = tid; f < taps * 2 * 64; f += 256) {
+      const int lane = f & 63, sidx = (f >> 6) & 1, tap = f >> 7;
+      const int r = lane & 31, h = lane >> 5;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cl = sidx * 16 + h * 8 + j;            // co within this block = the dgrad matrix's k index; its row = ci = r
+        v[j] = tile[cl * pitch + r * taps + (taps - 1 - tap)];
+      }
+      T* dst = (T*)a.dst2 + (size_t)chunk * a.dst2_ct_stride + ((((size_t)ct * taps + tap) * 2 + sidx) * 64 + lane) * 8;
+      Elem<T>::store(dst, Elem<T>::pack(v));
+    }
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const pd_pack_weight_args a) {
@@ -533,6 +549,8 @@ extern "C" int pd_pack_weight(const pd_pack_weight_args* a, void* stream) {
            "pd_pack_weight: padded sizes must be multiples of 32 (cout %d/%d, cin %d/%d)", a->cout, a->cout_pad, a->cin, a->cin_pad);
   const size_t per_ct = (size_t)(a->cin_pad / 32) * a->ksize * a->ksize * 2 * 64 * 8;
   PD_CHECK((size_t)a->dst_ct_stride >= per_ct, PD_ERR_ARG, "pd_pack_weight: dst_ct_stride too small");
+  PD_CHECK(a->dst2 == nullptr || (a->dgrad == 0 && (size_t)a->dst2_ct_stride >= (size_t)(a->cout_pad / 32) * a->ksize * a->ksize * 2 * 64 * 8), PD_ERR_ARG,
+           "pd_pack_weight: dst2 needs dgrad = 0 and dst2_ct_stride >= (cout_pad/32) * ksize^2 * 1024");
   const unsigned grid = (unsigned)((a->cout_pad / 32) * (a->cin_pad / 32));
   const size_t lds = (size_t)32 * (32 * a->ksize * a->ksize + 1) * sizeof(float);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);

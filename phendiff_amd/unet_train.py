@@ -727,6 +727,29 @@ def plan_grad_buckets(sizes: List[int], ready: List[int], bucket_elems: int) -> 
     return sorted(out, key=lambda b: b[2])
 
 
+def fuse_pack_jobs(jobs):
+    """A weight is re-packed twice after every optimizer step -- the forward layout and the input-gradient layout (transposed, taps
+    flipped) -- from the same fp32 master tensor.  Pairs whose 32 x 32 blocks coincide become ONE job with ``dst2`` (ABI 7): the master
+    weights are read once (the re-pack of the SD-2.1 UNet: 6.9 -> 3.5 GB of reads per step).  Jobs without a partner stay as they are."""
+    if os.environ.get("PD_PACK_FUSE", "1") == "0":      # diagnostic override (same-box A/B)
+        return list(jobs)
+    fwd = {}
+    for a in jobs:
+        if not a.dgrad and not a.dst2:
+            fwd.setdefault((a.src, a.ksize, a.cout, a.cin, a.cout_pad, a.cin_pad, a.src_in), []).append(a)
+    out, used = [], set()
+    for a in jobs:
+        if a.dgrad:
+            cands = fwd.get((a.src, a.ksize, a.cin, a.cout, a.cin_pad, a.cout_pad, a.src_in), [])
+            partner = next((f for f in cands if id(f) not in used), None)
+            if partner is not None:
+                used.add(id(partner))
+                partner.dst2, partner.dst2_ct_stride = a.dst, a.dst_ct_stride
+                continue
+        out.append(a)
+    return out
+
+
 def run_pack_jobs(lib, jobs, stream, cache, device):
     """All ``pd_pack_weight`` jobs of an optimizer step as ONE ``pd_pack_weight_batch`` launch: the descriptors are uploaded
     once (``cache``: a dict owned by the re-packer) next to the block-range table the kernel searches."""
@@ -734,6 +757,7 @@ def run_pack_jobs(lib, jobs, stream, cache, device):
         return
     st = cache.get("batch")
     if st is None:
+        jobs = fuse_pack_jobs(jobs)
         for a in jobs:     # what pd_pack_weight would refuse
             if a.cout_pad % 32 or a.cin_pad % 32 or a.cout_pad < a.cout or a.cin_pad < a.cin or a.dtype != jobs[0].dtype:
                 raise L.PhenDiffHipError("pd_pack_weight_batch: inconsistent job descriptors")

@@ -31,8 +31,8 @@ def _pair(mode):
 
 
 # f32: three optimisation steps (weights agree to ~2e-5) + 4 sampling steps, guidance w = 2 amplifies the difference ~2x
-# (round 6: the bf16 engine runs the guided case only -- the GPU suite's wall time is mostly the CPU oracle's)
-@pytest.mark.parametrize("mode,tol,w", [("f32", 6e-4, None), ("f32", 6e-4, 2.0), ("bf16", 4e-2, 2.0)])
+@pytest.mark.parametrize("mode,tol", [("f32", 6e-4), ("bf16", 4e-2)])
+@pytest.mark.parametrize("w", [None, 2.0])
 def test_ema_generation_matches_oracle_and_restores_training_weights(mode, tol, w):
     import phendiff_amd as P
     from phendiff_amd.eval_generation import generate_samples
