@@ -1250,8 +1250,8 @@ def main():
                                      "(same operands and buffers as the captured graph), one event pair per forward around one launch of "
                                      "this kernel, rotating over its launches, first 12 of 72 forwards discarded; it must fall inside "
                                      "avg_launch_ms_implied_by_forward = (ms_per_step / 2S - event-fenced sum of the other kinds [x0.9..1]) "
-                                     "/ launches, else frac is withheld; profiles/r5_kernel_stats_b32.csv (rocprofv3 --kernel-trace of "
-                                     "the graph replay, first 2 of 6 batches discarded) holds the same figure. avg_launch_ms_isolated: the "
+                                     "/ launches, else frac is withheld; profiles/r6_kernel_stats_b32.csv (rocprofv3 --kernel-trace of "
+                                     "the graph replay, first 2 of 4 batches discarded) holds the same figure. avg_launch_ms_isolated: the "
                                      "kernel's launches of one forward back to back between one event pair, 5 reps (boost clock; NOT what "
                                      "the workload sees). per_kernel_* and avg_launch_ms_event_fenced: one event between every two "
                                      "launches of an eager replay, 3 reps (each interval carries the event's fence)",
