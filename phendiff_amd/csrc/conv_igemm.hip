@@ -31,6 +31,17 @@
 #endif
 // 16-bit 3x3 stride-1 double-buffered variants multiply with v_mfma_f32_16x16x32 instead of 32x32x16 (see M16 in conv_kernel).
 // -DPD_CONV_M16=0 builds the 32x32x16 form everywhere (same-box A/B).
+// Round 6: depth of the weight-fragment register ring of the 8-wide 3x3 tiles (<= 128 pixels, 16-bit engines; 0: the general 3); must divide 18.
+// A 64-pixel tile has ONE 32-cycle MFMA per k-step and wave, so the general ring fetched a weight fragment 64 matrix cycles before its use -- far less
+// than an L2 round trip, let alone the HBM trip of the trajectory where 1.7 GB of weights pass between two uses of a layer.  Five k-steps ahead
+// (24 registers of 94): 1 280 -> 1 280 @8x8 with cold weights 117 -> 94 us, 2 560 -> 1 280 227 -> 170 us; same box, whole workloads: SD img2img
+// +1.9 %, SD fine-tuning +0.6 % (profiles/r6_ab_conv8_ring_*.log).  9 / 18 deep: no further gain.
+#ifndef PD_CONV_AR8
+#define PD_CONV_AR8 6
+#endif
+#ifndef PD_CONV_AR8_64   // ... of the 64-pixel tile (8 x 8 images)
+#define PD_CONV_AR8_64 PD_CONV_AR8
+#endif
 #ifndef PD_CONV_M16
 #define PD_CONV_M16 1
 #endif
@@ -117,18 +128,25 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 // PLAIN (compile time): no GroupNorm / SiLU prologue -- the input gradients of every convolution, the latent-diffusion UNet's convolutions
 // (its GroupNorms are applied by pd_gn_apply), the upsamplers.  The 16 scale / shift registers and the transform are gone, which is what lets
 // the 16x16x32 MFMA form (M16 below) fit the register budgets.
-template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1, bool PLAIN = false, int PRO = 0>
+template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1, bool PLAIN = false, int PRO = 0, bool STACK = false>
 __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2))) void conv_kernel(const ConvP p) {
   static_assert(PRO == 0 || (!PLAIN && DB && KS == 3 && STRIDE == 1 && sizeof(T) == 2), "compile-time prologue: 16-bit 3x3 stride-1 double-buffered launches");   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
   static_assert(NCO == 1 || (NCO == 2 && DB && KS == 3 && STRIDE == 1), "two output tiles per workgroup: 3x3 stride-1 double-buffered variant only");
+  // STACK (round 6): the tile is TH / 8 whole 8 x 8 IMAGES (samples n, n + 1, ...) stacked vertically, each with its own zero halo rows in LDS --
+  // an 8 x 8 level has 64 pixels per sample, and a 64-pixel tile streams a 32 co x 16 k weight fragment per MFMA; two images per tile halve
+  // that and the barriers per MFMA.  NHWC output of 8 x 8 images is contiguous over samples, so tile row R = 8 j + y of sample n + j lies at
+  // row R of sample n.  Per-sample operands: temb (a wave's fragments belong to ONE sample: n + wp), statistics (one reduction per sample);
+  // no GroupNorm prologue (dispatch).
+  static_assert(!STACK || (KS == 3 && STRIDE == 1 && TW == 8 && TH == 16 && NCO == 1 && !PLAIN && PRO == 0), "stacked 8 x 8 images: the 16 x 8 tile");
+  constexpr int SG = STACK ? TH / 8 : 1;   // images per tile
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using SR = typename Stage<T>::R;
   constexpr int TP = TH * TW;              // pixels per workgroup tile
   constexpr int NF = TP / 64;              // 32-pixel fragments per wave
   constexpr int RPF = 32 / TW;             // tile rows per fragment (TW == 32 -> 1)
-  constexpr int IN_TH = (TH - 1) * STRIDE + KS;
+  constexpr int IN_TH = STACK ? SG * 10 : (TH - 1) * STRIDE + KS;
   constexpr int IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int NPIX = IN_TH * IN_TW;
   // double-buffered variants interleave the two buffers per pixel -- [chunk c: 32 ch | chunk c+1: 32 ch | 16 B pad] -- so both
@@ -162,8 +180,8 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   // apart in dispatch order, i.e. on the same XCD / L2 whenever tiles-per-image % 8 == 0 (speed only)
   // co_major (round 6; layers whose weights outweigh their input activations): the work list runs channel tile -> sample -> pixel tile and
   // every XCD takes a contiguous run of it (xcd_chunk_index), so a channel tile's weights are streamed through ONE L2, not eight
-  int co_t = blockIdx.y, n = blockIdx.z, bx = blockIdx.x;
-  if (p.co_major) {
+  int co_t = blockIdx.y, n = blockIdx.z * SG, bx = blockIdx.x;
+  if (!STACK && p.co_major) {
     const int gx = gridDim.x, gxz = gridDim.x * gridDim.z;
     const int idx = xcd_chunk_index((int)pd_lin_block(), gxz * (int)gridDim.y);
     co_t = idx / gxz;
@@ -210,14 +228,15 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   for (int i = 0; i < NIT; ++i) {
     const int pix = (tid + 256 * i) >> 2;
     const int u = pix / IN_TW, vv = pix - u * IN_TW;
-    const int iy = iy_base + u, ix = ix_base + vv;
-    const bool ok = (pix < NPIX) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc)
+    const int sj = STACK ? u / 10 : 0, su = u - sj * 10;         // STACK: image within the tile, row within its 10-row halo block
+    const int iy = STACK ? su - 1 : iy_base + u, ix = ix_base + vv;
+    const bool ok = (pix < NPIX) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc) & (!STACK || n + sj < p.B)
                     & (((iy & ph_mask) == (ph_want & ph_mask)) & ((ix & ph_mask) == (ph_want & ph_mask)));
-    int v = (n_base + (iy >> ups) * istep) * Ws + (ix >> ups) * istep + p.in_ox;
+    int v = STACK ? ((n + sj) * 8 + iy) * 8 + ix : (n_base + (iy >> ups) * istep) * Ws + (ix >> ups) * istep + p.in_ox;
     // fused 1x1 tail: its chunks multiply the CENTRE tap only, so they need the tile's own pixels, not the halo ring around them
     // (a third more pixels: 10 x 34 against 8 x 32) -- bit 30 marks the pixels a tail chunk loads (an index is < 2^26: the tensors
     // are < 2 GiB at >= 64 bytes per pixel)
-    if (TAIL) v |= (((unsigned)(u - KS / 2) < (unsigned)TH) & ((unsigned)(vv - KS / 2) < (unsigned)TW)) ? TAIL_CENTRE : 0;
+    if (TAIL) v |= (((unsigned)((STACK ? su : u) - KS / 2) < (unsigned)(STACK ? 8 : TH)) & ((unsigned)(vv - KS / 2) < (unsigned)TW)) ? TAIL_CENTRE : 0;
     spix[i] = ok ? v : -1;
   }
   const bool affine = PRO || (!PLAIN && p.scale != nullptr);
@@ -340,7 +359,8 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
       rbase[f] = f == 0 ? ((wp * NF * RPF) * IN_TW + li) * PITCH + lg * 8 * E::BYTES : 0;
     } else {
       const int py = fi * RPF + r / TW, px = r % TW;
-      rbase[f] = ((py * STRIDE) * IN_TW + px * STRIDE) * PITCH + h * 8 * E::BYTES;
+      const int ly = STACK ? py + 2 * (py >> 3) : py * STRIDE;      // STACK: two halo rows between images
+      rbase[f] = (ly * IN_TW + px * STRIDE) * PITCH + h * 8 * E::BYTES;
     }
   }
 
@@ -363,7 +383,8 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   // load) is covered by AD x 4 MFMAs.  The ring index is static because AR divides KSTEPS.  The MFMA loop is kept
   // free of branches (prefetch index clamped, not guarded; have_next / wave_active are compile-time) so that it stays
   // ONE scheduling region with counted waits.
-  constexpr int AR = (KSTEPS % 3 == 0) ? 3 : 2;
+  constexpr int AR = (KS == 3 && TW == 8 && STRIDE == 1 && sizeof(T) == 2 && TP <= 128 && PD_CONV_AR8 > 0) ? (TP == 64 ? PD_CONV_AR8_64 : PD_CONV_AR8) : ((KSTEPS % 3 == 0) ? 3 : 2);
+  static_assert(KSTEPS % AR == 0, "the ring index is static");
   constexpr int AD = AR - 1;
   Frag aring[AR][NCO];
   // M16: the two 16 co x 32 k operands of a tap, ring of two taps (tap t in entry t & 1, tap t + 1 prefetched at the start of tap t;
@@ -637,15 +658,16 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
     }
   } else
   if (wave_active) {
+    const int nt = STACK ? min(n + wp, p.B - 1) : n;     // STACK: this wave's fragments are the two halves of image n + wp (static_assert: two images)
     const __amdgpu_buffer_rsrc_t rtemb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.temb ? p.temb : p.bias), 0,
-        p.temb ? ((unsigned)n * (unsigned)p.temb_stride + (unsigned)p.Cout) * 4u : 0u, 0x00020000);   // up to the end of row n's slice
+        p.temb ? ((unsigned)nt * (unsigned)p.temb_stride + (unsigned)p.Cout) * 4u : 0u, 0x00020000);   // up to the end of row n's slice
 #pragma unroll
     for (int c = 0; c < NCO; ++c)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int co = (ct32 + 2 * c) * 32 + 8 * g + 4 * h;
         bt[c][g] = *(const f32x4*)(p.bias + co);
-        tv[c][g] = __builtin_amdgcn_raw_buffer_load_b128(rtemb, (unsigned)(n * p.temb_stride + co) * 4u, 0, 0);
+        tv[c][g] = __builtin_amdgcn_raw_buffer_load_b128(rtemb, (unsigned)(nt * p.temb_stride + co) * 4u, 0, 0);
       }
   }
   if (!p.im2col3) issue_loads(0);      // everything below overlaps the HBM latency of chunk 0
@@ -818,6 +840,8 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
     const int oy = y0 + py0 + dpy, ox = x0 + px0 + dpx;
     const unsigned off = (unsigned)((n * HF + (y0 + py0) * os + p.out_oy) * WF + (x0 + px0) * os + p.out_ox) * (unsigned)(p.Cout * E::BYTES)
                          + (unsigned)co * E::BYTES + (unsigned)dpy * row_bytes + (unsigned)dpx * px_bytes;
+    // STACK: tile row 8 j + y is row y of sample n + j, and the 8 x 8 NHWC images are contiguous over samples: the same offset formula
+    if constexpr (STACK) return (n + ((py0 + dpy) >> 3) < p.B && co < p.Cout) ? off : OOB_OFF;
     return (oy < p.Hout && ox < p.Wout && co < p.Cout) ? off : OOB_OFF;
   };
   if (!DB) __syncthreads();                 // DB: the chunk loop already ended on a barrier
@@ -852,9 +876,12 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
     }
   }
   __syncthreads();
-  float ssum[EPC], ssq[EPC];                   // GroupNorm statistics of what is stored (consumer's norm input)
+  float ssum[SG][EPC], ssq[SG][EPC];           // GroupNorm statistics of what is stored (consumer's norm input); STACK: per image of the tile
 #pragma unroll
-  for (int j = 0; j < EPC; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  for (int g = 0; g < SG; ++g)
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) { ssum[g][j] = 0.f; ssq[g][j] = 0.f; }
+  static_assert(!STACK || (NEP % SG == 0 && (NEP / SG) * PXI == 64), "a thread's pieces of one image are consecutive iterations");
   if (p.out_mode == PD_OUT_NHWC) {
 #pragma unroll
     for (int it = 0; it < NEP; ++it) {
@@ -876,17 +903,18 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
       }
       __builtin_amdgcn_raw_buffer_store_b128(v, ry, off, 0, 0);
       if (p.stats) {                           // kernel-uniform
+        const int sg = STACK ? it / (NEP / SG) : 0;     // (compile-time: the loop is unrolled)
         if (off == OOB_OFF) v = (u32x4)(0u);   // pixels beyond the image / padded channels do not count
         if constexpr (E::BYTES == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float lo, hi;
             Pack16<T>::unpack(v[j], lo, hi);
-            ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
+            ssum[sg][2 * j] += lo; ssq[sg][2 * j] += lo * lo; ssum[sg][2 * j + 1] += hi; ssq[sg][2 * j + 1] += hi * hi;
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const float x = __uint_as_float(v[j]); ssum[j] += x; ssq[j] += x * x; }
+          for (int j = 0; j < 4; ++j) { const float x = __uint_as_float(v[j]); ssum[sg][j] += x; ssq[sg][j] += x * x; }
         }
       }
     }
@@ -909,23 +937,27 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
     // order (deterministic, conflict-free: for one prow the 128 readers cover 512 contiguous bytes)
     float* red = (float*)(lds + TP * EP_PITCH);
 #pragma unroll
-    for (int q = 0; q < 2 * EPC / 4; ++q) {
-      f32x4 v4;
+    for (int sg = 0; sg < SG; ++sg) {            // STACK: one reduction per image of the tile (sample n + sg)
+      if (sg > 0) __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int e = q * 4 + j; v4[j] = e < EPC ? ssum[e] : ssq[e - EPC]; }
-      *(f32x4*)(red + tid * (2 * EPC) + q * 4) = v4;
-    }
-    __syncthreads();
-    if (tid < 128) {
-      const int c = tid >> 1, which = tid & 1;
-      const int pc = c / EPC, j = c % EPC;
-      const int cog = co_tile * 64 + c;
-      float tot = 0.f;
+      for (int q = 0; q < 2 * EPC / 4; ++q) {
+        f32x4 v4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int e = q * 4 + j; v4[j] = e < EPC ? ssum[sg][e] : ssq[sg][e - EPC]; }
+        *(f32x4*)(red + tid * (2 * EPC) + q * 4) = v4;
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int c = tid >> 1, which = tid & 1;
+        const int pc = c / EPC, j = c % EPC;
+        const int cog = co_tile * 64 + c;
+        float tot = 0.f;
 #pragma unroll 8
-      for (int pr = 0; pr < PXI; ++pr) tot += red[(pr * PPP + pc) * (2 * EPC) + which * EPC + j];
-      if (cog < p.Cout) {
-        const int tile = p.stat_tile_base + ty * p.tiles_x + tx;
-        p.stats[(((size_t)n * p.stat_tiles + tile) * p.Cout + cog) * 2 + which] = tot;
+        for (int pr = 0; pr < PXI; ++pr) tot += red[(pr * PPP + pc) * (2 * EPC) + which * EPC + j];
+        if (cog < p.Cout && n + sg < p.B) {
+          const int tile = p.stat_tile_base + ty * p.tiles_x + tx;
+          p.stats[(((size_t)(n + sg) * p.stat_tiles + tile) * p.Cout + cog) * 2 + which] = tot;
+        }
       }
     }
   }
@@ -933,9 +965,9 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   PD_STAMP(6);
 }
 
-template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false, int NCO = 1, bool PLAIN = false, int PRO = 0>
+template <typename T, int KS, int STRIDE, int TH, int TW, bool TAIL = false, int NCO = 1, bool PLAIN = false, int PRO = 0, bool STACK = false>
 static int launch_conv(const ConvP& p, hipStream_t st) {
-  constexpr int IN_TH = (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
+  constexpr int IN_TH = STACK ? (TH / 8) * 10 : (TH - 1) * STRIDE + KS, IN_TW = (TW - 1) * STRIDE + KS;
   constexpr int PITCH = 32 * Elem<T>::BYTES + 16;
   constexpr int LDS_TILE = ((IN_TH * IN_TW * PITCH + 15) / 16) * 16;
   // double-buffer when two tiles fit comfortably -- and leave room for a second workgroup: the stride-2 halo tile (9 x 65 pixels)
@@ -948,14 +980,14 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int LDS_BYTES = LDS_MAIN > EPI_BYTES ? LDS_MAIN : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "tile too large");
   static_assert(NCO == 1 || DB, "NCO = 2 is a double-buffered variant");
-  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO, PLAIN, PRO>;
+  auto kern = conv_kernel<T, KS, STRIDE, TH, TW, DB, TAIL, NCO, PLAIN, PRO, STACK>;
   if (LDS_BYTES > 64 * 1024) {
     static LdsAttr attr;   // per instantiation, per device
     if (!ensure_lds(attr, kern, LDS_BYTES)) { set_error("pd_conv: cannot reserve %d bytes of LDS", LDS_BYTES); return PD_ERR_LAUNCH; }
   }
   ConvP q = p;
   q.tiles_x = (p.Wout + TW - 1) / TW;
-  q.tiles_y = (p.Hout + TH - 1) / TH;
+  q.tiles_y = STACK ? 1 : (p.Hout + TH - 1) / TH;
   q.tiles_x_shift = -1;
   for (int sft = 0; sft < 16; ++sft) if ((1 << sft) == q.tiles_x) q.tiles_x_shift = sft;
   q.n_co_tiles = (p.Cout_pad + 63) / 64;
@@ -970,9 +1002,9 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
     const long long wbytes = (long long)p.Cout_pad * cin * KS * KS * es, abytes = (long long)p.B * p.Hin * p.Win * cin * es;
     const long long blocks = (long long)q.tiles_x * q.tiles_y * (q.n_co_tiles / NCO) * p.B;
     const int env = diag_env("PD_CONV_XCD", 0);
-    q.co_major = blocks >= 64 && blocks < (1ll << 30) && !p.im2col3 && (env == 1 || (env == 2 && wbytes > abytes));
+    q.co_major = !STACK && blocks >= 64 && blocks < (1ll << 30) && !p.im2col3 && (env == 1 || (env == 2 && wbytes > abytes));
   }
-  hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.n_co_tiles / NCO, p.B), dim3(256), LDS_BYTES, st, q);
+  hipLaunchKernelGGL(kern, dim3(q.tiles_x * q.tiles_y, q.n_co_tiles / NCO, STACK ? (p.B + TH / 8 - 1) / (TH / 8) : p.B), dim3(256), LDS_BYTES, st, q);
   PD_LAUNCH_CHECK();
   return PD_OK;
 }
@@ -1038,6 +1070,12 @@ static int dispatch_conv(const ConvP& p, int ksize, int stride, hipStream_t st) 
     // images of at most 8 x 8 pixels (the SD UNet's innermost level at 512 x 512): an 8 x 8 tile = two 32-pixel fragments, one per
     // wave pair -- the 16 x 8 tile spent half of its MFMAs on rows below the image (round 3: 1 280 -> 1 280 @8x8 417 TF/s)
     const bool one8 = p.Hout <= 8 && w <= 8;
+    // 8 x 8 IMAGES (the SD UNet's innermost level at 512 x 512): two samples per 128-pixel tile (STACK), see conv_kernel.  OPT-IN (PD_CONV_STACK=1): as an op
+    // 5-10 % faster than the 64-pixel tile with cold weights (94 -> 84-89 us, 170 -> 161 us), on the whole workloads neutral (same box: SD img2img
+    // 10.243 vs 10.235 images/s, fine-tuning 243.75 vs 243.73 samples/s; profiles/r6_ab_conv8_stack_*.log) -- default: the 64-pixel tile
+    const bool stack = p.Hout == 8 && w == 8 && p.Hin == 8 && p.Win == 8 && !p.upsample && p.in_step == 1 && p.out_step == 1 && p.pad == 1 && p.pad_x == 1 &&
+                       p.scale == nullptr && !p.silu && !p.im2col3 && p.out_mode == PD_OUT_NHWC && p.B >= 2 && diag_env("PD_CONV_STACK", 0) != 0;
+    if (stack) return p.n_tail > 0 ? launch_conv<T, 3, 1, 16, 8, true, 1, false, 0, true>(p, st) : launch_conv<T, 3, 1, 16, 8, false, 1, false, 0, true>(p, st);
     if (p.n_tail > 0) {
       if (w >= 32) return launch_conv<T, 3, 1, 8, 32, true>(p, st);
       if (w >= 16) return launch_conv<T, 3, 1, 16, 16, true>(p, st);

@@ -679,3 +679,52 @@ def test_upsample_conv_input_gradient_as_four_subpixel_phases(env, mode, shape):
     assert lib.pd_conv(C.byref(a), stream()) != 0
     a.stats_out, a.phase = None, 0
     assert lib.pd_conv(C.byref(a), stream()) != 0
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
+@pytest.mark.parametrize("B,tail", [(5, False), (2, True), (4, False), (3, True)])
+def test_conv3x3_two_8x8_images_per_tile(env, mode, B, tail, monkeypatch):
+    """Round 6 (opt-in, PD_CONV_STACK=1): at the 8 x 8 level a workgroup's tile is TWO samples (conv_kernel STACK: images stacked with their own zero halo rows).  Everything
+    that is per sample -- time-embedding row, residual, output statistics, the odd batch's last tile -- against torch, and BIT FOR BIT against the
+    64-pixel tile form (PD_CONV_STACK=0: the same K order per pixel, the same pixel order per statistic)."""
+    L, lib, pack, dev = env
+    code, tdt = DT[mode]
+    g = torch.Generator().manual_seed(61)
+    c0, c1, cout, h = 64, 32, 96, 8
+    x0, x1 = torch.randn(B, c0, h, h, generator=g), torch.randn(B, c1, h, h, generator=g)
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / ((c0 + c1) * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    temb = torch.randn(B, 200, generator=g)            # row stride 200, the layer's slice starts at column 0
+    res = torch.randn(B, cout, h, h, generator=g)
+    xa = torch.randn(B, 64, h, h, generator=g)
+    ws = torch.randn(cout, 64, 1, 1, generator=g) / 8
+    wp = pack(w, tdt)
+    if tail:
+        ct = wp.shape[0]
+        wp = torch.cat([wp.reshape(ct, -1, 64, 8), pack(ws, tdt).reshape(ct, -1, 64, 8)], 1).contiguous()
+    wp = wp.to(dev)
+    X0, X1, XA, R = nhwc(x0.to(dev), tdt), nhwc(x1.to(dev), tdt), nhwc(xa.to(dev), tdt), nhwc(res.to(dev), tdt)
+    bias, tb = b.to(dev), temb.to(dev)
+    T = lib.pd_conv_stat_tiles(h, h, 3, 1)
+    outs = []
+    for stack in ("1", "0"):
+        monkeypatch.setenv("PD_CONV_STACK", stack)
+        y = torch.full((B, h, h, cout), float("nan"), dtype=tdt, device=dev)
+        st = torch.full((B, T, cout, 2), float("nan"), device=dev)
+        a = L.ConvArgs(dtype=code, B=B, Hin=h, Win=h, Hout=h, Wout=h, C0=c0, C1=c1, Cout=cout, Cout_pad=cout, ksize=3, stride=1, pad=1, upsample=0, silu=0,
+                       out_mode=0, heads=0, x0=X0.data_ptr(), x1=X1.data_ptr(), scale=None, shift=None, w_packed=wp.data_ptr(), bias=bias.data_ptr(),
+                       temb=tb.data_ptr(), temb_stride=200, residual=R.data_ptr(), y=y.data_ptr(), stats_out=st.data_ptr(),
+                       tail_x0=XA.data_ptr() if tail else None, tail_x1=None, tail_C0=64 if tail else 0, tail_C1=0, im2col3=0)
+        L.check(lib.pd_conv(C.byref(a), stream()), "pd_conv")
+        torch.cuda.synchronize()
+        outs.append((y, st))
+    (y, st), (y0, st0) = outs
+    assert torch.equal(y, y0) and torch.equal(st, st0)
+    xin = torch.cat([bf16_round(x0, mode), bf16_round(x1, mode)], 1)
+    ref = F.conv2d(xin, bf16_round(w, mode), b, padding=1) + temb[:, :cout, None, None]
+    if tail:
+        ref = ref + F.conv2d(bf16_round(xa, mode), bf16_round(ws, mode))
+    ref = bf16_round(ref, mode) + bf16_round(res, mode) if mode != "f32" else ref + res
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode] * 1.5
+    yf = y.float().cpu()
+    assert rel(st[:, 0, :, 0], yf.sum((1, 2))) < 1e-5 and rel(st[:, 0, :, 1], (yf * yf).sum((1, 2))) < 1e-5
