@@ -34,7 +34,7 @@ extern "C" {
  * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_attn_bwd_args.slab / slab_bytes +
  * pd_attn_d8_bwd_workspace (the one-pass backward); 7 = round 6: pd_gn_bwd_args.mod / mod_stride / dmod (scale_shift ResNet blocks train);
  * pd_resize_tf1, pd_conv_rect, pd_pool2d, pd_fc_f32 (the evaluation metrics' feature extractor); pd_pack_weight_args.dst2 / dst2_ct_stride. */
-#define PD_ABI_VERSION 7
+#define PD_ABI_VERSION 8
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
 /* PD_F32: exact-fp32 MFMA (parity mode).  PD_BF16 / PD_F16: 16-bit storage + MFMA, fp32 accumulate / statistics / softmax.
@@ -621,6 +621,9 @@ typedef struct {
   int dtype; long long rows; int C; float eps;
   const void* x; const void* dy; const float* gamma; const void* res;
   void* dx; float* dgamma; float* dbeta; float* partial;
+  /* ABI 8 (optional, needs `partial` sized for 3 * C floats per block): dxsum[c] += sum_rows dx[row][c] of the STORED dx -- the bias gradient of the
+   * Linear layer whose output gradient dx is (the residual stream), without another pass over it */
+  float* dxsum;
 } pd_layernorm_bwd_args;
 int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream);
 int pd_layernorm_bwd_blocks(long long rows);
@@ -632,7 +635,13 @@ typedef struct { int dtype; int rows, dim, num_classes; long long row_stride; co
 int pd_token_embedding_grad(const pd_token_embedding_grad_args* a, void* stream);
 
 /* pd_geglu_bwd: x = [h | g] (the forward's input, [rows][2*inner]), dy [rows][inner] -> dx = [dy*gelu(g) | dy*h*gelu'(g)] */
-typedef struct { int dtype; long long rows; int inner; const void* x; const void* dy; void* dx; } pd_geglu_bwd_args;
+typedef struct {
+  int dtype; long long rows; int inner; const void* x; const void* dy; void* dx;
+  /* ABI 8 (optional): per-split column sums of dx AS STORED -- the bias gradient of the projection that feeds the gate without another pass over
+   * dx: sums[(n * sum_splits + sp) * 2 * inner + c] for the B samples of rows / B rows each (the workspace layout of pd_channel_sum with x = NULL,
+   * which folds them).  Needs inner % 256 == 0 and rows % B == 0; sums = NULL: not computed. */
+  float* sums; int sum_splits; int B;
+} pd_geglu_bwd_args;
 int pd_geglu_bwd(const pd_geglu_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

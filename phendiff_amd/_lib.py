@@ -38,7 +38,7 @@ def library_is_current() -> bool:
 PD_F32, PD_BF16, PD_F16 = 0, 1, 2
 PD_PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 PD_OUT_NHWC, PD_OUT_NCHW_F32, PD_OUT_QKV_HEADS = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp = C.c_void_p
 
@@ -189,7 +189,7 @@ class AttnD64BwdArgs(C.Structure):
 
 class LayerNormBwdArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("C", C.c_int), ("eps", C.c_float), ("x", vp), ("dy", vp), ("gamma", vp),
-                ("res", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp), ("partial", vp)]
+                ("res", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp), ("partial", vp), ("dxsum", vp)]
 
 
 class TokenEmbeddingGradArgs(C.Structure):
@@ -198,7 +198,8 @@ class TokenEmbeddingGradArgs(C.Structure):
 
 
 class GegluBwdArgs(C.Structure):
-    _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("inner", C.c_int), ("x", vp), ("dy", vp), ("dx", vp)]
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_longlong), ("inner", C.c_int), ("x", vp), ("dy", vp), ("dx", vp),
+                ("sums", vp), ("sum_splits", C.c_int), ("B", C.c_int)]
 
 
 class LatentSampleArgs(C.Structure):

@@ -300,18 +300,21 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
 
 // NP = 8-element pieces per lane (C <= 512 * NP): narrow rows keep few registers, so more waves hide the three dependent
 // reductions per token
-template <typename T, int NP>
+// DXS (round 6, pd_layernorm_bwd_args.dxsum): a third column sum -- of dx as stored, the bias gradient of the Linear layer that wrote the residual
+// stream this dx is the gradient of (attn1 / attn2 to_out, proj_in): pd_channel_sum no longer reads dx back for it
+template <typename T, int NP, bool DXS>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_bwd_args a) {
   using E = Elem<T>;
-  __shared__ float red[3][2][NP][8][64];          // waves 1..3: [dgamma | dbeta] shares
+  constexpr int NS = DXS ? 3 : 2;
+  __shared__ float red[3][NS][NP][8][64];         // waves 1..3: [dgamma | dbeta (| dx sum)] shares
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pieces = a.C / 8;
-  float gam[NP][8], dg[NP][8], db[NP][8];
+  float gam[NP][8], dg[NP][8], db[NP][8], ds[DXS ? NP : 1][8];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pc = lane + 64 * i;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { gam[i][j] = pc < pieces ? a.gamma[pc * 8 + j] : 0.f; dg[i][j] = 0.f; db[i][j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { gam[i][j] = pc < pieces ? a.gamma[pc * 8 + j] : 0.f; dg[i][j] = 0.f; db[i][j] = 0.f; if (DXS) ds[i][j] = 0.f; }
   }
   const float invC = 1.0f / (float)a.C;
   for (long long row = (long long)blockIdx.x * 4 + wave; row < a.rows; row += (long long)gridDim.x * 4) {
@@ -369,7 +372,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
         if (res) E::unpack(E::load(res + pc * 8), rv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - mg - v[i][j] * mgx) + (res ? rv[j] : 0.f);
-        E::store(dx + pc * 8, E::pack(o));
+        const typename E::Frag fo = E::pack(o);
+        E::store(dx + pc * 8, fo);
+        if constexpr (DXS) {
+          E::unpack(fo, o);                      // the sum is over the stored values (what the weight gradient of that layer reads)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ds[i][j] += o[j];
+        }
       }
     }
   }
@@ -378,11 +387,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { red[wave - 1][0][i][j][lane] = dg[i][j]; red[wave - 1][1][i][j][lane] = db[i][j]; }
+      for (int j = 0; j < 8; ++j) {
+        red[wave - 1][0][i][j][lane] = dg[i][j]; red[wave - 1][1][i][j][lane] = db[i][j];
+        if constexpr (DXS) red[wave - 1][2][i][j][lane] = ds[i][j];
+      }
   }
   __syncthreads();
   if (wave == 0) {
-    float* pg = a.partial + (size_t)blockIdx.x * 2 * a.C;
+    float* pg = a.partial + (size_t)blockIdx.x * NS * a.C;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int pc = lane + 64 * i;
@@ -391,6 +403,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
         for (int j = 0; j < 8; ++j) {
           pg[pc * 8 + j] = ((dg[i][j] + red[0][0][i][j][lane]) + red[1][0][i][j][lane]) + red[2][0][i][j][lane];
           pg[a.C + pc * 8 + j] = ((db[i][j] + red[0][1][i][j][lane]) + red[1][1][i][j][lane]) + red[2][1][i][j][lane];
+          if constexpr (DXS) pg[2 * a.C + pc * 8 + j] = ((ds[i][j] + red[0][2][i][j][lane]) + red[1][2][i][j][lane]) + red[2][2][i][j][lane];
         }
       }
     }
@@ -399,20 +412,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
 
 // dgamma[c] += sum over workgroups of partial[wg][0][c], dbeta likewise (fixed order: bitwise reproducible).
 // Workgroup = 16 columns x 16 row groups: row group r sums workgroups r, r+16, ...; the 16 shares are added in order.
-__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* partial, int nblocks, int C, float* dgamma, float* dbeta) {
+// (ns = 3: a third column block, the sums of dx -> dxsum)
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* partial, int nblocks, int C, float* dgamma, float* dbeta, int ns, float* dxsum) {
   __shared__ float red[16][17];
   const int col = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + col;
   float s = 0.f;
-  if (idx < 2 * C)
-    for (int b = rg; b < nblocks; b += 16) s += partial[(size_t)b * 2 * C + idx];
+  if (idx < ns * C)
+    for (int b = rg; b < nblocks; b += 16) s += partial[(size_t)b * ns * C + idx];
   red[rg][col] = s;
   __syncthreads();
-  if (rg == 0 && idx < 2 * C) {
+  if (rg == 0 && idx < ns * C) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][col];
-    float* dst = idx < C ? dgamma + idx : dbeta + (idx - C);
+    float* dst = idx < C ? dgamma + idx : (idx < 2 * C ? dbeta + (idx - C) : dxsum + (idx - 2 * C));
     *dst += t;
   }
 }
@@ -439,6 +453,56 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const pd_geglu_bwd_args 
     }
     E::store((T*)a.dx + row * 2 * a.inner + pc * 8, E::pack(dh));
     E::store((T*)a.dx + row * 2 * a.inner + a.inner + pc * 8, E::pack(dgv));
+  }
+}
+
+// The same with the column sums of dx as stored (round 6; pd_geglu_bwd_args.sums): the bias gradient of ff.net.0.proj is the column sum of dx = [dh | dg],
+// the widest gradient tensor of a transformer block (8 x the hidden width: 671 MB at the 64 x 64 level) -- read back by pd_channel_sum it was 60 % of all the
+// bytes the bias gradients of a fine-tuning step fetched.  Workgroup = 32 piece columns (256 channels of h and of g: 512-byte row segments) x 8 row
+// phases over one sample's row range; a thread owns its 16 channels, the 8 phases are folded in a fixed order (fp64, as channel_sum_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_sums_kernel(const pd_geglu_bwd_args a) {
+  using E = Elem<T>;
+  __shared__ float red[8][32][16];
+  const int chunks = a.inner / 256;
+  const int chunk = blockIdx.x % chunks, sp = blockIdx.x / chunks;          // chunk fastest: neighbouring workgroups read neighbouring columns of the same rows
+  const int n = sp / a.sum_splits, sq = sp - n * a.sum_splits;
+  const long long N = a.rows / a.B, per = (N + a.sum_splits - 1) / a.sum_splits;
+  const long long r_lo = n * N + sq * per, r_hi = min(n * N + N, r_lo + per);
+  const int pcol = threadIdx.x & 31, phase = threadIdx.x >> 5;
+  const int pc = chunk * 32 + pcol;
+  float sh[8], sg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sh[j] = 0.f; sg[j] = 0.f; }
+  for (long long row = r_lo + phase; row < r_hi; row += 8) {
+    float hv[8], gv[8], dyv[8], dh[8], dgv[8];
+    E::unpack(E::load((const T*)a.x + row * 2 * a.inner + pc * 8), hv);
+    E::unpack(E::load((const T*)a.x + row * 2 * a.inner + a.inner + pc * 8), gv);
+    E::unpack(E::load((const T*)a.dy + row * a.inner + pc * 8), dyv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cdf = 0.5f * (1.0f + erff(gv[j] * 0.7071067811865476f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * gv[j] * gv[j]);
+      dh[j] = dyv[j] * gv[j] * cdf;
+      dgv[j] = dyv[j] * hv[j] * (cdf + gv[j] * pdf);
+    }
+    const typename E::Frag fh = E::pack(dh), fg = E::pack(dgv);
+    E::store((T*)a.dx + row * 2 * a.inner + pc * 8, fh);
+    E::store((T*)a.dx + row * 2 * a.inner + a.inner + pc * 8, fg);
+    E::unpack(fh, dh); E::unpack(fg, dgv);                                 // the sums are over what the weight gradient reads: the stored values
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[j] += dh[j]; sg[j] += dgv[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[phase][pcol][j] = sh[j]; red[phase][pcol][8 + j] = sg[j]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 512; o += 256) {
+    const int pq = o >> 4, j = o & 15;
+    double d = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d += (double)red[k][pq][j];
+    const int c = (j < 8 ? 0 : a.inner) + (chunk * 32 + pq) * 8 + (j & 7);
+    a.sums[(size_t)sp * 2 * a.inner + c] = (float)d;
   }
 }
 
@@ -508,22 +572,30 @@ extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
            "pd_layernorm_bwd: bad args (C must be a multiple of 8, <= 2048)");
   PD_CHECK((a->dgamma == nullptr) == (a->dbeta == nullptr) && (a->dgamma == nullptr) == (a->partial == nullptr), PD_ERR_ARG,
            "pd_layernorm_bwd: dgamma, dbeta and partial go together");
+  PD_CHECK(a->dxsum == nullptr || a->partial != nullptr, PD_ERR_ARG, "pd_layernorm_bwd: dxsum needs dgamma, dbeta and a partial workspace of 3 C floats per block");
   const int grid = pd_layernorm_bwd_blocks(a->rows);
   hipStream_t st = (hipStream_t)stream;
   const int np = (a->C / 8 + 63) / 64;
+  const bool dxs = a->dxsum != nullptr;
+  PD_CHECK(!dxs || np <= 3, PD_ERR_UNSUPPORTED, "pd_layernorm_bwd: dxsum needs C <= 1536 (C=%d)", a->C);
   if (a->dtype != PD_F32 && a->dtype != PD_BF16 && a->dtype != PD_F16) { set_error("pd_layernorm_bwd: bad dtype"); return PD_ERR_ARG; }
 #define PD_LN_BWD(NP_)                                                                                             \
   do {                                                                                                             \
-    if (a->dtype == PD_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, NP_>), dim3(grid), dim3(256), 0, st, *a); \
-    else if (a->dtype == PD_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<half_t, NP_>), dim3(grid), dim3(256), 0, st, *a); \
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NP_>), dim3(grid), dim3(256), 0, st, *a);                  \
+    if (dxs) {                                                                                                     \
+      if (a->dtype == PD_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, NP_, (NP_ <= 3)>), dim3(grid), dim3(256), 0, st, *a); \
+      else if (a->dtype == PD_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<half_t, NP_, (NP_ <= 3)>), dim3(grid), dim3(256), 0, st, *a); \
+      else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NP_, (NP_ <= 3)>), dim3(grid), dim3(256), 0, st, *a);           \
+    } else if (a->dtype == PD_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, NP_, false>), dim3(grid), dim3(256), 0, st, *a); \
+    else if (a->dtype == PD_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<half_t, NP_, false>), dim3(grid), dim3(256), 0, st, *a); \
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NP_, false>), dim3(grid), dim3(256), 0, st, *a);           \
   } while (0)
   if (np == 1) PD_LN_BWD(1); else if (np == 2) PD_LN_BWD(2); else if (np == 3) PD_LN_BWD(3); else PD_LN_BWD(4);
 #undef PD_LN_BWD
   PD_LAUNCH_CHECK();
   if (a->partial) {
-    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * a->C + 15) / 16), dim3(256), 0, st, (const float*)a->partial, grid, a->C,
-                       a->dgamma, a->dbeta);
+    const int ns = dxs ? 3 : 2;
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((ns * a->C + 15) / 16), dim3(256), 0, st, (const float*)a->partial, grid, a->C,
+                       a->dgamma, a->dbeta, ns, a->dxsum);
     PD_LAUNCH_CHECK();
   }
   return PD_OK;
@@ -544,6 +616,18 @@ extern "C" int pd_token_embedding_grad(const pd_token_embedding_grad_args* a, vo
 
 extern "C" int pd_geglu_bwd(const pd_geglu_bwd_args* a, void* stream) {
   PD_CHECK(a != nullptr && a->rows > 0 && a->inner > 0 && a->inner % 8 == 0 && a->x && a->dy && a->dx, PD_ERR_ARG, "pd_geglu_bwd: bad args");
+  if (a->sums) {
+    PD_CHECK(a->B > 0 && a->sum_splits > 0 && a->rows % a->B == 0 && a->inner % 256 == 0, PD_ERR_ARG,
+             "pd_geglu_bwd: column sums need inner %% 256 == 0 and rows %% B == 0 (rows=%lld B=%d inner=%d splits=%d)", a->rows, a->B, a->inner, a->sum_splits);
+    const long long blocks = (long long)a->B * a->sum_splits * (a->inner / 256);
+    PD_CHECK(blocks < (1ll << 31), PD_ERR_SHAPE, "pd_geglu_bwd: %lld workgroups", blocks);
+    if (a->dtype == PD_F32) hipLaunchKernelGGL(geglu_bwd_sums_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->dtype == PD_BF16) hipLaunchKernelGGL(geglu_bwd_sums_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->dtype == PD_F16) hipLaunchKernelGGL(geglu_bwd_sums_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else { set_error("pd_geglu_bwd: bad dtype"); return PD_ERR_ARG; }
+    PD_LAUNCH_CHECK();
+    return PD_OK;
+  }
   const size_t total = (size_t)a->rows * (a->inner / 8);
   const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   if (a->dtype == PD_F32) hipLaunchKernelGGL(geglu_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);

@@ -12,6 +12,7 @@ gradient of the class token (``pd_token_embedding_grad``) -- the only trainable 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
@@ -23,6 +24,9 @@ from .sd_unet import (CustomEmbedding, SDUNet2DConditionModel, SDUNetPlan, _SDPa
                       class_emb_to_encoder_hidden_states)
 from .unet import _Resnet, _Sampler, _copy_into
 from .unet_train import UNetTrainer, UNetTrainPlan, _contiguous_after, run_pack_jobs
+
+# diagnostic switch (same-box A/B): PD_BIAS_FUSE=0 -> every bias gradient of the transformer blocks is a pd_channel_sum pass over its dY again
+_BIAS_FUSE = os.environ.get("PD_BIAS_FUSE", "1") != "0"
 
 EMB_NAME = "class_embedding.inner_module.weight"
 
@@ -182,19 +186,24 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         else:
             super()._bwd_record(rec)
 
-    def _ln_bwd(self, x, ln, pname, dy, res, tag):
+    def _ln_bwd(self, x, ln, pname, dy, res, tag, bias_name=None):
+        """LayerNorm backward (+ the gradient arriving over the skip connection).  ``bias_name``: the bias of the Linear layer whose output gradient the
+        returned dx is -- its gradient (the column sums of dx) comes out of the same launch (round 6, ``pd_layernorm_bwd_args.dxsum``) instead of a
+        ``pd_channel_sum`` pass over dx; returns (dx, whether that happened)."""
         gamma, _, eps = ln
         B, h, w, ch = x.shape
         rows = B * h * w
         dx = self._tmp((B, h, w, ch), tag)
         partial = None
         dgam, dbet = self._G2(pname + ".weight", pname + ".bias")
+        fuse = bias_name is not None and dgam is not None and ch <= 1536 and _BIAS_FUSE and bias_name not in self.frozen
+        dxsum = self._G(bias_name) if fuse else None
         if dgam is not None:
-            partial = self._tmp((self.lib.pd_layernorm_bwd_blocks(rows) * 2 * ch,), "lnpart", torch.float32)
+            partial = self._tmp((self.lib.pd_layernorm_bwd_blocks(rows) * (3 if fuse else 2) * ch,), "lnpart3" if fuse else "lnpart", torch.float32)
         a = L.LayerNormBwdArgs(dtype=self.code, rows=rows, C=ch, eps=eps, x=x.data_ptr(), dy=dy.data_ptr(), gamma=gamma.data_ptr(),
-                               res=L.ptr(res), dx=dx.data_ptr(), dgamma=L.ptr(dgam), dbeta=L.ptr(dbet), partial=L.ptr(partial))
+                               res=L.ptr(res), dx=dx.data_ptr(), dgamma=L.ptr(dgam), dbeta=L.ptr(dbet), partial=L.ptr(partial), dxsum=L.ptr(dxsum))
         self._b(self.lib.pd_layernorm_bwd, a, "layernorm_bwd", 0.0, (3 + (res is not None)) * x.numel() * self._esz())
-        return dx
+        return dx, fuse
 
     def _attn_bwd64(self, q, qs, k, v, kvs, o, do, lse, heads, nq, nkv, dq, dqs, dk, dv, dkvs):
         delta = self._tmp((self.B, heads, nq), "delta64", torch.float32)
@@ -223,13 +232,22 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         dgg = self._dgrad(dh3, te.wff2_d, 4 * ch, ksize=1, tag="t_dgg")
         dff = self._tmp((B, h, w, 8 * ch), "t_dff")
         ga = L.GegluBwdArgs(dtype=self.code, rows=B * N, inner=4 * ch, x=rec.ff.data_ptr(), dy=dgg.data_ptr(), dx=dff.data_ptr())
+        if _BIAS_FUSE and self.param_grads and (4 * ch) % 256 == 0 and (blk + ".ff.net.0.proj.bias") not in self.frozen:
+            # the gate's backward also leaves the per-split column sums of dff (the widest gradient of the block): the bias gradient folds
+            # those (B x splits x 8 ch floats) instead of reading dff back
+            gs = max(1, min(64, N // 64))
+            gws = self._tmp((B * gs * 8 * ch,), "geglu_sums", torch.float32)
+            ga.sums, ga.sum_splits, ga.B = gws.data_ptr(), gs, B
+            self._fused_sums[id(dff)] = (gws, gs)
         self._b(self.lib.pd_geglu_bwd, ga, "geglu_bwd", 0.0, 5.0 * dgg.numel() * esz)
         self._bias_grad(dff, G(blk + ".ff.net.0.proj.bias"))
+        self._fused_sums.pop(id(dff), None)               # (dff is a scratch buffer other blocks reuse)
         lin_w(rec.y3, dff, blk + ".ff.net.0.proj.weight")
         dy3 = self._dgrad(dff, te.wff1_d, ch, ksize=1, tag="t_dy")
-        dh2 = self._ln_bwd(rec.h2, e.ln3, blk + ".norm3", dy3, dh3, "t_dh2")
+        dh2, fb = self._ln_bwd(rec.h2, e.ln3, blk + ".norm3", dy3, dh3, "t_dh2", bias_name=blk + ".attn2.to_out.0.bias")
         # cross attention: h2 = to_out(attn(to_q(LN2(h1)), to_k(ehs), to_v(ehs))) + h1
-        self._bias_grad(dh2, G(blk + ".attn2.to_out.0.bias"))
+        if not fb:
+            self._bias_grad(dh2, G(blk + ".attn2.to_out.0.bias"))
         lin_w(rec.a2, dh2, blk + ".attn2.to_out.0.weight")
         da2 = self._dgrad(dh2, te.wo2_d, ch, ksize=1, tag="t_da")
         dq2 = self._tmp((B, h, w, ch), "t_dq2")
@@ -242,9 +260,10 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
         if self._want_ehs_grad():
             self._dgrad(dkv, te.wkv2_d, self.ehs.shape[3], ksize=1, into=self._dehs)
         dy2 = self._dgrad(dq2, te.wq2_d, ch, ksize=1, tag="t_dy")
-        dh1 = self._ln_bwd(rec.h1, e.ln2, blk + ".norm2", dy2, dh2, "t_dh1")
+        dh1, fb = self._ln_bwd(rec.h1, e.ln2, blk + ".norm2", dy2, dh2, "t_dh1", bias_name=blk + ".attn1.to_out.0.bias")
         # self attention: h1 = to_out(attn(qkv(LN1(h0)))) + h0
-        self._bias_grad(dh1, G(blk + ".attn1.to_out.0.bias"))
+        if not fb:
+            self._bias_grad(dh1, G(blk + ".attn1.to_out.0.bias"))
         lin_w(rec.a1, dh1, blk + ".attn1.to_out.0.weight")
         da1 = self._dgrad(dh1, te.wo1_d, ch, ksize=1, tag="t_da")
         dqkv = self._tmp((B, h, w, 3 * ch), "t_dqkv")
@@ -253,9 +272,10 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
                          dp, 3 * ch, dp + ch * esz, dp + 2 * ch * esz, 3 * ch)
         lin_w(rec.y1, dqkv, (blk + ".attn1.to_q.weight", (blk + ".attn1.to_k.weight", blk + ".attn1.to_v.weight")))
         dy1 = self._dgrad(dqkv, te.wqkv1_d, ch, ksize=1, tag="t_dy")
-        dh0 = self._ln_bwd(rec.h0, e.ln1, blk + ".norm1", dy1, dh1, "t_dh0")
+        dh0, fb = self._ln_bwd(rec.h0, e.ln1, blk + ".norm1", dy1, dh1, "t_dh0", bias_name=n + ".proj_in.bias")
         # proj_in over GroupNorm(x) (no SiLU)
-        self._bias_grad(dh0, G(n + ".proj_in.bias"))
+        if not fb:
+            self._bias_grad(dh0, G(n + ".proj_in.bias"))
         lin_w(rec.x, dh0, n + ".proj_in.weight", gn=rec.gn)
         dz = self._dgrad(dh0, te.w_in_d, ch, ksize=1, tag="t_dz")
         self._gn_bwd(rec.gn, dz, 0, res=dout, wname=n + ".norm")

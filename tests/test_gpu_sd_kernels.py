@@ -175,6 +175,22 @@ def test_layernorm_backward(env, mode, cfg, with_res):
     want = x.grad + (res if with_res else 0)
     assert rel(dx.float(), want) < (3e-6 if mode == "f32" else 5e-3)
     assert rel(dgm - 1.0, gamma.grad) < 2e-5 and rel(dbt + 2.0, beta.grad) < 2e-5
+    # round 6: + the column sums of the stored dx (the bias gradient of the Linear layer dx is the output gradient of), C <= 1536
+    if Cc <= 1536:
+        part3 = torch.empty(nb * 3 * Cc, dtype=torch.float32, device=dev)
+        dxs = torch.full((Cc,), 0.5, dtype=torch.float32, device=dev)       # accumulates (+=)
+        dgm3, dbt3, dx3 = torch.zeros_like(dgm), torch.zeros_like(dbt), torch.empty_like(dx)
+        a.dgamma, a.dbeta, a.partial, a.dxsum, a.dx = dgm3.data_ptr(), dbt3.data_ptr(), part3.data_ptr(), dxs.data_ptr(), dx3.data_ptr()
+        L.check(lib.pd_layernorm_bwd(C.byref(a), stream()), "pd_layernorm_bwd")
+        torch.cuda.synchronize()
+        # (another instantiation of the kernel: the compiler may contract the fp32 expressions differently -- last-bit differences in the f32 engine)
+        assert rel(dx3.float(), dx.float()) < 1e-6 and rel(dgm3, dgm - 1.0) < 1e-5 and rel(dbt3, dbt + 2.0) < 1e-5
+        assert rel(dxs - 0.5, dx3.double().sum(0).float()) < 1e-5
+        a.dxsum = None
+    else:
+        a.dxsum = dx.data_ptr()
+        assert lib.pd_layernorm_bwd(C.byref(a), stream()) != 0              # refused, not silently skipped
+        a.dxsum = None
     # input-gradient-only form
     a.dgamma, a.dbeta, a.partial = None, None, None
     dx2 = torch.empty_like(dx)
@@ -199,6 +215,18 @@ def test_geglu_backward(env, mode):
     L.check(lib.pd_geglu_bwd(C.byref(a), stream()), "pd_geglu_bwd")
     torch.cuda.synchronize()
     assert rel(dx.float(), x.grad) < (2e-6 if mode == "f32" else 4e-3)
+    # round 6: the same launch leaves the per-split column sums of the stored dx (workspace layout of pd_channel_sum with x = NULL)
+    for B, splits in ((3, 5), (1, 64), (37, 1)):          # rows = 333 = 3 x 111 = 37 x 9; 111 rows in 5 splits of 23: a ragged last split
+        ws = torch.full((B * splits * 2 * inner,), float("nan"), dtype=torch.float32, device=dev)
+        dx2 = torch.empty_like(dx)
+        a2 = L.GegluBwdArgs(dtype=code, rows=rows, inner=inner, x=X.data_ptr(), dy=DY.data_ptr(), dx=dx2.data_ptr(), sums=ws.data_ptr(), sum_splits=splits, B=B)
+        L.check(lib.pd_geglu_bwd(C.byref(a2), stream()), "pd_geglu_bwd")
+        torch.cuda.synchronize()
+        assert rel(dx2.float(), dx.float()) < 1e-6 and (mode == "f32" or torch.equal(dx2, dx))     # (f32: another kernel, other fp32 contraction)
+        per = ws.reshape(B, splits, 2 * inner).sum(1)
+        assert rel(per, dx2.double().reshape(B, rows // B, 2 * inner).sum(1).float()) < 1e-5
+    a2.inner, a2.rows = 1288, 10
+    assert lib.pd_geglu_bwd(C.byref(a2), stream()) != 0      # inner % 256 != 0 with sums: refused
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
