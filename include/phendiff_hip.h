@@ -33,7 +33,8 @@ extern "C" {
  * fold_ws_bytes + pd_linear_fold_workspace,
  * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_attn_bwd_args.slab / slab_bytes +
  * pd_attn_d8_bwd_workspace (the one-pass backward); 7 = round 6: pd_gn_bwd_args.mod / mod_stride / dmod (scale_shift ResNet blocks train);
- * pd_resize_tf1, pd_conv_rect, pd_pool2d, pd_fc_f32 (the evaluation metrics' feature extractor); pd_pack_weight_args.dst2 / dst2_ct_stride. */
+ * pd_resize_tf1, pd_conv_rect, pd_pool2d, pd_fc_f32 (the evaluation metrics' feature extractor); pd_pack_weight_args.dst2 / dst2_ct_stride;
+ * 8 = pd_geglu_bwd_args.sums / sum_splits / B, pd_layernorm_bwd_args.dxsum (bias gradients without a pass over dY), pd_upsample_phase_weights. */
 #define PD_ABI_VERSION 8
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
@@ -418,6 +419,13 @@ typedef struct {
   int total_blocks; int max_ksize;
 } pd_pack_weight_batch_args;
 int pd_pack_weight_batch(const pd_pack_weight_batch_args* a, void* stream);
+
+/* pd_upsample_phase_weights (ABI 8): the four 2x2 sub-pixel phase kernels of "nearest x2, then 3x3 pad-1 convolution" (diffusers Upsample2D,
+ * cond_unet_2d.py via UpBlock2D; phendiff_amd.packing.upsample_phase_weights) from the OIHW fp32 master weight, stacked:
+ * out[2 a + b][o][i][u][v] = sum_{y in Y_a(u), x in Y_b(v)} w[o][i][y][x],  Y_0 = ({0}, {1, 2}),  Y_1 = ({0, 1}, {2})  -- rows first, then columns,
+ * in fp32.  The fine-tuning step refreshes them after every optimizer step (before pd_pack_weight_batch packs them). */
+typedef struct { int cout, cin; const float* w; float* out; } pd_upsample_phase_weights_args;
+int pd_upsample_phase_weights(const pd_upsample_phase_weights_args* a, void* stream);
 
 /* pd_im2col3: out[n][y][x][ci*9+ky*3+kx] = x[n][ci][y+ky-1][x+kx-1] (zero padded; 27 of 32 channels used): the input of
  * conv_in seen as a 1x1 convolution, for its weight gradient (cond_unet_2d.py:127-129). x: NCHW fp32, C <= 3; out: NHWC dtype. */

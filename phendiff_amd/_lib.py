@@ -202,6 +202,10 @@ class GegluBwdArgs(C.Structure):
                 ("sums", vp), ("sum_splits", C.c_int), ("B", C.c_int)]
 
 
+class UpsamplePhaseWeightsArgs(C.Structure):
+    _fields_ = [("cout", C.c_int), ("cin", C.c_int), ("w", vp), ("out", vp)]
+
+
 class LatentSampleArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("scale", C.c_float), ("moments", vp), ("noise", vp), ("out", vp)]
 
@@ -313,6 +317,7 @@ SYMBOLS = {
     "pd_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "pd_im2col3": (C.c_int, [C.POINTER(Im2col3Args), vp]),
     "pd_pack_weight": (C.c_int, [C.POINTER(PackWeightArgs), vp]),
+    "pd_upsample_phase_weights": (C.c_int, [C.POINTER(UpsamplePhaseWeightsArgs), vp]),
     "pd_pack_weight_batch": (C.c_int, [C.POINTER(PackWeightBatchArgs), vp]),
     "pd_attn_d8_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
     "pd_attn_d8_bwd_workspace": (C.c_size_t, [C.POINTER(AttnBwdArgs)]),

@@ -37,6 +37,21 @@ def upsample_phase_weights_stacked(w: torch.Tensor, out: torch.Tensor | None = N
     contraction on the weight's device -- R_a w R_b^T with R_0 = [[1,0,0],[0,1,1]] (taps {0 | 1+2}), R_1 = [[1,1,0],[0,0,1]] ({0+1 | 2}) --
     so that the training re-pack can refresh them every step (``out``: a persistent buffer the pack jobs read)."""
     assert w.ndim == 4 and w.shape[2:] == (3, 3)
+    if w.is_cuda:
+        # on the device (model load, and after every optimizer step of a fine-tuning run): one launch of the HIP library, the same sums in the
+        # same order (rows, then columns) -- torch.einsum lowered this to two fp32 GEMMs + copies, 1.8 ms of every SD-2.1 step
+        import ctypes as C
+        from . import _lib as L
+        wf = w.detach()
+        if wf.dtype != torch.float32 or not wf.is_contiguous():
+            wf = wf.float().contiguous()
+        if out is None:
+            out = torch.empty((4, w.shape[0], w.shape[1], 2, 2), dtype=torch.float32, device=w.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.shape == (4, w.shape[0], w.shape[1], 2, 2)
+        a = L.UpsamplePhaseWeightsArgs(cout=w.shape[0], cin=w.shape[1], w=wf.data_ptr(), out=out.data_ptr())
+        with torch.cuda.device(w.device):
+            L.check(L.lib().pd_upsample_phase_weights(C.byref(a), torch.cuda.current_stream().cuda_stream), "pd_upsample_phase_weights")
+        return out
     R = torch.tensor([[[1., 0., 0.], [0., 1., 1.]], [[1., 1., 0.], [0., 0., 1.]]], dtype=torch.float32, device=w.device)
     k = torch.einsum("auy,oiyx,bvx->aboiuv", R, w.detach().float(), R).reshape(4, w.shape[0], w.shape[1], 2, 2)
     if out is not None:

@@ -728,3 +728,26 @@ def test_conv3x3_two_8x8_images_per_tile(env, mode, B, tail, monkeypatch):
     assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[mode] * 1.5
     yf = y.float().cpu()
     assert rel(st[:, 0, :, 0], yf.sum((1, 2))) < 1e-5 and rel(st[:, 0, :, 1], (yf * yf).sum((1, 2))) < 1e-5
+
+
+def test_upsample_phase_weights_on_device_match_the_host_contraction(env):
+    """Round 6: pd_upsample_phase_weights (what the fine-tuning step's re-pack calls after every optimizer step) against the host-side
+    contraction R_a w R_b^T of packing.upsample_phase_weights_stacked on the CPU, and against the convolution identity it stands for."""
+    from phendiff_amd.packing import upsample_phase_weights_stacked
+    L, lib, pack, dev = env
+    g = torch.Generator().manual_seed(62)
+    w = torch.randn(96, 40, 3, 3, generator=g)
+    host = upsample_phase_weights_stacked(w)                       # CPU: einsum
+    got = upsample_phase_weights_stacked(w.to(dev))                # device: the HIP entry point
+    assert got.shape == host.shape == (4, 96, 40, 2, 2)
+    assert rel(got, host) < 1e-7
+    into = torch.full_like(got, float("nan"))
+    assert upsample_phase_weights_stacked(w.to(dev), out=into) is into and torch.equal(into, got)
+    x = torch.randn(2, 40, 5, 7, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    k = got.cpu()
+    for a in range(2):
+        for b in range(2):
+            xp = F.pad(x, (1 - b, b, 1 - a, a))
+            ph = F.conv2d(xp, k[2 * a + b])
+            assert rel(ph, ref[:, :, a::2, b::2]) < 1e-5
