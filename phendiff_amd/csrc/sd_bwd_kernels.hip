@@ -562,9 +562,20 @@ extern "C" int pd_attn_d64_bwd(const pd_attn_d64_bwd_args* a, void* stream) {
   return PD_ERR_ARG;
 }
 
+// workspace bound: `partial` holds this many rows of 2 (3 with dxsum) * C floats
 extern "C" int pd_layernorm_bwd_blocks(long long rows) {
   const long long nb = (rows + 3) / 4;
   return (int)(nb < 2048 ? nb : 2048);
+}
+// Workgroups actually launched (<= the bound above): every workgroup leaves one row of the partial, and the fold of those rows was as long as
+// the kernel itself at 2 048 of them (C = 1 280: 94 us for kernel + fold, 39 us with 512; C = 640: 90 -> 61; C = 320: 132 -> 108 with 1 024,
+// 149 with 512 -- scripts/experiments/bench_ln_bwd.py).  PD_LN_BWD_BLOCKS: diagnostic override.
+static int ln_bwd_grid(long long rows, int C) {
+  const long long nb = (rows + 3) / 4;
+  const int cap = diag_env("PD_LN_BWD_BLOCKS", C <= 384 ? 1024 : 512);
+  const int bound = pd_layernorm_bwd_blocks(rows);
+  const long long g = nb < cap ? nb : cap;
+  return (int)(g < bound ? g : bound);
 }
 
 extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
@@ -573,7 +584,7 @@ extern "C" int pd_layernorm_bwd(const pd_layernorm_bwd_args* a, void* stream) {
   PD_CHECK((a->dgamma == nullptr) == (a->dbeta == nullptr) && (a->dgamma == nullptr) == (a->partial == nullptr), PD_ERR_ARG,
            "pd_layernorm_bwd: dgamma, dbeta and partial go together");
   PD_CHECK(a->dxsum == nullptr || a->partial != nullptr, PD_ERR_ARG, "pd_layernorm_bwd: dxsum needs dgamma, dbeta and a partial workspace of 3 C floats per block");
-  const int grid = pd_layernorm_bwd_blocks(a->rows);
+  const int grid = ln_bwd_grid(a->rows, a->C);
   hipStream_t st = (hipStream_t)stream;
   const int np = (a->C / 8 + 63) / 64;
   const bool dxs = a->dxsum != nullptr;
