@@ -12,6 +12,10 @@
 
 namespace pd {
 
+#ifndef PD_ATTN64_PIPE      // 1: both sub-tiles' score MFMAs before the first softmax (attn_d64_kernel); 0: sub-tile by sub-tile (same-box A/B builds)
+#define PD_ATTN64_PIPE 1
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Attention, head_dim 64.  Workgroup = 4 waves = 128 queries of one (batch, head); keys/values stream through LDS in
 // double-buffered tiles of 64.  Per wave and 32-key sub-tile:
@@ -106,16 +110,131 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
   for (int k0 = 0, cur = 0; k0 < a.Nkv; k0 += KT, cur ^= 1) {
     const unsigned char* kb = lds + cur * (KBYTES + VBYTES);
     const unsigned char* vb = kb + KBYTES;
+    // the three stages of a 32-key sub-tile
+    auto qk = [&](int sub, f32x16 (&s)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const Frag kf = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) s[j] = E::mma(kf, qf[j][ks], ks == 0 ? negm[j] : s[j]);     // s = S - m
+      }
+    };
+    // (`ahead`: the scores of the NEXT sub-tile, already computed against the old reference -- a rescale moves them too)
+    auto soft = [&](f32x16 (&s)[QB], f32x16 (*ahead)[QB]) __attribute__((always_inline)) {
+      float tmax[QB];
+      bool need = first;
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        float t = fmaxf(fmaxf(s[j][0], s[j][1]), s[j][2]);   // v_max3_f32 chain
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, s[j][i]), s[j][i + 1]);
+        tmax[j] = fmaxf(t, s[j][15]);
+        need = need || tmax[j] > RESCALE_THR;
+      }
+      if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+          const float tq = fmaxf(tmax[j], __shfl_xor(tmax[j], 32));   // finite: every sub-tile visited holds at least one real key
+          const float delta = first ? tq : fmaxf(0.f, tq);      // how far the reference moves up (first: to the exact maximum)
+          const float alpha = __builtin_amdgcn_exp2f(-delta);   // first: l = o = 0, any finite factor will do
+          m[j] += delta;
+          l[j] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { o0[j][i] *= alpha; o1[j][i] *= alpha; s[j][i] -= delta; }
+          if (ahead) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) (*ahead)[j][i] -= delta;
+          }
+          negm[j] = (f32x16)(-m[j]);
+        }
+        first = false;
+      }
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        f32x2 acc2 = (f32x2)(0.f);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {              // packed fp32 add: one VALU slot per score pair
+          f32x2 d;
+          d.x = __builtin_amdgcn_exp2f(s[j][i]); d.y = __builtin_amdgcn_exp2f(s[j][i + 1]);
+          s[j][i] = d.x; s[j][i + 1] = d.y;
+          acc2 += d;
+        }
+        l[j] += acc2.x + acc2.y;
+      }
+    };
+    auto pv = [&](int sub, f32x16 (&s)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const unsigned char* vs = vb + v_lane + (sub * 32 + 16 * st) * VP;
+        const Frag v0 = X::load_vt(vs), v1 = X::load_vt(vs + 32 * ES);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+          const Frag pf = X::pack_p(s[j], st);
+          o0[j] = E::mma(v0, pf, o0[j]);
+          o1[j] = E::mma(v1, pf, o1[j]);
+        }
+      }
+    };
+    if constexpr (PD_ATTN64_PIPE && QB == 2) {      // (dispatch: QB = 2 only with Nkv % 64 == 0)
+      // Round 6, whole 64-key tiles of the two-fragment form: the wave's two query fragments are walked as a two-stage pipeline -- scores of
+      // fragment 0, scores of fragment 1 (4 + 4 MFMAs from the same K fragments), then softmax(0) while the matrix pipe still works on the
+      // scores of 1, PV(0), softmax(1) under PV(0), PV(1).  In the old order (both score chains interleaved, both softmaxes, both PVs) a wave's
+      // own MFMAs and vector work never overlapped -- only the other wave of the SIMD filled the gaps (matrix pipe 0.41 busy, LAB_r6 section 3).
+      // No extra registers: the V^T fragments are read per query fragment (the LDS pipe was 8.5 % busy).
+#pragma unroll
+      for (int sub = 0; sub < KT / 32; ++sub) {
+        Frag kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
+        f32x16 sj[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) sj[j] = E::mma(kf[ks], qf[j][ks], ks == 0 ? negm[j] : sj[j]);
+        const bool was_first = first;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+          f32x16& sc = sj[j];
+          float t = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+          for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, sc[i]), sc[i + 1]);
+          t = fmaxf(t, sc[15]);
+          if (__builtin_amdgcn_ballot_w64(was_first || t > RESCALE_THR) != 0) {
+            const float tq = fmaxf(t, __shfl_xor(t, 32));
+            const float delta = was_first ? tq : fmaxf(0.f, tq);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m[j] += delta;
+            l[j] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[j][i] *= alpha; o1[j][i] *= alpha; sc[i] -= delta; }
+            negm[j] = (f32x16)(-m[j]);
+          }
+          f32x2 acc2 = (f32x2)(0.f);
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            f32x2 d;
+            d.x = __builtin_amdgcn_exp2f(sc[i]); d.y = __builtin_amdgcn_exp2f(sc[i + 1]);
+            sc[i] = d.x; sc[i + 1] = d.y;
+            acc2 += d;
+          }
+          l[j] += acc2.x + acc2.y;
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            const unsigned char* vs = vb + v_lane + (sub * 32 + 16 * st) * VP;
+            const Frag v0 = X::load_vt(vs), v1 = X::load_vt(vs + 32 * ES);
+            const Frag pf = X::pack_p(sc, st);
+            o0[j] = E::mma(v0, pf, o0[j]);
+            o1[j] = E::mma(v1, pf, o1[j]);
+          }
+        }
+        first = false;
+      }
+    } else {
 #pragma unroll
     for (int sub = 0; sub < KT / 32; ++sub) {
       if (k0 + sub * 32 < a.Nkv) {                    // workgroup-uniform
         f32x16 s[QB];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const Frag kf = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
-#pragma unroll
-          for (int j = 0; j < QB; ++j) s[j] = E::mma(kf, qf[j][ks], ks == 0 ? negm[j] : s[j]);     // s = S - m
-        }
+        qk(sub, s);
         if (k0 + sub * 32 + 32 > a.Nkv) {              // keys beyond the context length
 #pragma unroll
           for (int j = 0; j < QB; ++j)
@@ -123,54 +242,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
             for (int i = 0; i < 16; ++i)
               if (k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Nkv) s[j][i] = -INFINITY;
         }
-        float tmax[QB];
-        bool need = first;
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
-          float t = fmaxf(fmaxf(s[j][0], s[j][1]), s[j][2]);   // v_max3_f32 chain
-#pragma unroll
-          for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, s[j][i]), s[j][i + 1]);
-          tmax[j] = fmaxf(t, s[j][15]);
-          need = need || tmax[j] > RESCALE_THR;
-        }
-        if (__builtin_amdgcn_ballot_w64(need) != 0) {
-#pragma unroll
-          for (int j = 0; j < QB; ++j) {
-            const float tq = fmaxf(tmax[j], __shfl_xor(tmax[j], 32));   // finite: every sub-tile visited holds at least one real key
-            const float delta = first ? tq : fmaxf(0.f, tq);      // how far the reference moves up (first: to the exact maximum)
-            const float alpha = __builtin_amdgcn_exp2f(-delta);   // first: l = o = 0, any finite factor will do
-            m[j] += delta;
-            l[j] *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[j][i] *= alpha; o1[j][i] *= alpha; s[j][i] -= delta; }
-            negm[j] = (f32x16)(-m[j]);
-          }
-          first = false;
-        }
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
-          f32x2 acc2 = (f32x2)(0.f);
-#pragma unroll
-          for (int i = 0; i < 16; i += 2) {              // packed fp32 add: one VALU slot per score pair
-            f32x2 d;
-            d.x = __builtin_amdgcn_exp2f(s[j][i]); d.y = __builtin_amdgcn_exp2f(s[j][i + 1]);
-            s[j][i] = d.x; s[j][i + 1] = d.y;
-            acc2 += d;
-          }
-          l[j] += acc2.x + acc2.y;
-        }
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          const unsigned char* vs = vb + v_lane + (sub * 32 + 16 * st) * VP;
-          const Frag v0 = X::load_vt(vs), v1 = X::load_vt(vs + 32 * ES);
-#pragma unroll
-          for (int j = 0; j < QB; ++j) {
-            const Frag pf = X::pack_p(s[j], st);
-            o0[j] = E::mma(v0, pf, o0[j]);
-            o1[j] = E::mma(v1, pf, o1[j]);
-          }
-        }
+        soft(s, nullptr);
+        pv(sub, s);
       }
+    }
     }
     if (k0 + KT < a.Nkv) {
       commit(cur ^ 1);
@@ -312,11 +387,11 @@ extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
     // two query fragments per wave once that still fills the chip (256 CUs x 2 resident workgroups) and the key sequence is
     // long enough for the LDS traffic to matter
     const bool qb1_only = diag_env("PD_ATTN64_QB1", 0) != 0;      // diagnostic: same-box A/B
-    const bool wide = !qb1_only && a->Nkv >= 512 && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
+    const bool wide = !qb1_only && a->Nkv >= 512 && (!PD_ATTN64_PIPE || a->Nkv % 64 == 0) && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
     return wide ? launch_attn_d64<bf16_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<bf16_t, 1>(a, (hipStream_t)stream);
   }
   if (a->dtype == PD_F16) {
-    const bool wide = a->Nkv >= 512 && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
+    const bool wide = a->Nkv >= 512 && (!PD_ATTN64_PIPE || a->Nkv % 64 == 0) && (long long)(a->Nq / 256) * a->heads * a->B >= 1024;
     return wide ? launch_attn_d64<half_t, 2>(a, (hipStream_t)stream) : launch_attn_d64<half_t, 1>(a, (hipStream_t)stream);
   }
   set_error("pd_attn_d64: bad dtype");
