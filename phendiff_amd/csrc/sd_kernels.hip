@@ -12,7 +12,7 @@
 
 namespace pd {
 
-#ifndef PD_ATTN64_PIPE      // 1: both sub-tiles' score MFMAs before the first softmax (attn_d64_kernel); 0: sub-tile by sub-tile (same-box A/B builds)
+#ifndef PD_ATTN64_PIPE      // attn_d64_kernel, two-fragment form.  0: sub-tile by sub-tile; 1: the two query fragments as a two-stage pipeline; 2 (diagnostic builds): + both sub-tiles' scores up front, Q parked in LDS -- parity-green, 912 vs 928 TF/s: the vector issue port binds, not the overlap
 #define PD_ATTN64_PIPE 1
 #endif
 
@@ -67,6 +67,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
       qf[j][ks] = E::pack(v);
     }
   }
+  // PIPE2: the Q fragments live in LDS, each lane reading back exactly the 16-byte slots it wrote ([fragment][k-step][thread]: consecutive lanes,
+  // consecutive slots -- no conflict, no barrier): 32 registers for the second sub-tile's scores (see the key loop)
+  constexpr bool PIPE2 = PD_ATTN64_PIPE >= 2 && QB == 2 && sizeof(T) == 2;
+  unsigned char* qpark = lds + 2 * (KBYTES + VBYTES) + tid * 16;
+  if constexpr (PIPE2) {
+#pragma unroll
+    for (int j = 0; j < QB; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) E::store(qpark + (j * 4 + ks) * 4096, qf[j][ks]);
+  }
+  auto qfrag = [&](int j, int ks) __attribute__((always_inline)) -> Frag {
+    if constexpr (PIPE2) return E::load(qpark + (j * 4 + ks) * 4096);
+    else return qf[j][ks];
+  };
   // Deferred-rescale online softmax (as pd_attn_d8): `m` is a REFERENCE maximum (log2 domain) shared by both lane halves of a
   // query, p = exp2(s - m).  It is only raised when some score of the sub-tile exceeds m + RESCALE_THR (p <= 2^THR
   // otherwise: harmless in fp32 / bf16), so the accumulator rescale (32 multiplies), the cross-half exchange and the second
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
       for (int ks = 0; ks < 4; ++ks) {
         const Frag kf = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
 #pragma unroll
-        for (int j = 0; j < QB; ++j) s[j] = E::mma(kf, qf[j][ks], ks == 0 ? negm[j] : s[j]);     // s = S - m
+        for (int j = 0; j < QB; ++j) s[j] = E::mma(kf, qfrag(j, ks), ks == 0 ? negm[j] : s[j]);     // s = S - m
       }
     };
     // (`ahead`: the scores of the NEXT sub-tile, already computed against the old reference -- a rescale moves them too)
@@ -181,20 +195,33 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
       // scores of 1, PV(0), softmax(1) under PV(0), PV(1).  In the old order (both score chains interleaved, both softmaxes, both PVs) a wave's
       // own MFMAs and vector work never overlapped -- only the other wave of the SIMD filled the gaps (matrix pipe 0.41 busy, LAB_r6 section 3).
       // No extra registers: the V^T fragments are read per query fragment (the LDS pipe was 8.5 % busy).
+      // PIPE2: the scores of BOTH sub-tiles are issued up front (8 + 8 MFMAs; the second sub-tile's run under the first one's softmaxes)
+      f32x16 sall[PIPE2 ? 2 : 1][QB];
+      if constexpr (PIPE2) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const Frag kf1 = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
+#pragma unroll
+            for (int j = 0; j < QB; ++j) sall[sub][j] = E::mma(kf1, qfrag(j, ks), ks == 0 ? negm[j] : sall[sub][j]);
+          }
+      }
 #pragma unroll
       for (int sub = 0; sub < KT / 32; ++sub) {
-        Frag kf[4];
+        if constexpr (!PIPE2) {
+          Frag kf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[ks] = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
-        f32x16 sj[QB];
+          for (int ks = 0; ks < 4; ++ks) kf[ks] = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
 #pragma unroll
-        for (int j = 0; j < QB; ++j)
+          for (int j = 0; j < QB; ++j)
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) sj[j] = E::mma(kf[ks], qf[j][ks], ks == 0 ? negm[j] : sj[j]);
+            for (int ks = 0; ks < 4; ++ks) sall[0][j] = E::mma(kf[ks], qf[j][ks], ks == 0 ? negm[j] : sall[0][j]);
+        }
         const bool was_first = first;
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
-          f32x16& sc = sj[j];
+          f32x16& sc = sall[PIPE2 ? sub : 0][j];
           float t = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
           for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, sc[i]), sc[i + 1]);
@@ -207,6 +234,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
             l[j] *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[j][i] *= alpha; o1[j][i] *= alpha; sc[i] -= delta; }
+            if constexpr (PIPE2) {
+              if (sub == 0) {                    // the second sub-tile's scores were computed against the old reference
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sall[1][j][i] -= delta;
+              }
+            }
             negm[j] = (f32x16)(-m[j]);
           }
           f32x2 acc2 = (f32x2)(0.f);
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const pd_geglu_args a) {
 
 template <typename T, int QB>
 static int launch_attn_d64(const pd_attn_d64_args* a, hipStream_t st) {
-  constexpr int LDS = 2 * 64 * (D64<T>::KP + D64<T>::VP);
+  constexpr int LDS = 2 * 64 * (D64<T>::KP + D64<T>::VP) + ((PD_ATTN64_PIPE >= 2 && QB == 2 && sizeof(T) == 2) ? QB * 4 * 4096 : 0);
   auto kern = attn_d64_kernel<T, QB>;
   static LdsAttr attr;
   if (!ensure_lds(attr, kern, LDS)) {
