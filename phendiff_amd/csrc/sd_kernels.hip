@@ -15,6 +15,15 @@ namespace pd {
 #ifndef PD_ATTN64_PIPE      // attn_d64_kernel, two-fragment form.  0: sub-tile by sub-tile; 1: the two query fragments as a two-stage pipeline; 2 (diagnostic builds): + both sub-tiles' scores up front, Q parked in LDS -- parity-green, 912 vs 928 TF/s: the vector issue port binds, not the overlap
 #define PD_ATTN64_PIPE 1
 #endif
+#ifndef PD_ATTN64_PARKQ     // 1: the Q fragments are parked in LDS (lane-private slots) and re-read per MFMA: 32 registers
+#define PD_ATTN64_PARKQ 0
+#endif
+#ifndef PD_ATTN64_QK_SPLIT
+#define PD_ATTN64_QK_SPLIT 0
+#endif
+#ifndef PD_ATTN64_LAZYMAX   // 1: the pipelined form takes the row maximum only when the lane sums of the probabilities say it has to (0: every sub-tile)
+#define PD_ATTN64_LAZYMAX 1
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Attention, head_dim 64.  Workgroup = 4 waves = 128 queries of one (batch, head); keys/values stream through LDS in
@@ -70,15 +79,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
   // PIPE2: the Q fragments live in LDS, each lane reading back exactly the 16-byte slots it wrote ([fragment][k-step][thread]: consecutive lanes,
   // consecutive slots -- no conflict, no barrier): 32 registers for the second sub-tile's scores (see the key loop)
   constexpr bool PIPE2 = PD_ATTN64_PIPE >= 2 && QB == 2 && sizeof(T) == 2;
+  constexpr bool PARKQ = (PIPE2 || PD_ATTN64_PARKQ) && QB == 2 && sizeof(T) == 2;
   unsigned char* qpark = lds + 2 * (KBYTES + VBYTES) + tid * 16;
-  if constexpr (PIPE2) {
+  if constexpr (PARKQ) {
 #pragma unroll
     for (int j = 0; j < QB; ++j)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) E::store(qpark + (j * 4 + ks) * 4096, qf[j][ks]);
   }
   auto qfrag = [&](int j, int ks) __attribute__((always_inline)) -> Frag {
-    if constexpr (PIPE2) return E::load(qpark + (j * 4 + ks) * 4096);
+    if constexpr (PARKQ) return E::load(qpark + (j * 4 + ks) * 4096);
     else return qf[j][ks];
   };
   // Deferred-rescale online softmax (as pd_attn_d8): `m` is a REFERENCE maximum (log2 domain) shared by both lane halves of a
@@ -210,52 +220,78 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
 #pragma unroll
       for (int sub = 0; sub < KT / 32; ++sub) {
         if constexpr (!PIPE2) {
+#if PD_ATTN64_QK_SPLIT      // diagnostic: the two fragments' score chains one after the other (K fragments held in 16 registers)
           Frag kf[4];
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) kf[ks] = E::load(kb + k_lane + sub * 32 * KP + ks * 16 * ES);
 #pragma unroll
           for (int j = 0; j < QB; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) sall[0][j] = E::mma(kf[ks], qf[j][ks], ks == 0 ? negm[j] : sall[0][j]);
+            for (int ks = 0; ks < 4; ++ks) sall[0][j] = E::mma(kf[ks], qfrag(j, ks), ks == 0 ? negm[j] : sall[0][j]);
+#else
+          qk(sub, sall[0]);
+#endif
         }
         const bool was_first = first;
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
           f32x16& sc = sall[PIPE2 ? sub : 0][j];
-          float t = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+          // Common path WITHOUT the row maximum (16 v_max3 + compares of ~130 vector instructions per sub-tile; the vector issue port is what binds
+          // this kernel): exponentiate against the current reference and look at the lane's SUM of the 16 probabilities, which the row sum needs
+          // anyway -- sum <= 2^15 proves every p <= 2^15 (the deferred-rescale invariant p <= 2^THR); a larger or non-finite sum on any lane sends
+          // the wave to the exact path below, which recomputes the four score MFMAs (K fragments re-read from LDS) and takes the maximum as before.
+          bool exact = was_first || !PD_ATTN64_LAZYMAX;     // the first sub-tile sets the reference to the exact maximum
+          f32x16 pe;                                          // the probabilities (the scores stay intact for the exact path)
+          if (!exact) {
+            f32x2 acc2 = (f32x2)(0.f);
 #pragma unroll
-          for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, sc[i]), sc[i + 1]);
-          t = fmaxf(t, sc[15]);
-          if (__builtin_amdgcn_ballot_w64(was_first || t > RESCALE_THR) != 0) {
-            const float tq = fmaxf(t, __shfl_xor(t, 32));
-            const float delta = was_first ? tq : fmaxf(0.f, tq);
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
-            m[j] += delta;
-            l[j] *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[j][i] *= alpha; o1[j][i] *= alpha; sc[i] -= delta; }
-            if constexpr (PIPE2) {
-              if (sub == 0) {                    // the second sub-tile's scores were computed against the old reference
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sall[1][j][i] -= delta;
-              }
+            for (int i = 0; i < 16; i += 2) {
+              f32x2 d;
+              d.x = __builtin_amdgcn_exp2f(sc[i]); d.y = __builtin_amdgcn_exp2f(sc[i + 1]);
+              pe[i] = d.x; pe[i + 1] = d.y;
+              acc2 += d;
             }
-            negm[j] = (f32x16)(-m[j]);
+            const float a1 = acc2.x + acc2.y;
+            exact = __builtin_amdgcn_ballot_w64(!(a1 <= 32768.0f)) != 0;       // (NaN / inf fail the comparison too)
+            if (!exact) l[j] += a1;
           }
-          f32x2 acc2 = (f32x2)(0.f);
+          if (exact) {
+            float t = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) {
-            f32x2 d;
-            d.x = __builtin_amdgcn_exp2f(sc[i]); d.y = __builtin_amdgcn_exp2f(sc[i + 1]);
-            sc[i] = d.x; sc[i + 1] = d.y;
-            acc2 += d;
+            for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, sc[i]), sc[i + 1]);
+            t = fmaxf(t, sc[15]);
+            float delta = 0.f;
+            if (__builtin_amdgcn_ballot_w64(was_first || t > RESCALE_THR) != 0) {
+              const float tq = fmaxf(t, __shfl_xor(t, 32));
+              delta = was_first ? tq : fmaxf(0.f, tq);
+              const float alpha = __builtin_amdgcn_exp2f(-delta);
+              m[j] += delta;
+              l[j] *= alpha;
+#pragma unroll
+              for (int i = 0; i < 16; ++i) { o0[j][i] *= alpha; o1[j][i] *= alpha; }
+              if constexpr (PIPE2) {
+                if (sub == 0) {                    // the second sub-tile's scores were computed against the old reference
+#pragma unroll
+                  for (int i = 0; i < 16; ++i) sall[1][j][i] -= delta;
+                }
+              }
+              negm[j] = (f32x16)(-m[j]);
+            }
+            f32x2 acc2 = (f32x2)(0.f);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+              f32x2 d;
+              d.x = __builtin_amdgcn_exp2f(sc[i] - delta); d.y = __builtin_amdgcn_exp2f(sc[i + 1] - delta);
+              pe[i] = d.x; pe[i + 1] = d.y;
+              acc2 += d;
+            }
+            l[j] += acc2.x + acc2.y;
           }
-          l[j] += acc2.x + acc2.y;
 #pragma unroll
           for (int st = 0; st < 2; ++st) {
             const unsigned char* vs = vb + v_lane + (sub * 32 + 16 * st) * VP;
             const Frag v0 = X::load_vt(vs), v1 = X::load_vt(vs + 32 * ES);
-            const Frag pf = X::pack_p(sc, st);
+            const Frag pf = X::pack_p(pe, st);
             o0[j] = E::mma(v0, pf, o0[j]);
             o1[j] = E::mma(v1, pf, o1[j]);
           }
@@ -391,7 +427,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const pd_geglu_args a) {
 
 template <typename T, int QB>
 static int launch_attn_d64(const pd_attn_d64_args* a, hipStream_t st) {
-  constexpr int LDS = 2 * 64 * (D64<T>::KP + D64<T>::VP) + ((PD_ATTN64_PIPE >= 2 && QB == 2 && sizeof(T) == 2) ? QB * 4 * 4096 : 0);
+  constexpr int LDS = 2 * 64 * (D64<T>::KP + D64<T>::VP) + (((PD_ATTN64_PIPE >= 2 || PD_ATTN64_PARKQ) && QB == 2 && sizeof(T) == 2) ? QB * 4 * 4096 : 0);
   auto kern = attn_d64_kernel<T, QB>;
   static LdsAttr attr;
   if (!ensure_lds(attr, kern, LDS)) {

@@ -74,7 +74,7 @@ def test_geglu(env, mode):
 
 
 # ---- backward kernels of the Transformer2D blocks: against autograd over plain PyTorch fp32 ---------------------------------
-@pytest.mark.parametrize("mode,shape", [("f32", (2, 3, 320)), ("bf16", (2, 3, 320)), ("bf16", (16, 16, 1024))])   # last: 64 queries per wave
+@pytest.mark.parametrize("mode,shape", [("f32", (2, 3, 320)), ("bf16", (2, 3, 320)), ("bf16", (16, 16, 1024)), ("fp16", (16, 16, 1024))])   # the last two: 64 queries per wave
 def test_attention_d64_deferred_rescale(env, mode, shape):
     """Scores that jump far above the running reference maximum late in the key sequence (and a first tile far BELOW the
     rest) force the rescale branch of the deferred-rescale online softmax; checked against fp64 softmax, lse included."""
@@ -92,6 +92,12 @@ def test_attention_d64_deferred_rescale(env, mode, shape):
     kh[:, :, 290] = qh[:, :, 170] * 6.0
     kh[:, :, 100] = qh[:, :, 319] * 2.5
     kh[:, :, :32] -= 4.0 * qh[:, :, 40:41] / qh[:, :, 40:41].norm(dim=-1, keepdim=True)   # query 40: first sub-tile ~ -32 below the rest
+    if N >= 1024:
+        # round 6 (the two-fragment form takes the row maximum lazily, from the lane sums of the probabilities): a score ~ 160 nats (230 in the
+        # log2 domain) above everything before it -- exp2 overflows to +inf on the lazy path, which must fall back to the exact one --, and one
+        # that only just lifts a lane sum over the 2^15 trigger
+        kh[:, :, 700] = qh[:, :, 900] * 20.0
+        kh[:, :, 901] = qh[:, :, 333] * 1.6
     q, k, v = (bf16_round(t, mode) for t in (q, k, v))
     Q, K, V = (t.to(tdt).to(dev).contiguous() for t in (q, k, v))
     out = torch.full((B, N, Cc), float("nan"), dtype=tdt, device=dev)
@@ -103,6 +109,7 @@ def test_attention_d64_deferred_rescale(env, mode, shape):
     s = torch.einsum("bhid,bhjd->bhij", sp(q).double(), sp(k).double()) / 8
     assert float((s.max(-1).values - s[..., :32].max(-1).values).max()) > 20         # the spikes are real
     ref = (torch.softmax(s, -1) @ sp(v).double()).transpose(1, 2).reshape(B, N, Cc)
+    assert torch.isfinite(out).all()
     assert rel(out.float(), ref) < (1e-5 if mode == "f32" else 1.5e-2)
     assert rel(lse.cpu(), torch.logsumexp(s, -1) * 1.4426950408889634) < (1e-5 if mode == "f32" else 2e-3)
 
