@@ -105,14 +105,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && QB == 1) ? 3 : 2) void attn
   bool first = true;
 
   Frag stk[PIECES], stv[PIECES];
+  // K / V tiles through buffer resources (round 6): per-lane offset fixed, the tile's offset scalar -- no 64-bit vector address arithmetic and no
+  // bounds test per piece (a key past Nkv lies beyond the resource: zeros), ~20 vector instructions per 64-key tile of a kernel bound by that port
+  const unsigned kv_bytes = (unsigned)(((size_t)(a.Nkv - 1) * a.kv_stride + 64) * ES);      // this (batch, head)'s slice ends with its last key's 64 channels
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, kv_bytes, 0x00020000);
+  unsigned kvoff[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) { const int pc = tid + 256 * i; kvoff[i] = (unsigned)(((pc >> 3) * a.kv_stride + (pc & 7) * 8) * ES); }
   auto issue = [&](int k0) {
+    const unsigned so = (unsigned)k0 * (unsigned)a.kv_stride * ES;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int pc = tid + 256 * i, key = k0 + (pc >> 3), sub = pc & 7;
-      if (key < a.Nkv) {
-        stk[i] = E::load(kp + (size_t)key * a.kv_stride + sub * 8);
-        stv[i] = E::load(vp + (size_t)key * a.kv_stride + sub * 8);
-      } else { stk[i] = E::zero(); stv[i] = E::zero(); }
+      stk[i] = E::load_buf(rk, kvoff[i], so);
+      stv[i] = E::load_buf(rv, kvoff[i], so);
     }
   };
   auto commit = [&](int buf) {
@@ -451,6 +457,7 @@ extern "C" int pd_attn_d64(const pd_attn_d64_args* a, void* stream) {
   PD_CHECK(a->q_stride >= a->heads * 64 && a->kv_stride >= a->heads * 64 && a->out_stride >= a->heads * 64 && a->q_stride % 8 == 0 &&
                a->kv_stride % 8 == 0 && a->out_stride % 8 == 0, PD_ERR_SHAPE, "pd_attn_d64: strides must cover heads*64 channels and be multiples of 8");
   PD_CHECK((long long)((a->Nq + 127) / 128) * a->heads * a->B < (1ll << 31), PD_ERR_SHAPE, "pd_attn_d64: grid too large");
+  PD_CHECK((unsigned long long)a->Nkv * (unsigned long long)a->kv_stride * 4ull < (1ull << 32), PD_ERR_SHAPE, "pd_attn_d64: one sample's K / V rows must span < 4 GiB (32-bit buffer offsets)");
   if (a->dtype == PD_F32) return launch_attn_d64<float, 1>(a, (hipStream_t)stream);
   if (a->dtype == PD_BF16) {
     // two query fragments per wave once that still fills the chip (256 CUs x 2 resident workgroups) and the key sequence is
