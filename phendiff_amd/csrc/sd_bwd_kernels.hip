@@ -81,14 +81,19 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
   f32x16 dq0 = (f32x16)(0.f), dq1 = (f32x16)(0.f);
 
   Frag stk[PIECES], stv[PIECES];
+  // (round 6, as pd_attn_d64: tiles through buffer resources -- fixed per-lane offset, scalar tile offset, keys past Nkv read zeros)
+  const unsigned kv_bytes = (unsigned)(((size_t)(a.Nkv - 1) * a.kv_stride + 64) * ES);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, kv_bytes, 0x00020000);
+  unsigned kvoff[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) { const int pc = tid + 256 * i; kvoff[i] = (unsigned)(((pc >> 3) * a.kv_stride + (pc & 7) * 8) * ES); }
   auto issue = [&](int k0) {
+    const unsigned so = (unsigned)k0 * (unsigned)a.kv_stride * ES;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int pc = tid + 256 * i, key = k0 + (pc >> 3), sub = pc & 7;
-      if (key < a.Nkv) {
-        stk[i] = E::load(kp + (size_t)key * a.kv_stride + sub * 8);
-        stv[i] = E::load(vp + (size_t)key * a.kv_stride + sub * 8);
-      } else { stk[i] = E::zero(); stv[i] = E::zero(); }
+      stk[i] = E::load_buf(rk, kvoff[i], so);
+      stv[i] = E::load_buf(rv, kvoff[i], so);
     }
   };
   auto commit = [&](int buf) {
@@ -201,15 +206,22 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
   f32x16 dk0 = (f32x16)(0.f), dk1 = (f32x16)(0.f), dv0 = (f32x16)(0.f), dv1 = (f32x16)(0.f);
 
   Frag stq[PIECES], std_[PIECES];
+  // (round 6: Q / dO tiles through buffer resources, queries past Nq read zeros)
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (unsigned)(((size_t)(a.Nq - 1) * a.q_stride + 64) * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dop, 0, (unsigned)(((size_t)(a.Nq - 1) * a.o_stride + 64) * ES), 0x00020000);
+  unsigned qoff[PIECES], dooff[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int pc = tid + 256 * i;
+    qoff[i] = (unsigned)(((pc >> 3) * a.q_stride + (pc & 7) * 8) * ES);
+    dooff[i] = (unsigned)(((pc >> 3) * a.o_stride + (pc & 7) * 8) * ES);
+  }
   float st_stat = 0.f;                                 // thread t < 64: lse of query t; 64 <= t < 128: delta of query t - 64
   auto issue = [&](int q0) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int pc = tid + 256 * i, qi = q0 + (pc >> 3), sub = pc & 7;
-      if (qi < a.Nq) {
-        stq[i] = E::load(qp + (size_t)qi * a.q_stride + sub * 8);
-        std_[i] = E::load(dop + (size_t)qi * a.o_stride + sub * 8);
-      } else { stq[i] = E::zero(); std_[i] = E::zero(); }
+      stq[i] = E::load_buf(rq, qoff[i], (unsigned)q0 * (unsigned)a.q_stride * ES);
+      std_[i] = E::load_buf(rdo, dooff[i], (unsigned)q0 * (unsigned)a.o_stride * ES);
     }
     if (tid < 128) {
       const int qi = q0 + (tid & 63);
@@ -555,6 +567,8 @@ extern "C" int pd_attn_d64_bwd(const pd_attn_d64_bwd_args* a, void* stream) {
            "pd_attn_d64_bwd: strides must cover heads*64 channels and be multiples of 8");
   PD_CHECK((long long)((a->Nq + 127) / 128) * a->heads * a->B < (1ll << 31) && (long long)a->B * a->Nq * a->heads * 8 / 256 < (1ll << 31),
            PD_ERR_SHAPE, "pd_attn_d64_bwd: grid too large");
+  PD_CHECK((unsigned long long)a->Nkv * (unsigned long long)a->kv_stride * 4ull < (1ull << 32) && (unsigned long long)a->Nq * (unsigned long long)(a->q_stride > a->o_stride ? a->q_stride : a->o_stride) * 4ull < (1ull << 32),
+           PD_ERR_SHAPE, "pd_attn_d64_bwd: one sample's rows must span < 4 GiB (32-bit buffer offsets)");
   if (a->dtype == PD_F32) return launch_attn_d64_bwd<float>(a, (hipStream_t)stream);
   if (a->dtype == PD_BF16) return launch_attn_d64_bwd<bf16_t>(a, (hipStream_t)stream);
   if (a->dtype == PD_F16) return launch_attn_d64_bwd<half_t>(a, (hipStream_t)stream);      // fp16 training (round 5): under the trainer's loss scale
