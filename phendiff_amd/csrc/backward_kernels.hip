@@ -142,23 +142,26 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const pd_gn_bwd_ar
       a.coef[(n * a.groups + tid) * 2] = (float)(r * A / M);
       a.coef[(n * a.groups + tid) * 2 + 1] = (float)(r * Bq / M);
     }
-  } else {   // parameter gradients, one channel per block: the 256 threads share its B x splits terms (round 4: 32 lanes per channel walked
-             // 224 dependent-latency loads each at B = 112 -- 14 us per launch, 287 launches per step), combined in a fixed order
-    const int c = blockIdx.x - a.B;
+  } else {   // parameter gradients: FOUR channels per block (round 6: one channel per block read 16 bytes of every 64-byte sector of the partial --
+             // 16 us per launch for a few hundred KB, 61 launches per SD-2.1 step), 64 term lanes each, combined in a fixed order
+    const int cl = tid & 3, tl = tid >> 2;
+    const int c = (blockIdx.x - a.B) * 4 + cl;
     double d1 = 0.0, d2 = 0.0;
     const int terms = a.B * a.splits;
-    for (int t = tid; t < terms; t += 256) {
-      const double* in = a.partial + ((size_t)t * C + c) * 2;
-      const double wgt = a.mod ? 1.0 + (double)a.mod[(size_t)(t / a.splits) * a.mod_stride + c] : 1.0;     // (1 + scale_n) of the term's sample
-      d1 += wgt * in[0]; d2 += wgt * in[1];
+    if (c < C) {
+      for (int t = tl; t < terms; t += 64) {
+        const double* in = a.partial + ((size_t)t * C + c) * 2;
+        const double wgt = a.mod ? 1.0 + (double)a.mod[(size_t)(t / a.splits) * a.mod_stride + c] : 1.0;     // (1 + scale_n) of the term's sample
+        d1 += wgt * in[0]; d2 += wgt * in[1];
+      }
     }
 #pragma unroll
-    for (int msk = 1; msk < 64; msk <<= 1) { d1 += __shfl_xor(d1, msk); d2 += __shfl_xor(d2, msk); }
-    if ((tid & 63) == 0) { s1[tid >> 6] = d1; s2[tid >> 6] = d2; }
+    for (int msk = 4; msk < 64; msk <<= 1) { d1 += __shfl_xor(d1, msk); d2 += __shfl_xor(d2, msk); }     // the 16 term lanes of this wave that share channel cl
+    if ((tid & 63) < 4) { s1[(tid >> 6) * 4 + cl] = d1; s2[(tid >> 6) * 4 + cl] = d2; }
     __syncthreads();
-    if (tid == 0) {
-      if (a.dbeta) a.dbeta[c] += (float)(((s1[0] + s1[1]) + s1[2]) + s1[3]);
-      if (a.dgamma) a.dgamma[c] += (float)(((s2[0] + s2[1]) + s2[2]) + s2[3]);
+    if (tid < 4 && c < C) {
+      if (a.dbeta) a.dbeta[c] += (float)(((s1[cl] + s1[4 + cl]) + s1[8 + cl]) + s1[12 + cl]);
+      if (a.dgamma) a.dgamma[c] += (float)(((s2[cl] + s2[4 + cl]) + s2[8 + cl]) + s2[12 + cl]);
     }
   }
 }
@@ -441,15 +444,15 @@ extern "C" int pd_gn_silu_bwd(const pd_gn_bwd_args* a, void* stream) {
   const dim3 agrid((unsigned)(a->B * a->splits), (unsigned)((C + GN_CHUNK - 1) / GN_CHUNK));
   if (a->dtype == PD_F32) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, agrid, dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + C), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 3) / 4), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, agrid, dim3(256), 0, st, *a);
   } else if (a->dtype == PD_BF16) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, agrid, dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + C), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 3) / 4), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), 0, st, *a);
   } else if (a->dtype == PD_F16) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<half_t>, agrid, dim3(256), 0, st, *a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + C), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a->B + (C + 3) / 4), dim3(256), 0, st, *a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, agrid, dim3(256), 0, st, *a);
   } else { set_error("pd_gn_silu_bwd: bad dtype"); return PD_ERR_ARG; }
   PD_LAUNCH_CHECK();

@@ -635,7 +635,7 @@ static void token_wgrad_plan(long long M, int K, int N, int esz, int* n_tiles, i
 static void token_wgrad_plan_dma(long long M, int K, int N, int tn, int tk, int* n_tiles, int* k_tiles, int* splits, int* cps, int* nchunks) {
   *n_tiles = (N + tn - 1) / tn; *k_tiles = (K + tk - 1) / tk;
   *nchunks = (int)(M / 32);
-  const int s = token_wgrad_splits(*nchunks, *n_tiles * *k_tiles, 512, 16);   // >= 16 stages (448 KB staged) per slab tile written (160 KB)
+  const int s = token_wgrad_splits(*nchunks, *n_tiles * *k_tiles, diag_env("PD_TW_SLOTS", 512), 16);   // >= 16 stages (448 KB staged) per slab tile written (160 KB)
   *cps = (*nchunks + s - 1) / s;
   *splits = (*nchunks + *cps - 1) / *cps;
 }

@@ -329,21 +329,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
     for (int j = 0; j < 8; ++j) { gam[i][j] = pc < pieces ? a.gamma[pc * 8 + j] : 0.f; dg[i][j] = 0.f; db[i][j] = 0.f; if (DXS) ds[i][j] = 0.f; }
   }
   const float invC = 1.0f / (float)a.C;
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < a.rows; row += (long long)gridDim.x * 4) {
-    const T* x = (const T*)a.x + row * a.C;
-    const T* dy = (const T*)a.dy + row * a.C;
-    float v[NP][8], g[NP][8];
+  // Round 6: the NEXT row's x / dy / res pieces are requested before this row's three dependent reductions (a wave walks its rows one after the
+  // other: with the loads issued at the top of the row, two or three 16-byte loads per lane were all a wave had in flight)
+  typename E::Frag fx[NP], fdy[NP], fres[NP];
+  const long long stride = (long long)gridDim.x * 4;
+  auto fetch = [&](long long row) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int pc = lane + 64 * i;
+      if (pc < pieces) {
+        fx[i] = E::load((const T*)a.x + row * a.C + pc * 8);
+        fdy[i] = E::load((const T*)a.dy + row * a.C + pc * 8);
+        if (a.res) fres[i] = E::load((const T*)a.res + row * a.C + pc * 8);
+      }
+    }
+  };
+  long long row = (long long)blockIdx.x * 4 + wave;
+  if (row < a.rows) fetch(row);
+  for (; row < a.rows; row += stride) {
+    float v[NP][8], g[NP][8], rv[NP][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int pc = lane + 64 * i;
       if (pc < pieces) {
-        E::unpack(E::load(x + pc * 8), v[i]);
-        E::unpack(E::load(dy + pc * 8), g[i]);
+        E::unpack(fx[i], v[i]);
+        E::unpack(fdy[i], g[i]);
+        if (a.res) E::unpack(fres[i], rv[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[i][j];
       }
     }
+    if (row + stride < a.rows) fetch(row + stride);
 #pragma unroll
     for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk);
     const float mean = s * invC;
@@ -375,15 +392,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const pd_layernorm_b
     for (int msk = 32; msk >= 1; msk >>= 1) { sg += __shfl_xor(sg, msk); sgx += __shfl_xor(sgx, msk); }
     const float mg = sg * invC, mgx = sgx * invC;
     T* dx = (T*)a.dx + row * a.C;
-    const T* res = a.res ? (const T*)a.res + row * a.C : nullptr;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int pc = lane + 64 * i;
       if (pc < pieces) {
-        float o[8], rv[8];
-        if (res) E::unpack(E::load(res + pc * 8), rv);
+        float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - mg - v[i][j] * mgx) + (res ? rv[j] : 0.f);
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - mg - v[i][j] * mgx) + (a.res ? rv[i][j] : 0.f);
         const typename E::Frag fo = E::pack(o);
         E::store(dx + pc * 8, fo);
         if constexpr (DXS) {
