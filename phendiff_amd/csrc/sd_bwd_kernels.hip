@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using X = D64<T>;
-  constexpr int KT = 64, VP = X::VP, ES = E::BYTES;
+  using XB = D64B<T>;                                  // tile layout: pd_d64.h (16-bit: 128-byte rows, XOR-swizzled slots)
+  constexpr int KT = 64, VP = XB::P, ES = E::BYTES;
   constexpr int TB = KT * VP;                          // bytes of one [64][64] tile
   constexpr int PIECES = KT * 64 / 8 / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][K tile | V tile]
@@ -101,12 +102,13 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int pc = tid + 256 * i, row = pc >> 3, sub = pc & 7;
-      E::store(kb + row * VP + sub * 8 * ES, stk[i]);
-      E::store(kb + TB + row * VP + sub * 8 * ES, stv[i]);
+      E::store(kb + XB::store_off(row, sub), stk[i]);
+      E::store(kb + TB + XB::store_off(row, sub), stv[i]);
     }
   };
-  const int row_lane = r * VP + 8 * h * ES;            // row fragment: row r, d = 16 ks + 8 h + (0..7)
-  const int t_lane = X::vt_lane_off(lane);
+  const int row_lane0 = XB::row_base(r, h);            // row fragment: row r, d = 16 ks + 8 h + (0..7)
+  const int row_ks[4] = {XB::row_off(row_lane0, 0), XB::row_off(row_lane0, 1), XB::row_off(row_lane0, 2), XB::row_off(row_lane0, 3)};
+  const typename XB::VtOff t_lane = XB::vt_off(lane);
 
   issue(0);
   commit(0);
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
         f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          s = E::mma(E::load(kb + row_lane + sub * 32 * VP + ks * 16 * ES), qf[ks], s);
-          dp = E::mma(E::load(vb + row_lane + sub * 32 * VP + ks * 16 * ES), dof[ks], dp);
+          s = E::mma(E::load(kb + sub * 32 * VP + row_ks[ks]), qf[ks], s);
+          dp = E::mma(E::load(vb + sub * 32 * VP + row_ks[ks]), dof[ks], dp);
         }
         if (k0 + sub * 32 + 32 > a.Nkv) {               // keys beyond the context length (workgroup-uniform): P = 0
 #pragma unroll
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(256) void attn_d64_dq_kernel(const pd_attn_d64_bwd_
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           const Frag df = X::pack_p(s, st);
-          const unsigned char* ks_ = kb + t_lane + (sub * 32 + 16 * st) * VP;
-          dq0 = E::mma(X::load_vt(ks_), df, dq0);
-          dq1 = E::mma(X::load_vt(ks_ + 32 * ES), df, dq1);
+          const unsigned char* ks_ = kb + (sub * 32 + 16 * st) * VP;
+          dq0 = E::mma(XB::load_vt(ks_, t_lane, 0), df, dq0);
+          dq1 = E::mma(XB::load_vt(ks_, t_lane, 1), df, dq1);
         }
       }
     }
@@ -169,7 +171,8 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
   using E = Elem<T>;
   using Frag = typename E::Frag;
   using X = D64<T>;
-  constexpr int QT = 64, VP = X::VP, ES = E::BYTES;
+  using XB = D64B<T>;
+  constexpr int QT = 64, VP = XB::P, ES = E::BYTES;
   constexpr int TB = QT * VP;
   constexpr int BUF = 2 * TB + 2 * QT * 4;             // Q tile | dO tile | lse[64] | delta[64]
   constexpr int PIECES = QT * 64 / 8 / 256;
@@ -233,13 +236,14 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int pc = tid + 256 * i, row = pc >> 3, sub = pc & 7;
-      E::store(qb_ + row * VP + sub * 8 * ES, stq[i]);
-      E::store(qb_ + TB + row * VP + sub * 8 * ES, std_[i]);
+      E::store(qb_ + XB::store_off(row, sub), stq[i]);
+      E::store(qb_ + TB + XB::store_off(row, sub), std_[i]);
     }
     if (tid < 128) ((float*)(qb_ + 2 * TB))[tid] = st_stat;
   };
-  const int row_lane = r * VP + 8 * h * ES;
-  const int t_lane = X::vt_lane_off(lane);
+  const int row_lane0 = XB::row_base(r, h);
+  const int row_ks[4] = {XB::row_off(row_lane0, 0), XB::row_off(row_lane0, 1), XB::row_off(row_lane0, 2), XB::row_off(row_lane0, 3)};
+  const typename XB::VtOff t_lane = XB::vt_off(lane);
 
   issue(0);
   commit(0);
@@ -256,8 +260,8 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
         f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          s = E::mma(E::load(qb_ + row_lane + sub * 32 * VP + ks * 16 * ES), kf[ks], s);     // S[query][key]
-          dp = E::mma(E::load(db + row_lane + sub * 32 * VP + ks * 16 * ES), vf[ks], dp);    // dP[query][key]
+          s = E::mma(E::load(qb_ + sub * 32 * VP + row_ks[ks]), kf[ks], s);     // S[query][key]
+          dp = E::mma(E::load(db + sub * 32 * VP + row_ks[ks]), vf[ks], dp);    // dP[query][key]
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                   // registers 4g..4g+3 <-> queries sub*32 + 8g + 4h + (0..3)
@@ -275,12 +279,12 @@ __global__ __launch_bounds__(256) void attn_d64_dkv_kernel(const pd_attn_d64_bwd
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           const Frag pf = X::pack_p(s, st), df = X::pack_p(dp, st);
-          const unsigned char* dro = db + t_lane + (sub * 32 + 16 * st) * VP;
-          const unsigned char* qro = qb_ + t_lane + (sub * 32 + 16 * st) * VP;
-          dv0 = E::mma(X::load_vt(dro), pf, dv0);
-          dv1 = E::mma(X::load_vt(dro + 32 * ES), pf, dv1);
-          dk0 = E::mma(X::load_vt(qro), df, dk0);
-          dk1 = E::mma(X::load_vt(qro + 32 * ES), df, dk1);
+          const unsigned char* dro = db + (sub * 32 + 16 * st) * VP;
+          const unsigned char* qro = qb_ + (sub * 32 + 16 * st) * VP;
+          dv0 = E::mma(XB::load_vt(dro, t_lane, 0), pf, dv0);
+          dv1 = E::mma(XB::load_vt(dro, t_lane, 1), pf, dv1);
+          dk0 = E::mma(XB::load_vt(qro, t_lane, 0), df, dk0);
+          dk1 = E::mma(XB::load_vt(qro, t_lane, 1), df, dk1);
         }
       }
     }
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256) void token_embedding_grad_kernel(const pd_toke
 
 template <typename T>
 static int launch_attn_d64_bwd(const pd_attn_d64_bwd_args* a, hipStream_t st) {
-  constexpr int TB = 64 * D64<T>::VP;
+  constexpr int TB = 64 * D64B<T>::P;
   constexpr int LDS_DQ = 2 * 2 * TB, LDS_DKV = 2 * (2 * TB + 2 * 64 * 4);
   auto kq = attn_d64_dq_kernel<T>;
   auto kkv = attn_d64_dkv_kernel<T>;
