@@ -42,6 +42,10 @@
 #ifndef PD_CONV_AR8_64   // ... of the 64-pixel tile (8 x 8 images)
 #define PD_CONV_AR8_64 PD_CONV_AR8
 #endif
+#ifndef PD_CONV_RMAP     // 1: bank-conflict-free row order of the 8 x 8 tile's fragments (conv_kernel RMAP) -- diagnostic builds: parity-green, neutral as an op
+                         // (94.2 vs 94.4 us, 176 vs 177 us) and on SD img2img (9.943 vs 9.948): the LDS pipe was never what this tile waited for
+#define PD_CONV_RMAP 0
+#endif
 #ifndef PD_CONV_M16
 #define PD_CONV_M16 1
 #endif
@@ -348,6 +352,12 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
   };
 
   // ---- per-lane LDS read bases for the B (activation) fragments
+  // RMAP (round 6, the 8 x 8 tile = 8 x 8 images): the four 8-pixel rows of fragment fi are tile rows {0, 4, 1, 5} + 2 fi instead of 4 fi + {0..3}.  A 16-lane pass
+  // of the ds_read_b128 then covers halo-tile pixels 10 y + (0..7) and 10 (y + 4) + (0..7) = 16 different residues mod 16 (the 144-byte pixel pitch repeats
+  // its banks every 16 pixels); rows y and y + 1 put pixels p and p + 16 into one pass: every pass ran twice (PMC: conflict cycles 0.64 of the LDS-active
+  // cycles of this instantiation, by far the most conflicted kernel of the SD workloads).  Only the lane -> pixel map changes (here and in the epilogue).
+  constexpr bool RMAP = PD_CONV_RMAP && TH == 8 && TW == 8 && KS == 3 && STRIDE == 1 && !STACK;
+  auto frag_row = [&](int fi, int q) { return RMAP ? (q >> 1) + 4 * (q & 1) + 2 * fi : fi * RPF + q; };     // tile row of 8-pixel run q of fragment fi
   const int li = lane & 15, lg = lane >> 4;          // M16: row / column within a 16 x 16 operand, k group
   constexpr int TJ_STEP = (TW >= 32 ? 16 : IN_TW) * PITCH;   // M16: bytes from the first to the second 16-pixel run of a fragment
   int rbase[NF];
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
       // one VGPR: fragment f is a compile-time distance from fragment 0 (folded into the ds_read offset field)
       rbase[f] = f == 0 ? ((wp * NF * RPF) * IN_TW + li) * PITCH + lg * 8 * E::BYTES : 0;
     } else {
-      const int py = fi * RPF + r / TW, px = r % TW;
+      const int py = frag_row(fi, r / TW), px = r % TW;
       const int ly = STACK ? py + 2 * (py >> 3) : py * STRIDE;      // STACK: two halo rows between images
       rbase[f] = (ly * IN_TW + px * STRIDE) * PITCH + h * 8 * E::BYTES;
     }
@@ -800,7 +810,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int fi = wp * NF + f;
-      const int oy = y0 + fi * RPF + r / TW, ox = x0 + r % TW;
+      const int oy = y0 + frag_row(fi, r / TW), ox = x0 + r % TW;
       if (oy >= p.Hout || ox >= p.Wout) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -868,7 +878,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS 
     } else {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const int plin = (wp * NF + f) * 32 + r;
+      const int plin = RMAP ? frag_row(wp * NF + f, r / TW) * TW + r % TW : (wp * NF + f) * 32 + r;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         store4((T*)(lds + plin * EP_PITCH) + wc * 32 + 8 * g + 4 * h, acc[cth][f][4 * g], acc[cth][f][4 * g + 1], acc[cth][f][4 * g + 2], acc[cth][f][4 * g + 3]);
