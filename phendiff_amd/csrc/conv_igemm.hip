@@ -42,6 +42,9 @@
 #ifndef PD_CONV_AR8_64   // ... of the 64-pixel tile (8 x 8 images)
 #define PD_CONV_AR8_64 PD_CONV_AR8
 #endif
+#ifndef PD_CONV_TAILPLAIN_WPS   // workgroups per CU the prologue-free convolutions with a fused 1x1 tail are compiled for (0: as the tail-free form, 3 -- where they spill 20 B / lane)
+#define PD_CONV_TAILPLAIN_WPS 0
+#endif
 #ifndef PD_CONV_RMAP     // 1: bank-conflict-free row order of the 8 x 8 tile's fragments (conv_kernel RMAP) -- diagnostic builds: parity-green, neutral as an op
                          // (94.2 vs 94.4 us, 176 vs 177 us) and on SD img2img (9.943 vs 9.948): the LDS pipe was never what this tile waited for
 #define PD_CONV_RMAP 0
@@ -133,7 +136,7 @@ __device__ unsigned long long pd_conv_stamps[4096 * 16];
 // (its GroupNorms are applied by pd_gn_apply), the upsamplers.  The 16 scale / shift registers and the transform are gone, which is what lets
 // the 16x16x32 MFMA form (M16 below) fit the register budgets.
 template <typename T, int KS, int STRIDE, int TH, int TW, bool DB, bool TAIL, int NCO = 1, bool PLAIN = false, int PRO = 0, bool STACK = false>
-__global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : (((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2))) void conv_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : ((TAIL && PLAIN && PD_CONV_TAILPLAIN_WPS) ? PD_CONV_TAILPLAIN_WPS : (((KS == 1 || (KS == 3 && STRIDE == 1 && TH * TW == 256)) && sizeof(T) == 2) ? 3 : 2)))) void conv_kernel(const ConvP p) {
   static_assert(PRO == 0 || (!PLAIN && DB && KS == 3 && STRIDE == 1 && sizeof(T) == 2), "compile-time prologue: 16-bit 3x3 stride-1 double-buffered launches");   // 1x1: fits 168 registers without spilling -> 3 workgroups per CU
   static_assert(!TAIL || (DB && KS == 3 && STRIDE == 1), "fused shortcut tail: 3x3 stride-1 double-buffered variant only");
   static_assert(NCO == 1 || (NCO == 2 && DB && KS == 3 && STRIDE == 1), "two output tiles per workgroup: 3x3 stride-1 double-buffered variant only");
