@@ -42,6 +42,10 @@
 #ifndef PD_CONV_AR8_64   // ... of the 64-pixel tile (8 x 8 images)
 #define PD_CONV_AR8_64 PD_CONV_AR8
 #endif
+#ifndef PD_CONV_PIXMAP16   // 1: staging pieces dealt to the lanes pixel-fastest (conv_kernel PIXMAP16) -- diagnostic builds: removes the LDS store conflicts and is
+                           // 1.5 % SLOWER on the headline (15.25 vs 15.48 images/s, same box): a 16-lane group of the global load then touches 16 lines instead of 4
+#define PD_CONV_PIXMAP16 0
+#endif
 #ifndef PD_CONV_TAILPLAIN_WPS   // workgroups per CU the prologue-free convolutions with a fused 1x1 tail are compiled for (0: as the tail-free form, 3 -- where they spill 20 B / lane)
 #define PD_CONV_TAILPLAIN_WPS 0
 #endif
@@ -216,7 +220,14 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : ((TAIL
   const __amdgpu_buffer_rsrc_t rt1 = __builtin_amdgcn_make_buffer_rsrc((void*)((TAIL && p.t1) ? p.t1 : p.x0), 0, (TAIL && p.t1) ? p.tbytes1 : p.bytes0, 0x00020000);
 
   // ---- staging bookkeeping: this thread's pieces (pixel, 8-channel sub-block)
-  const int sub = tid & 3;
+  // Round 6: which (pixel, 8-channel sub-block) piece a thread stages.  Per 64 lanes the pieces are the same 16 pixels x 4 sub-blocks either way (same global
+  // lines), but with lane = 4 pixel + sub a 16-lane pass of the LDS store covers 4 pixels x 64 B, and at the 144-byte (and 80-byte) pixel pitch pixels p and
+  // p + 2 overlap in 8 banks: every store pass ran twice (PMC: 19-28 % of the convolutions' LDS-active cycles were conflict cycles).  lane = 16 sub + pixel puts
+  // 16 different pixels' same sub-block into a pass: 36 p mod 64 = 16 different multiples of 4, conflict-free.  (The 160-byte pitch of the 16x16x32 form repeats
+  // every 8 pixels: it keeps the old map.)
+  constexpr bool PIXMAP16 = PD_CONV_PIXMAP16 && !M16;
+  const int sub = PIXMAP16 ? (tid >> 4) & 3 : tid & 3;
+  auto stage_pix = [&](int i) { return PIXMAP16 ? ((tid >> 6) + 4 * i) * 16 + (tid & 15) : (tid + 256 * i) >> 2; };
   const int Hc = p.upsample ? p.Hin * 2 : p.Hin;
   const int Wc = p.upsample ? p.Win * 2 : p.Win;
   int spix[NIT];   // linear source pixel index (n, sy, sx) or -1 (zero padding / no such piece)
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : ((TAIL
   const int iy_base = y0 * STRIDE - p.pad, ix_base = x0 * STRIDE - p.pad_x, n_base = n * p.Hin * istep + p.in_oy;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int pix = (tid + 256 * i) >> 2;
+    const int pix = stage_pix(i);
     const int u = pix / IN_TW, vv = pix - u * IN_TW;
     const int sj = STACK ? u / 10 : 0, su = u - sj * 10;         // STACK: image within the tile, row within its 10-row halo block
     const int iy = STACK ? su - 1 : iy_base + u, ix = ix_base + vv;
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : ((TAIL
   // written again: the per-piece "if (!valid) zero the 8 transformed values" (5 vector instructions per piece, ~6 % of the
   // kernel's vector work by the round-3 instruction counters) becomes an exec-masked store.
   auto write_piece = [&](int i, unsigned char* buf, bool tail_piece = false) {
-    const int pix = (tid + 256 * i) >> 2;
+    const int pix = stage_pix(i);
     if constexpr (PRO) {
       if (TAIL && tail_piece) {          // (compile-time at every call site) a fused-tail chunk is staged as it is
         if (pix < NPIX && spix[i] >= 0) *(u32x4*)(buf + pix * PITCH + sub * 8 * E::BYTES) = Stage<T>::raw(stage[i]);
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : ((TAIL
   auto zero_padding = [&]() {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int pix = (tid + 256 * i) >> 2;
+      const int pix = stage_pix(i);
       if (pix < NPIX && spix[i] < 0) {
         unsigned char* d = lds + pix * PITCH + sub * 8 * E::BYTES;
 #pragma unroll
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(256, NCO == 2 ? 2 : (PRO ? PD_CONV_PRO_WPS : ((TAIL
           else if constexpr (stg == 8) { uint32_t w = po[j]; asm volatile("" : "+v"(w)); po[j] = w; }
           else asm volatile("" : "+v"(pw[j]));
         } else {
-          const int pix = (tid + 256 * i) >> 2;
+          const int pix = stage_pix(i);
           const bool ok = pix < NPIX && spix[i] >= 0;
           *(u32x4*)(ok ? nbuf + pix * PITCH + sub * 8 * E::BYTES : lds + NPIX * PITCH) = NEXT_PLAIN ? Stage<T>::raw(stage[i]) : po;
         }
