@@ -34,7 +34,8 @@ extern "C" {
  * pd_conv_args.phase); 5 = pd_conv_args.phase_in, pd_wgrad_args.phase; 6 = round 5: pd_attn_bwd_args.slab / slab_bytes +
  * pd_attn_d8_bwd_workspace (the one-pass backward); 7 = round 6: pd_gn_bwd_args.mod / mod_stride / dmod (scale_shift ResNet blocks train);
  * pd_resize_tf1, pd_conv_rect, pd_pool2d, pd_fc_f32 (the evaluation metrics' feature extractor); pd_pack_weight_args.dst2 / dst2_ct_stride;
- * 8 = pd_geglu_bwd_args.sums / sum_splits / B, pd_layernorm_bwd_args.dxsum (bias gradients without a pass over dY), pd_upsample_phase_weights. */
+ * 8 = pd_geglu_bwd_args.sums / sum_splits / B, pd_layernorm_bwd_args.dxsum (bias gradients without a pass over dY), pd_upsample_phase_weights,
+ * pd_token_wgrad_args.stage / pd_wgrad_args.stage. */
 #define PD_ABI_VERSION 8
 
 typedef enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_SHAPE = -2, PD_ERR_LAUNCH = -3, PD_ERR_UNSUPPORTED = -4 } pd_status;
@@ -387,6 +388,7 @@ typedef struct {
                                output [B][2 Hout][2 Wout][Cout] (Hout = Hin, Wout = Win) read at its pixels (2 oy + a, 2 ox + b), dw = the 3x3
                                gradient [Cout][C0][3][3]: the phase kernel's tap gradients are added to the 3x3 taps they are sums of (phase 1
                                honours `accumulate`, phases 2-4 always add: run the four in order).  4 / 9 of the FLOPs of upsample = 1. */
+  int stage;                /* (ABI 8) 0: both launches; 1: the GEMM only; 2: the fold of the slab into dw only (as pd_token_wgrad_args.stage) */
 } pd_wgrad_args;
 size_t pd_conv_wgrad_workspace(const pd_wgrad_args* a);
 int pd_conv_wgrad(const pd_wgrad_args* a, void* stream);
@@ -504,6 +506,8 @@ typedef struct {
   const void* dy; int dy_stride;
   float* dw; int accumulate;
   float* slab; size_t slab_bytes;
+  int stage;                /* (ABI 8) 0: both launches.  1: the GEMM only (partial tiles -> slab).  2: the ordered fold of the slab into dw only -- a caller
+                               with one slab per call may run the folds (bandwidth-bound, a few CUs) on a second stream under the next layers' GEMMs */
 } pd_token_wgrad_args;
 int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream);
 size_t pd_token_wgrad_workspace(const pd_token_wgrad_args* a);

@@ -120,7 +120,7 @@ class WgradArgs(C.Structure):
                 ("C0", C.c_int), ("C1", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
                 ("upsample", C.c_int), ("silu", C.c_int), ("x0", vp), ("x1", vp), ("scale", vp), ("shift", vp), ("dy", vp),
                 ("slab", vp), ("slab_bytes", C.c_size_t), ("dw", vp), ("Cout_valid", C.c_int), ("Cin_valid", C.c_int),
-                ("accumulate", C.c_int), ("phase", C.c_int)]
+                ("accumulate", C.c_int), ("phase", C.c_int), ("stage", C.c_int)]
 
 
 class PackWeightArgs(C.Structure):
@@ -149,7 +149,7 @@ class AttnD64Args(C.Structure):
 
 class TokenWgradArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_longlong), ("K", C.c_int), ("N", C.c_int), ("x", vp), ("x_stride", C.c_int), ("dy", vp),
-                ("dy_stride", C.c_int), ("dw", vp), ("accumulate", C.c_int), ("slab", vp), ("slab_bytes", C.c_size_t)]
+                ("dy_stride", C.c_int), ("dw", vp), ("accumulate", C.c_int), ("slab", vp), ("slab_bytes", C.c_size_t), ("stage", C.c_int)]
 
 
 class GnApplyArgs(C.Structure):

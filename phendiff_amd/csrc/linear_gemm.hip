@@ -1238,6 +1238,8 @@ extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
   p.xcd_order = diag_env("PD_TW_XCD", 1) != 0;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(p.splits * p.n_tiles * p.k_tiles);
+  PD_CHECK(a->stage >= 0 && a->stage <= 2, PD_ERR_ARG, "pd_token_wgrad: stage %d", a->stage);
+  if (a->stage == 2) goto fold;
   if (variant != 0) {
     const int rc = variant == 1 ? launch_token_wgrad_dma<bf16_t, 5, 2, 2>(p, st)
                  : variant == 2 ? launch_token_wgrad_dma<bf16_t, 2, 5, 2>(p, st) : launch_token_wgrad_dma<bf16_t, 2, 2, 3>(p, st);
@@ -1258,6 +1260,8 @@ extern "C" int pd_token_wgrad(const pd_token_wgrad_args* a, void* stream) {
     hipLaunchKernelGGL(token_wgrad_kernel<float>, dim3(grid), dim3(256), LDS, st, p);
   }
   PD_LAUNCH_CHECK();
+  if (a->stage == 1) return PD_OK;
+fold:
   hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)((a->K + 255) / 256), (unsigned)a->N), dim3(256), 0, st, (const float*)a->slab, a->dw,
                      p.splits, p.NP, p.KP, a->N, a->K, a->accumulate);
   PD_LAUNCH_CHECK();

@@ -444,8 +444,11 @@ static int launch_wgrad(const pd_wgrad_args* a, hipStream_t st) {
     return PD_ERR_LAUNCH;
   }
   const unsigned grid = (unsigned)((p.nwork + 7) / 8 * 8);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cf::LDS_BYTES, st, p);
-  PD_LAUNCH_CHECK();
+  if (a->stage != 2) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cf::LDS_BYTES, st, p);
+    PD_LAUNCH_CHECK();
+  }
+  if (a->stage == 1) return PD_OK;
   const int cout_v = a->Cout_valid > 0 ? a->Cout_valid : a->Cout, cin_v = a->Cin_valid > 0 ? a->Cin_valid : cin;
   if (splits > 8)     // small weights spread over many pixel splits: parallelise over the splits
     hipLaunchKernelGGL(wgrad_reduce_split_kernel, dim3((unsigned)((size_t)Cf::TAPS * p.COP * p.CIP / 64)), dim3(256), 0, st,
@@ -473,6 +476,7 @@ extern "C" int pd_conv_wgrad(const pd_wgrad_args* a, void* stream) {
   PD_CHECK(a != nullptr, PD_ERR_ARG, "pd_conv_wgrad: null args");
   PD_CHECK(a->dtype == PD_F32 || a->dtype == PD_BF16 || a->dtype == PD_F16, PD_ERR_ARG, "pd_conv_wgrad: bad dtype");
   PD_CHECK(a->B > 0 && a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0, PD_ERR_SHAPE, "pd_conv_wgrad: bad shape");
+  PD_CHECK(a->stage >= 0 && a->stage <= 2, PD_ERR_ARG, "pd_conv_wgrad: stage %d", a->stage);
   PD_CHECK(a->C0 > 0 && a->C0 % 32 == 0 && a->C1 >= 0 && a->C1 % 32 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: C0=%d C1=%d must be multiples of 32", a->C0, a->C1);
   PD_CHECK(a->Cout > 0 && a->Cout % 8 == 0, PD_ERR_SHAPE, "pd_conv_wgrad: Cout=%d (channel stride of dy) must be a multiple of 8", a->Cout);
   PD_CHECK(a->phase >= 0 && a->phase <= 4, PD_ERR_ARG, "pd_conv_wgrad: phase %d", a->phase);

@@ -461,11 +461,12 @@ def _copy_into(dst, src):
 class _Op:
     """One kernel launch of the plan; ``flops`` / ``bytes`` are its ALGORITHMIC work (logical shapes, each tensor
     read or written once), used by bench.py's roofline leg."""
-    __slots__ = ("fn", "args", "what", "flops", "bytes", "ctx")
+    __slots__ = ("fn", "args", "what", "flops", "bytes", "ctx", "side")
 
     def __init__(self, fn, args, what, flops=0.0, nbytes=0.0):
         self.fn, self.args, self.what, self.flops, self.bytes = fn, args, what, float(flops), float(nbytes)
         self.ctx = False        # True: depends on the conditioning context only (the SD plan's cross-attention k / v projections)
+        self.side = False       # True (training plans): the fold of a weight-gradient slab -- may run on the plan's second stream
 
 
 class UNetPlan:

@@ -32,6 +32,10 @@ from .unet import CustomCondUNet2DModel, UNetPlan, _Attention, _Op, _PackedWeigh
 
 # diagnostic (same-box A/B): route the 1x1 gradients through pd_conv / pd_conv_wgrad as the 3x3 ones
 _NO_LINEAR_GRADS = bool(os.environ.get("PD_NO_LINEAR_GRADS"))
+# Round 6: every weight-gradient launch is two kernels -- the GEMM that leaves per-split partial tiles in a slab, and the ordered fold of the slab
+# into the fp32 gradient (bandwidth-bound, few workgroups, ~150 + 70 of them per SD-2.1 step).  With ONE slab PER LAUNCH (288 GB of HBM: ~18 GB for the
+# SD-2.1 UNet at B = 32) the folds run on a second stream under the next layers' GEMMs.  PD_WGRAD_SIDE=0: one shared slab, one stream (same-box A/B).
+_WGRAD_SIDE = os.environ.get("PD_WGRAD_SIDE", "1") != "0"
 # diagnostic (same-box A/B): keep the GroupNorm-prologue 1x1 weight gradients on pd_conv_wgrad (round 3 routes them through
 # pd_gn_apply + pd_token_wgrad)
 _NO_PREAPPLY_WGRAD = bool(os.environ.get("PD_NO_PREAPPLY_WGRAD"))
@@ -332,8 +336,7 @@ class UNetTrainPlan(UNetPlan):
             N, M = dy.shape[3], B * h * w
             a = L.TokenWgradArgs(dtype=self.code, M=M, K=K, N=N, x=x0.data_ptr(), x_stride=K, dy=dy.data_ptr(), dy_stride=N,
                                  dw=dw.data_ptr(), accumulate=1)
-            self._twgrad_args.append(a)
-            self._b(self.lib.pd_token_wgrad, a, "wgrad_linear", 2.0 * M * K * N, (M * (K + N)) * self._esz() + K * N * 4.0)
+            self._emit_wgrad(self.lib.pd_token_wgrad, a, "wgrad_linear", 2.0 * M * K * N, (M * (K + N)) * self._esz() + K * N * 4.0, self._twgrad_args)
             return
         B, hin, win, c0 = x0.shape
         c1 = x1.shape[3] if x1 is not None else 0
@@ -344,10 +347,29 @@ class UNetTrainPlan(UNetPlan):
                         stride=stride, pad=pad, upsample=upsample, silu=silu, x0=x0.data_ptr(), x1=L.ptr(x1),
                         scale=L.ptr(gn[0]) if gn else None, shift=L.ptr(gn[1]) if gn else None, dy=dy.data_ptr(),
                         dw=dw.data_ptr(), Cout_valid=cout_valid, Cin_valid=cin_valid, accumulate=1, phase=phase)
-        self._wgrad_args.append(a)
         flops = 2.0 * B * hout * wout * cout * (c0 + c1) * ksize * ksize
         nbytes = (x0.numel() + (x1.numel() if x1 is not None else 0) + dy.numel()) * self._esz() + dw.numel() * 4
-        self._b(self.lib.pd_conv_wgrad, a, f"wgrad{ksize}x{ksize}", flops, nbytes)
+        self._emit_wgrad(self.lib.pd_conv_wgrad, a, f"wgrad{ksize}x{ksize}", flops, nbytes, self._wgrad_args)
+
+    def _emit_wgrad(self, fn, a, what, flops, nbytes, arglist):
+        """One weight-gradient launch.  Side mode (``_WGRAD_SIDE``): two ops -- stage 1 (the GEMM) in the main sequence and stage 2 (the fold of its
+        slab into the gradient) flagged ``side``, which :meth:`backward` runs on the plan's second stream; the gradient is final after the fold."""
+        if not _WGRAD_SIDE:
+            arglist.append((a, None))
+            self._b(fn, a, what, flops, nbytes)
+            return
+        a.stage = 1
+        a2 = type(a)()
+        C.memmove(C.byref(a2), C.byref(a), C.sizeof(a))
+        a2.stage = 2
+        arglist.append((a, a2))
+        self._b(fn, a, what, flops, nbytes)
+        main = len(self.bwd_ops) - 1
+        self._b(fn, a2, what + "_fold", 0.0, 0.0)
+        self.bwd_ops[-1].side = True
+        for n, r in self.grad_ready.items():        # "the op at `main` writes this gradient" -> its fold does
+            if r == main:
+                self.grad_ready[n] = main + 1
 
     def _dgrad(self, dy, wpk, cout, *, ksize=3, zero_stuff=False, into=None, tag="dz"):
         """Input gradient of a convolution: ``pd_conv`` over dy with the transposed/flipped weights (1x1: the GEMM kernel
@@ -431,17 +453,24 @@ class UNetTrainPlan(UNetPlan):
         if not self.param_grads:
             return
         self._temb_bwd()
-        # one slab serves every weight-gradient launch (they run back to back on one stream)
-        if self._wgrad_args:            # (none when every convolution weight is frozen: attention-only fine-tuning)
-            need = max(self.lib.pd_conv_wgrad_workspace(C.byref(a)) for a in self._wgrad_args)
-            self.slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
-            for a in self._wgrad_args:
-                a.slab, a.slab_bytes = self.slab.data_ptr(), need
-        if self._twgrad_args:       # likewise for the token-reduction weight gradients of the Linear layers
-            need = max(self.lib.pd_token_wgrad_workspace(C.byref(a)) for a in self._twgrad_args)
-            self.slab_tokens = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
-            for a in self._twgrad_args:
-                a.slab, a.slab_bytes = self.slab_tokens.data_ptr(), need
+        # slabs of the weight-gradient launches: ONE per launch in side mode (its fold runs later, on the second stream), else one shared by all
+        # (they then run back to back on one stream)
+        for pairs, ws in ((self._wgrad_args, self.lib.pd_conv_wgrad_workspace), (self._twgrad_args, self.lib.pd_token_wgrad_workspace)):
+            if not pairs:               # (no convolution weight gradients when every convolution is frozen: attention-only fine-tuning)
+                continue
+            if _WGRAD_SIDE:
+                for a, a2 in pairs:
+                    need = ws(C.byref(a))
+                    slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
+                    self.bufs.append(slab)
+                    a.slab = a2.slab = slab.data_ptr()
+                    a.slab_bytes = a2.slab_bytes = need
+            else:
+                need = max(ws(C.byref(a)) for a, _ in pairs)
+                slab = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device)
+                self.bufs.append(slab)
+                for a, _ in pairs:
+                    a.slab, a.slab_bytes = slab.data_ptr(), need
 
     def _bwd_record(self, rec):
         """Emit the backward launches of one forward tape record."""
@@ -692,20 +721,56 @@ class UNetTrainPlan(UNetPlan):
         labels = getattr(self, "_labels", None)
         emb_at = getattr(self, "_emb_grad_at", -1)
         skip0, skip1 = getattr(self, "_class_mlp_ops", (0, 0)) if not getattr(self, "_class_mlp_ran", False) else (0, 0)
+        side, ms, evs, join = self._side_streams(stream)
+        k, dirty = 0, False
         for i, op in enumerate(self.bwd_ops):
             if skip0 <= i < skip1:            # class MLP (class_embed_type = "timestep") on a step whose rows bypassed it
                 continue
             if i == emb_at and labels is not None:
                 self._emb_grad_args.labels = labels.data_ptr()
                 check(self.lib.pd_embedding_grad(byref(self._emb_grad_args), stream), "pd_embedding_grad")
-            rc = op.fn(byref(op.args), stream)
+            if op.side and side is not None:
+                # the fold of the slab the previous op (its GEMM, on the main stream) just filled: second stream, behind an event
+                ev = evs[k]
+                k += 1
+                ev.record(ms)
+                side.wait_event(ev)
+                rc = op.fn(byref(op.args), side.cuda_stream)
+                dirty = True
+            else:
+                rc = op.fn(byref(op.args), stream)
             if rc:
                 check(rc, op.what)
             if after_op is not None:
                 f = after_op.get(i)
                 if f is not None:
+                    if dirty:                 # a gradient bucket becomes final here: the folds so far belong to it
+                        join.record(side)
+                        ms.wait_event(join)
+                        dirty = False
                     f()
+        if dirty:                             # whoever reads the gradients next does so on the main stream
+            join.record(side)
+            ms.wait_event(join)
         self._keep_dout = dout
+
+    def _side_streams(self, stream):
+        """(second stream, the main stream as a torch object, one event per side op, a join event) -- or (None, ...) when the plan has no side op."""
+        st = getattr(self, "_side_state", None)
+        if st is None:
+            n = sum(1 for op in self.bwd_ops if op.side)
+            if n == 0:
+                st = self._side_state = (None, None, None, None, -1)
+            else:
+                with torch.cuda.device(self.device):
+                    st = self._side_state = (torch.cuda.Stream(self.device), None, [torch.cuda.Event() for _ in range(n)], torch.cuda.Event(), -1)
+        if st[0] is None:
+            return None, None, None, None
+        if st[4] != stream:                   # the main stream as a torch object (cached per handle)
+            cur = torch.cuda.current_stream(self.device)
+            ms = cur if cur.cuda_stream == stream else torch.cuda.ExternalStream(stream, device=self.device)
+            st = self._side_state = (st[0], ms, st[2], st[3], stream)
+        return st[0], st[1], st[2], st[3]
 
 
 def plan_grad_buckets(sizes: List[int], ready: List[int], bucket_elems: int) -> List[Tuple[int, int, int]]:

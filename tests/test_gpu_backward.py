@@ -184,6 +184,19 @@ def run_wgrad(env, mode, x0, dy, *, x1=None, ksize=3, stride=1, pad=1, upsample=
     a.slab, a.slab_bytes = slab.data_ptr(), nbytes
     L.check(lib.pd_conv_wgrad(C.byref(a), stream()), "pd_conv_wgrad")
     torch.cuda.synchronize()
+    # round 6 (ABI 8): every call of this helper also runs the two launches separately -- stage 1 (GEMM -> slab), stage 2 (fold) on a second
+    # stream behind an event -- and wants the same bits
+    dw2 = (prev.clone().to(dev) if prev is not None else torch.full((cov, civ, ksize, ksize), float("nan"), device=dev))
+    slab.fill_(float("nan"))
+    a.dw, a.stage = dw2.data_ptr(), 1
+    L.check(lib.pd_conv_wgrad(C.byref(a), stream()), "pd_conv_wgrad")
+    ev, side = torch.cuda.Event(), torch.cuda.Stream()
+    ev.record(torch.cuda.current_stream())
+    side.wait_event(ev)
+    a.stage = 2
+    L.check(lib.pd_conv_wgrad(C.byref(a), side.cuda_stream), "pd_conv_wgrad")
+    side.synchronize()
+    assert torch.equal(dw2, dw)
     return dw.cpu()
 
 

@@ -344,6 +344,20 @@ def test_token_wgrad(env, mode, cfg, accumulate):
     a.dw = dw2.data_ptr()
     L.check(lib.pd_token_wgrad(C.byref(a), stream()), "pd_token_wgrad")
     assert torch.equal(dw2, dw)
+    # round 6 (ABI 8): the two launches separately -- stage 1 (GEMM -> slab), then stage 2 (fold) on ANOTHER stream behind an event: the same bits
+    dw3 = prev.clone().to(dev) if accumulate else torch.full((N, K), float("nan"), device=dev)
+    slab.fill_(float("nan"))
+    a.dw, a.stage = dw3.data_ptr(), 1
+    L.check(lib.pd_token_wgrad(C.byref(a), stream()), "pd_token_wgrad")
+    ev, side = torch.cuda.Event(), torch.cuda.Stream()
+    ev.record(torch.cuda.current_stream())
+    side.wait_event(ev)
+    a.stage = 2
+    L.check(lib.pd_token_wgrad(C.byref(a), side.cuda_stream), "pd_token_wgrad")
+    side.synchronize()
+    assert torch.equal(dw3, dw)
+    a.stage = 3
+    assert lib.pd_token_wgrad(C.byref(a), stream()) != 0
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "fp16"])
