@@ -236,9 +236,10 @@ class SDUNetTrainPlan(UNetTrainPlan, SDUNetPlan):
             # the gate's backward also leaves the per-split column sums of dff (the widest gradient of the block): the bias gradient folds
             # those (B x splits x 8 ch floats) instead of reading dff back
             gs = max(1, min(64, N // 64))
-            gws = self._tmp((B * gs * 8 * ch,), "geglu_sums", torch.float32)
+            gws = torch.empty((B * gs * 8 * ch,), dtype=torch.float32, device=self.device)      # this block's own (its fold may run on the second stream)
+            self.bufs.append(gws)
             ga.sums, ga.sum_splits, ga.B = gws.data_ptr(), gs, B
-            self._fused_sums[id(dff)] = (gws, gs)
+            self._fused_sums[id(dff)] = (gws, gs, True)
         self._b(self.lib.pd_geglu_bwd, ga, "geglu_bwd", 0.0, 5.0 * dgg.numel() * esz)
         self._bias_grad(dff, G(blk + ".ff.net.0.proj.bias"))
         self._fused_sums.pop(id(dff), None)               # (dff is a scratch buffer other blocks reuse)

@@ -293,11 +293,16 @@ class UNetTrainPlan(UNetPlan):
         fused = self._fused_sums.get(id(dy))
         if fused is not None:
             # the GroupNorm backward that stored the final value of this gradient also left its per-split channel sums
-            ws, splits = fused
+            ws, splits = fused[0], fused[1]
+            # (round 6) sums in a workspace no other launch reuses, no per-sample consumer: the fold may run on the second stream with the slab folds
+            side = _WGRAD_SIDE and per_sample is None and len(fused) > 2 and fused[2]
+            if side:
+                out = self._tmp((B, ch), "chsum_side", torch.float32)
             a = L.ChannelSumArgs(dtype=self.code, B=B, HW=h * w, C=ch, x=None, out=out.data_ptr(), out_stride=per_stride or ch,
                                  accumulate=0, total=total.data_ptr(), total_valid=valid or ch, workspace=ws.data_ptr(),
                                  splits=splits)
             self._b(self.lib.pd_channel_sum, a, "channel_sum_fused", 0.0, B * splits * ch * 4.0)
+            self.bwd_ops[-1].side = bool(side)
             return
         splits = max(1, min(64, (h * w) // 64))
         ws = self._tmp((B * splits * ch,), "chsum_ws", torch.float32)
@@ -435,7 +440,7 @@ class UNetTrainPlan(UNetPlan):
             self.bufs.append(st)
             setattr(a, fld, st.data_ptr())
             self._sum_owner[id(src)] = (a, fld)
-            self._fused_sums[id(gb[0])] = (st, splits)
+            self._fused_sums[id(gb[0])] = (st, splits, True)       # (`st` belongs to this launch alone)
         n = B * h * w * (c0 + c1)
         self._b(self.lib.pd_gn_silu_bwd, a, "gn_silu_bwd", 0.0, n * self._esz() * (5 + (1 if res is not None else 0)))
 
