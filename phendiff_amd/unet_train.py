@@ -727,6 +727,12 @@ class UNetTrainPlan(UNetPlan):
         emb_at = getattr(self, "_emb_grad_at", -1)
         skip0, skip1 = getattr(self, "_class_mlp_ops", (0, 0)) if not getattr(self, "_class_mlp_ran", False) else (0, 0)
         side, ms, evs, join = self._side_streams(stream)
+        if after_op is not None or _data_parallel():
+            # data-parallel run (gradient buckets are handed to the exchange on its own stream): the folds stay on the main stream, right behind
+            # their GEMMs -- the launch order of rounds 1-5, in every step of the run (so that a step without the exchange, bench.py's
+            # `step_ms_no_comm`, is the same program).  (Two ranks on ONE card over gloo, the only N > 1 run this box allows, were 15 x slower with
+            # three streams per process; nothing says RCCL on separate cards would be, nothing here can show it.)
+            side = None
         k, dirty = 0, False
         for i, op in enumerate(self.bwd_ops):
             if skip0 <= i < skip1:            # class MLP (class_embed_type = "timestep") on a step whose rows bypassed it
@@ -776,6 +782,11 @@ class UNetTrainPlan(UNetPlan):
             ms = cur if cur.cuda_stream == stream else torch.cuda.ExternalStream(stream, device=self.device)
             st = self._side_state = (st[0], ms, st[2], st[3], stream)
         return st[0], st[1], st[2], st[3]
+
+
+def _data_parallel() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def plan_grad_buckets(sizes: List[int], ready: List[int], bucket_elems: int) -> List[Tuple[int, int, int]]:
